@@ -1,0 +1,101 @@
+"""ctypes binding of tools/fastq_gen.c - deterministic synthetic FASTQ (test / bench input only).
+
+Records are pure functions of (seed, index), so the GPU box regenerates exactly the inputs whose
+reference manifests were produced in the build container (tests/golden/manifest_*.json).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SRC = os.path.join(_ROOT, "tools", "fastq_gen.c")
+_SO = os.path.join(_ROOT, "tools", "libfastq_gen.so")
+
+
+class _Params(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("first_index", ctypes.c_uint64), ("style", ctypes.c_uint32),
+                ("len_min", ctypes.c_uint32), ("len_max", ctypes.c_uint32), ("qual_model", ctypes.c_uint32),
+                ("n_rate_ppm", ctypes.c_uint32), ("n_lowq_pct", ctypes.c_uint32),
+                ("fixed_width", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+@dataclass(frozen=True)
+class GenConfig:
+    seed: int = 1234
+    first_index: int = 1
+    style: int = 0          # 0 ERR005195-like, 1 SRR/HWI, 2 Illumina-1.8 (has a varying text field)
+    len_min: int = 36
+    len_max: int = 36
+    qual_model: int = 0     # 0: 70% 'I' else uniform; 1: geometric below Q38; 2: skewed alphabet
+    n_rate_ppm: int = 0
+    n_lowq_pct: int = 0
+    fixed_width: int = 0
+
+    def c(self) -> _Params:
+        return _Params(self.seed, self.first_index, self.style, self.len_min, self.len_max, self.qual_model,
+                       self.n_rate_ppm, self.n_lowq_pct, self.fixed_width, 0)
+
+
+# The configurations named in BASELINE.json / SURVEY.md section 8(d)
+CFG1 = GenConfig(seed=1234, style=0, len_min=36, len_max=36, qual_model=0)                  # 10 MiB, P=2
+CFG2 = GenConfig(seed=2, style=0, len_min=36, len_max=36, qual_model=0)                     # 1 GB, 36 bp
+CFG3 = GenConfig(seed=3, style=1, len_min=150, len_max=150, qual_model=1, n_rate_ppm=2000, n_lowq_pct=80)
+CFG5 = GenConfig(seed=5, style=2, len_min=36, len_max=200, qual_model=2, n_rate_ppm=2000, n_lowq_pct=80)
+# seekable (every record the same size) variant of CFG2 for multi-rank weak scaling
+CFG2_FIXED = GenConfig(seed=2, style=0, len_min=36, len_max=36, qual_model=0, fixed_width=1,
+                       first_index=10_000_000)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO, _SRC])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build())
+        lib.fq_generate.restype = ctypes.c_uint64
+        lib.fq_generate.argtypes = [ctypes.POINTER(_Params), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                    ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        lib.fq_generate_range.restype = ctypes.c_int
+        lib.fq_generate_range.argtypes = [ctypes.POINTER(_Params), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        lib.fq_fixed_record_size.restype = ctypes.c_uint64
+        lib.fq_fixed_record_size.argtypes = [ctypes.POINTER(_Params)]
+        _lib = lib
+    return _lib
+
+
+def generate(cfg: GenConfig, target_bytes: int = 0, n_records: int = 0, rec0: int = 0) -> np.ndarray:
+    """Whole records from record ``rec0``: up to ``target_bytes`` bytes, or exactly ``n_records``."""
+    lib = _load()
+    cap = target_bytes if target_bytes else n_records * (2 * cfg.len_max + 160)
+    buf = np.empty(cap + 8192, dtype=np.uint8)
+    n = ctypes.c_uint64(0)
+    p = cfg.c()
+    got = lib.fq_generate(ctypes.byref(p), rec0, n_records, target_bytes, buf.ctypes.data, cap + 8192,
+                          ctypes.byref(n))
+    return buf[:got]
+
+
+def record_size(cfg: GenConfig) -> int:
+    p = cfg.c()
+    return int(_load().fq_fixed_record_size(ctypes.byref(p)))
+
+
+def generate_range(cfg: GenConfig, byte_off: int, length: int) -> np.ndarray:
+    """Bytes [byte_off, byte_off+length) of the logical file (fixed-width configs only)."""
+    buf = np.empty(length, dtype=np.uint8)
+    p = cfg.c()
+    rc = _load().fq_generate_range(ctypes.byref(p), byte_off, length, buf.ctypes.data)
+    if rc:
+        raise ValueError(f"configuration is not seekable (rc={rc})")
+    return buf

@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by running the UNMODIFIED reference binary.
+
+Run in the build container only (needs oracle/_ref/phyNGSC from oracle/build_ref.sh and MPICH's
+mpiexec).  For every case it writes
+
+  small/<name>.fastq          the crafted input (committed whole, <= 256 KB each)
+  small/<name>.p<P>.ngsc      the reference's output, threads=1 (the StoreTree static-buffer race,
+                              huffman.cpp:193-194, makes threads>1 unsafe)
+  manifest_<name>.json        for generator-made inputs (10 MB .. 1 GB): generator parameters +
+                              per-(WRID,k) block sha256 + footer scalars of the reference's output
+
+Fixtures are data only: inputs and expected outputs.  The reference itself never travels.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from phyngsc_amd import fastq_gen, ngsc_format  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "phyNGSC")
+MPIEXEC = os.environ.get("MPIEXEC", "/opt/conda/bin/mpiexec")
+SMALL = os.path.join(HERE, "small")
+
+
+def run_ref(fastq_path: str, P: int, out_path: str) -> bool:
+    if os.path.exists(out_path):
+        os.remove(out_path)
+    r = subprocess.run([MPIEXEC, "-np", str(P), REF, fastq_path, out_path, "1"], capture_output=True, text=True,
+                       timeout=3600)
+    ok = r.returncode == 0 and os.path.exists(out_path) and "WARNING" not in r.stdout
+    if not ok:
+        print(f"   reference failed rc={r.returncode}: {r.stdout[-300:]} {r.stderr[-300:]}")
+    return ok
+
+
+# ------------------------------------------------------------------------------------------------
+# crafted small inputs
+# ------------------------------------------------------------------------------------------------
+def rec(title: str, seq: str, qual: str) -> str:
+    assert len(seq) == len(qual)
+    return f"{title}\n{seq}\n+\n{qual}\n"
+
+
+def rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+def rand_qual(rng, n, lo=33, hi=73, p_top=0.7):
+    return "".join(chr(hi) if rng.random() < p_top else chr(rng.randint(lo, hi)) for _ in range(n))
+
+
+def case_err_style(rng, n, L=36, start=1):
+    return "".join(rec(f"@ERR005195.{start + i} BGI-FC30BFTAAXX_5_1_000:{rng.randint(1, 2000)}/2",
+                       rand_seq(rng, L), rand_qual(rng, L)) for i in range(n))
+
+
+def case_n_transfer(rng, n, L=50, mode="transfer"):
+    out = []
+    amb = "NYRWSKMDVHBXU.-"
+    for i in range(n):
+        seq = list(rand_seq(rng, L))
+        qual = list(rand_qual(rng, L))
+        k = rng.choice([0, 0, 1, 2, 5])
+        for _ in range(k):
+            p = rng.randrange(L)
+            seq[p] = rng.choice(amb) if mode != "nonly" else "N"
+            if mode == "transfer" or (mode == "mixed" and rng.random() < 0.7) or mode == "nonly":
+                qual[p] = chr(rng.randint(33, 40))
+            else:
+                qual[p] = chr(rng.randint(41, 73))
+        out.append(rec(f"@SRR1.{i + 1} L:{rng.randint(1, 8)}:{rng.randint(1000, 9999)}", "".join(seq), "".join(qual)))
+    return "".join(out)
+
+
+def case_text_titles(rng, n, L=40, long_field=False):
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "la", "m"]
+    out = []
+    for i in range(n):
+        w = rng.choice(words)
+        tag = "".join(rng.choice("ACGTN") for _ in range(rng.randint(4, 9)))
+        extra = ""
+        if long_field:
+            ln = rng.choice([3, 60, 127, 129, 130, 200, 255])
+            extra = " " + "".join(rng.choice("abcdefghijklmnopqrstuvwxyz0123456789") for _ in range(ln))
+        out.append(rec(f"@read{w}{extra} sample={tag}:{rng.randint(0, 3)}#{i % 7}", rand_seq(rng, L), rand_qual(rng, L)))
+    return "".join(out)
+
+
+def case_numeric_fields(rng, n, L=36):
+    out = []
+    a = 100
+    b = 5_000_000
+    for i in range(n):
+        a += rng.randint(1, 5)          # small positive deltas -> delta coding + Huffman over deltas
+        b += rng.randint(-3000, 9000)   # wide deltas (> 512 distinct) -> plain bit packing
+        lane1 = rng.randint(1, 8)       # small value range, field index 1 (< last vector realloc): no tree
+        lane2 = rng.randint(1, 8)       # same at index 6 (kept num_values): value coding + Huffman
+        big = rng.randint(0, 1_000_000_000)
+        out.append(rec(f"@run:{lane1}:{a}:{b}:{big}:{i // 40}:{lane2}", rand_seq(rng, L), rand_qual(rng, L)))
+    return "".join(out)
+
+
+def case_leading_zero_and_switch(rng, n, L=30):
+    out = []
+    for i in range(n):
+        z = f"{rng.randint(0, 999):03d}"                      # leading zeros -> text (utils.h:107-114)
+        sw = str(rng.randint(10, 99)) if i < n // 2 else rng.choice(["ab", "cd", "12"])  # numeric then text
+        empty = "" if i % 3 else "x"                          # sometimes-empty field
+        out.append(rec(f"@id_{z}_{sw}..{empty},{i}", rand_seq(rng, L), rand_qual(rng, L)))
+    return "".join(out)
+
+
+def case_group_constant(rng, n, L=36):
+    """Text field constant inside 32-record groups, numeric field with constant delta in groups."""
+    out = []
+    v = 1000
+    for i in range(n):
+        g = i // 32
+        tile = f"T{g % 5}x"
+        step = 1 if (g % 3) else rng.randint(1, 2)
+        v += step
+        same = 77 if (g % 2) else rng.randint(70, 80)
+        out.append(rec(f"@{tile}:{v}:{same}:{rng.choice(['aa', 'ab', 'b'])}", rand_seq(rng, L), rand_qual(rng, L)))
+    return "".join(out)
+
+
+def case_const_titles(rng, n, L=36):
+    return "".join(rec("@same title:1/2", rand_seq(rng, L), rand_qual(rng, L)) for _ in range(n))
+
+
+def case_varlen(rng, n, lo=20, hi=120):
+    out = []
+    for i in range(n):
+        L = rng.randint(lo, hi)
+        out.append(rec(f"@v.{i + 1} len={L}", rand_seq(rng, L), rand_qual(rng, L, 33, 126, 0.2)))
+    return "".join(out)
+
+
+def case_alphabets(rng, n, L, seq_alpha, q_lo, q_hi):
+    return "".join(rec(f"@a.{i + 1}", rand_seq(rng, L, seq_alpha), rand_qual(rng, L, q_lo, q_hi, 0.5)) for i in range(n))
+
+
+def small_cases():
+    cases = []
+
+    def add(name, text, ranks):
+        assert len(text) <= 256 * 1024, (name, len(text))
+        cases.append((name, text, ranks))
+
+    rng = random.Random(20261003)
+    add("err_8rec", case_err_style(rng, 8), [2])
+    add("err_62rec", case_err_style(rng, 62), [2])
+    add("err_64rec", case_err_style(rng, 64), [2])
+    add("err_66rec", case_err_style(rng, 66), [2])
+    add("err_200rec_digits", case_err_style(rng, 200, start=950), [2, 3])
+    add("err_2000rec", case_err_style(rng, 2000), [2, 4, 8])
+    add("n_transfer", case_n_transfer(rng, 600, mode="transfer"), [2])
+    add("n_keep", case_n_transfer(rng, 600, mode="keep"), [2])
+    add("n_mixed", case_n_transfer(rng, 900, mode="mixed"), [2, 3])
+    add("n_only", case_n_transfer(rng, 500, mode="nonly"), [2])
+    add("title_text", case_text_titles(rng, 700), [2, 4])
+    add("title_long", case_text_titles(rng, 300, long_field=True), [2])
+    add("title_numeric", case_numeric_fields(rng, 1500), [2, 3])
+    add("title_zero_switch", case_leading_zero_and_switch(rng, 500), [2])
+    add("title_group_const", case_group_constant(rng, 1000), [2, 4])
+    add("title_const", case_const_titles(rng, 301), [2])
+    add("varlen", case_varlen(rng, 800), [2, 5])
+    add("lowercase", case_alphabets(rng, 300, 40, "ACGTacgtn", 33, 73), [2])
+    add("dna_3sym", case_alphabets(rng, 300, 40, "ACG", 33, 73), [2])
+    add("dna_1sym", case_alphabets(rng, 300, 40, "A", 33, 73), [2])
+    add("qual_1sym", case_alphabets(rng, 300, 40, "ACGT", 73, 73), [2])
+    add("qual_2sym", case_alphabets(rng, 300, 40, "ACGT", 72, 73), [2])
+    add("qual_wide", case_alphabets(rng, 1200, 60, "ACGT", 33, 126), [2])
+    return cases
+
+
+# generator-made inputs: (name, GenConfig, target bytes, ranks)
+GEN_CASES = [
+    ("cfg1_10MiB", fastq_gen.CFG1, 10 << 20, [2, 8]),
+    ("cfg2_100MB", fastq_gen.CFG2, 100_000_000, [2, 8]),
+    ("cfg3_150bp_100MB", fastq_gen.CFG3, 100_000_000, [4, 8]),
+    ("cfg5_mixed_60MB", fastq_gen.CFG5, 60_000_000, [8]),
+    ("cfg2_1GB", fastq_gen.CFG2, 1_000_000_000, [8]),
+    ("cfg2fixed_256MB", fastq_gen.CFG2_FIXED, 256 << 20, [8]),
+]
+
+
+def main():
+    only = set(sys.argv[1:])
+    os.makedirs(SMALL, exist_ok=True)
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/phyNGSC missing: run oracle/build_ref.sh first")
+    index = {"small": {}, "generated": {}}
+    for name, text, ranks in small_cases():
+        if only and name not in only and "small" not in only:
+            continue
+        path = os.path.join(SMALL, name + ".fastq")
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        good = []
+        for P in ranks:
+            outp = os.path.join(SMALL, f"{name}.p{P}.ngsc")
+            print(f"[small] {name} P={P}")
+            if run_ref(path, P, outp):
+                good.append(P)
+            elif os.path.exists(outp):
+                os.remove(outp)
+        index["small"][name] = good
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for name, cfg, target, ranks in GEN_CASES:
+            if only and name not in only and "generated" not in only:
+                continue
+            data = fastq_gen.generate(cfg, target_bytes=target)
+            path = os.path.join(tmp, name + ".fastq")
+            data.tofile(path)
+            man = {"generator": cfg.__dict__, "target_bytes": target, "fastq_bytes": int(data.size), "ranks": {}}
+            for P in ranks:
+                outp = os.path.join(tmp, f"{name}.p{P}.ngsc")
+                print(f"[gen] {name} ({data.size} B) P={P}")
+                if run_ref(path, P, outp):
+                    with open(outp, "rb") as f:
+                        man["ranks"][str(P)] = ngsc_format.manifest(f.read())
+                    os.remove(outp)
+            with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
+                json.dump(man, f, indent=1, sort_keys=True)
+            os.remove(path)
+    if not only or "small" in only:
+        with open(os.path.join(HERE, "index.json"), "w") as f:
+            json.dump(index["small"], f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
