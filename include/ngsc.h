@@ -1,0 +1,145 @@
+/*
+ * ngsc.h - C ABI of libngsc_hip.so, the MI355X (gfx950) FASTQ sub-block compression engine.
+ *
+ * Drop-in boundary for the hot path of pcdslab/PHYNGSC (file:line below are into that repository).
+ * The reference exposes no FFI; what its main() calls per sub-block is the tasks.h function set
+ *   AnalyzeTitleFields / AnalyzeDNA / AnalyzeQuality / StoreTitle / StoreDNA / StoreQuality
+ *   (tasks.h:20-42) on top of BitStream (bit_stream.h) and HuffmanEncoder (huffman.h),
+ * driven by the loop phyNGSC.cpp:168-906, plus MakeHeader / MakeFooter (tasks.h:61-65) for the
+ * container.  This library replaces exactly that:
+ *
+ *   ngsc_compress_device()   <- phyNGSC.cpp:113-166 (region split, first-record sync), :254-331
+ *                               (record index), :342-742 (field split, prepass, Analyze*, Store*,
+ *                               info header), :745-755 (sub-block cuts), :793-840 (stream concat),
+ *                               for all sub-blocks of a range of virtual ranks, on the GPU
+ *   ngsc_plan_blocks()       <- phyNGSC.cpp:842-928 (8 MiB block assembly, split sub-blocks)
+ *   ngsc_make_header()       <- MakeHeader, tasks.cpp:1179-1200
+ *   ngsc_make_footer()       <- MakeFooter, tasks.cpp:1104-1176
+ *   ngsc_compress_file()     <- main(), phyNGSC.cpp:30-1076, `<in.fastq> <out.ngsc>` semantics with
+ *                               P virtual ranks instead of `mpiexec -np P`
+ *
+ * Conventions: plain pointers and sizes, no exceptions, every function returns 0 or a negative
+ * NGSC_ERR_* code and never exits the process (the reference printf()s and exit()s).  Device
+ * pointers must be 16-byte aligned.  Input buffers are const: the in-place N-transfer rewrite of
+ * the reference (phyNGSC.cpp:573-588) is recomputed on the fly instead.  A context is bound to one
+ * GPU and one stream; use one context per GPU (contexts are independent and thread-compatible).
+ * There is no CPU fallback: without a HIP device every compute entry point fails with NGSC_ERR_HIP.
+ */
+#ifndef NGSC_H
+#define NGSC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGSC_VERSION 100
+
+enum {
+    NGSC_OK = 0,
+    NGSC_ERR_FORMAT = -1,      /* not 4-line FASTQ with bare '+' lines / quality length != sequence length */
+    NGSC_ERR_FIELDS = -2,      /* title separator count differs inside a sub-block (reference: warning, then UB) */
+    NGSC_ERR_TOOMANY = -3,     /* > 100000 records in one sub-block (reference: warning + overflow) */
+    NGSC_ERR_COLORSPACE = -4,  /* SOLiD colour-space reads (phyNGSC.cpp:473-547): out of scope */
+    NGSC_ERR_RANGE = -5,       /* numeric title field >= 2^31 (reference: int32 wrap) */
+    NGSC_ERR_NOMEM = -6,
+    NGSC_ERR_ARG = -7,
+    NGSC_ERR_UNSUPPORTED = -8, /* engine limit: > 32 title fields, text field > 256 B, code > 26 bits */
+    NGSC_ERR_HIP = -9,         /* HIP runtime / device failure (ngsc_last_hip_error()) */
+    NGSC_ERR_CAPACITY = -10,   /* output buffer too small: ngsc_result_bytes() tells the size needed */
+    NGSC_ERR_IO = -11
+};
+
+#define NGSC_BLOCK_SIZE (8u << 20) /* WRITE_BUFFER_SIZE, defs.h:21 */
+
+typedef struct ngsc_ctx ngsc_ctx;
+
+/* One compressed sub-block (one iteration of phyNGSC.cpp:168-906). Bytes live at d_out + out_off. */
+typedef struct {
+    uint32_t rank;       /* WRID of the virtual rank that owns it */
+    uint32_t n_records;
+    uint64_t win_pos;    /* file offset of its read window */
+    uint64_t wsize;      /* window size (r_buffer_size) */
+    uint64_t out_off;
+    uint32_t info_len, title_len, qual_len, dna_len; /* stream order info|title|quality|DNA */
+    uint32_t max_qlen, max_slen, nsym, nqual, flags, n_fields;
+} ngsc_subblock_t;
+
+typedef struct {
+    uint32_t rank;
+    uint32_t n_subblocks;
+    uint32_t first_subblock; /* index into ngsc_result_subblocks() */
+    int32_t overlap_used;    /* wr_ov_used, phyNGSC.cpp:160 (footer OV) */
+    uint64_t stream_off;     /* the rank's sub-blocks are contiguous in d_out from here */
+    uint64_t stream_bytes;
+} ngsc_rank_t;
+
+/* One output block of a rank: header bytes followed by stream[stream_off, stream_off+payload). */
+typedef struct {
+    uint32_t wrid;
+    uint32_t size;       /* header_len + payload: 8 MiB except the rank's last block */
+    uint32_t header_len;
+    uint32_t payload;
+    uint64_t stream_off; /* offset inside the rank's sub-block stream */
+    uint8_t header[288]; /* MakeHeader bytes: NOSB <= 63 entries of <= 32 bits */
+} ngsc_block_t;
+
+typedef struct {
+    const char *name;
+    double ms;        /* accumulated device time of this kernel (HIP events on the context's stream) */
+    uint32_t launches;
+} ngsc_kernel_time_t;
+
+int ngsc_version(void);
+const char *ngsc_strerror(int code);
+
+int ngsc_ctx_create(int device_id, ngsc_ctx **out);
+void ngsc_ctx_destroy(ngsc_ctx *ctx);
+const char *ngsc_last_hip_error(ngsc_ctx *ctx);
+
+/* Per-kernel device timing (hipEvent pairs around every launch). Off by default. */
+int ngsc_set_profiling(ngsc_ctx *ctx, int enable);
+int ngsc_reset_kernel_times(ngsc_ctx *ctx);
+uint32_t ngsc_get_kernel_times(ngsc_ctx *ctx, ngsc_kernel_time_t *out, uint32_t cap);
+
+/*
+ * Compresses the virtual ranks [rank_lo, rank_hi) of a P-rank run over a FASTQ file of file_size
+ * bytes.  d_buf holds the file bytes [buf_off, buf_off + buf_len) in device memory; it must start
+ * at or before the first rank's region and extend past the last rank's region by the reference's
+ * overlap (500 B) plus one record, or to the end of the file.  buf_len < 4 GiB.
+ * hip_stream: a hipStream_t (e.g. torch's current stream) or NULL for the context's own stream.
+ * On return the stream has been synchronised and d_out[0 .. ngsc_result_bytes()) holds, rank after
+ * rank, every sub-block's info|title|quality|DNA bytes.
+ */
+int ngsc_compress_device(ngsc_ctx *ctx, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
+                         uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap,
+                         void *hip_stream);
+
+uint64_t ngsc_result_bytes(ngsc_ctx *ctx);
+uint32_t ngsc_result_num_subblocks(ngsc_ctx *ctx);
+uint32_t ngsc_result_num_ranks(ngsc_ctx *ctx);
+const ngsc_subblock_t *ngsc_result_subblocks(ngsc_ctx *ctx);
+const ngsc_rank_t *ngsc_result_ranks(ngsc_ctx *ctx);
+
+/* ---- container (host side) ------------------------------------------------------------------- */
+/* Splits one rank's sub-block sizes into 8 MiB blocks (phyNGSC.cpp:842-928). */
+int ngsc_plan_blocks(uint32_t P, uint32_t wrid, const uint32_t *sb_sizes, uint32_t n_sb, ngsc_block_t *blocks,
+                     uint32_t cap, uint32_t *n_blocks);
+uint32_t ngsc_make_header(uint8_t *out, uint32_t wrid, uint32_t bewr, uint32_t bhs, uint32_t beso, uint32_t bcss,
+                          const uint32_t *sbol, uint32_t nosb);
+/* cbo: WRID of every block in physical order; lb_sizes/overlaps: one entry per rank. out >= 64 + bytes(cbo). */
+uint32_t ngsc_make_footer(uint8_t *out, uint32_t P, uint64_t fastq_size, uint32_t n_blocks, uint32_t n_subblocks,
+                          const int32_t *overlaps, const uint32_t *cbo, const uint32_t *lb_sizes);
+
+/*
+ * `<in.fastq> <out.ngsc>` (phyNGSC.cpp:61-108) with P virtual ranks on this context's GPU: reads the
+ * file, uploads it, compresses, assembles blocks in the deterministic order "round k = k-th block of
+ * every rank" and writes blocks + footer.  seconds_out (nullable, 3 doubles): read+H2D, device, D2H+write.
+ */
+int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,248 @@
+"""Host-side mirror of the reference's interface for the sub-block compression path.
+
+The reference is a compiled MPI program: ``mpiexec -np P ./phyNGSC in.fastq out.ngsc T``
+(phyNGSC.cpp:61-108).  Its per-sub-block work (tasks.h:20-42) and container functions
+(MakeHeader / MakeFooter, tasks.h:61-65) run here behind the C ABI of ``libngsc_hip.so``; this
+module only moves buffers (torch tensors in HBM), splits virtual ranks over processes and assembles
+the container.  Names follow the reference: working regions (ranks), sub-blocks, blocks, footer.
+
+There is no CPU fallback: every compute entry point needs the HIP library and a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Block, KernelTime, NgscError, Rank, SubBlock
+
+WINDOW = 1 << 23   # READ_BUFFER_SIZE, defs.h:20
+OVERLAP = 500      # phyNGSC.cpp:48
+
+
+def region_bounds(file_size: int, P: int, rank: int) -> Tuple[int, int]:
+    """[wr_start, wr_end] of a virtual rank (phyNGSC.cpp:113-116), both inclusive."""
+    region = file_size // P
+    start = rank * region
+    end = start + region + OVERLAP - 1 if rank != P - 1 else file_size - 1
+    return start, end
+
+
+def job_byte_range(file_size: int, P: int, rank_lo: int, rank_hi: int, slack: int = 1 << 16) -> Tuple[int, int]:
+    """Byte range [lo, hi) of the file a process must hold to compress ranks [rank_lo, rank_hi)."""
+    lo = region_bounds(file_size, P, rank_lo)[0]
+    hi = min(file_size, region_bounds(file_size, P, rank_hi - 1)[1] + 1 + slack)
+    return lo, hi
+
+
+@dataclass
+class DeviceResult:
+    """Outcome of one ngsc_compress_device() call; the sub-block bytes stay in HBM (``out``)."""
+    total_bytes: int
+    subblocks: List[SubBlock]
+    ranks: List[Rank]
+    out: object  # torch.Tensor (uint8, cuda)
+
+
+class Engine:
+    """One GPU context (ngsc_ctx): grow-only HBM workspace + stream."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        rc = self._L.ngsc_ctx_create(device, ctypes.byref(h))
+        if rc:
+            raise NgscError(rc, "no HIP device: this engine has no CPU fallback")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ngsc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- profiling -------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._L.ngsc_set_profiling(self._h, int(on))
+
+    def reset_kernel_times(self):
+        self._L.ngsc_reset_kernel_times(self._h)
+
+    def kernel_times(self) -> dict:
+        n = self._L.ngsc_get_kernel_times(self._h, None, 0)
+        arr = (KernelTime * max(n, 1))()
+        n = self._L.ngsc_get_kernel_times(self._h, arr, n)
+        return {arr[i].name.decode(): (arr[i].ms, arr[i].launches) for i in range(n)}
+
+    # ---- the hot path ----------------------------------------------------------------------------
+    def compress_device(self, d_in, file_size: int, P: int, rank_lo: int = 0, rank_hi: Optional[int] = None,
+                        buf_off: int = 0, out=None, stream: Optional[int] = None) -> DeviceResult:
+        """Compresses virtual ranks [rank_lo, rank_hi) of a P-rank run.
+
+        d_in: uint8 CUDA tensor holding file bytes [buf_off, buf_off + d_in.numel()).
+        out:  uint8 CUDA tensor for the sub-block bytes (allocated when None).
+        """
+        import torch
+        if rank_hi is None:
+            rank_hi = P
+        assert d_in.is_cuda and d_in.dtype == torch.uint8 and d_in.is_contiguous()
+        if out is None:
+            out = torch.empty(int(d_in.numel() * 0.6) + (16 << 20), dtype=torch.uint8, device=d_in.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        rc = self._L.ngsc_compress_device(self._h, d_in.data_ptr(), d_in.numel(), buf_off, file_size, P, rank_lo,
+                                          rank_hi, out.data_ptr(), out.numel(), ctypes.c_void_p(stream))
+        if rc:
+            raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
+        nsb = self._L.ngsc_result_num_subblocks(self._h)
+        nrk = self._L.ngsc_result_num_ranks(self._h)
+        sp, rp = self._L.ngsc_result_subblocks(self._h), self._L.ngsc_result_ranks(self._h)
+        sbs = [_copy_struct(sp[i]) for i in range(nsb)]
+        rks = [_copy_struct(rp[i]) for i in range(nrk)]
+        return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
+
+    def compress_file(self, in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
+        """``<in.fastq> <out.ngsc>`` on this GPU; returns (read+H2D, device, D2H+write) seconds."""
+        sec = (ctypes.c_double * 3)()
+        rc = self._L.ngsc_compress_file(self._h, in_path.encode(), out_path.encode(), P, sec)
+        if rc:
+            raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
+        return sec[0], sec[1], sec[2]
+
+
+def _copy_struct(s):
+    c = type(s)()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(s), ctypes.sizeof(s))
+    return c
+
+
+# ---- container (host) -----------------------------------------------------------------------------
+def plan_blocks(P: int, wrid: int, sb_sizes: Sequence[int]) -> List[Block]:
+    """8 MiB block split of one rank's sub-block stream (phyNGSC.cpp:842-928)."""
+    L = _lib.lib()
+    n = len(sb_sizes)
+    sizes = (ctypes.c_uint32 * max(n, 1))(*sb_sizes)
+    cap = sum(sb_sizes) // (_lib.BLOCK_SIZE - 4096) + 4
+    blocks = (Block * cap)()
+    nb = ctypes.c_uint32()
+    rc = L.ngsc_plan_blocks(P, wrid, sizes, n, blocks, cap, ctypes.byref(nb))
+    if rc:
+        raise NgscError(rc)
+    return [_copy_struct(blocks[i]) for i in range(nb.value)]
+
+
+def make_footer(P: int, fastq_size: int, n_subblocks: int, overlaps: Sequence[int], cbo: Sequence[int],
+                lb_sizes: Sequence[int]) -> bytes:
+    """MakeFooter (tasks.cpp:1104-1176); cbo = WRID of every block in physical order."""
+    L = _lib.lib()
+    ov = (ctypes.c_int32 * P)(*overlaps)
+    cb = (ctypes.c_uint32 * max(len(cbo), 1))(*cbo)
+    lb = (ctypes.c_uint32 * P)(*lb_sizes)
+    out = (ctypes.c_uint8 * (256 + 4 * len(cbo) + 8 * P))()
+    n = L.ngsc_make_footer(out, P, fastq_size, len(cbo), n_subblocks, ov, cb, lb)
+    return bytes(out[:n])
+
+
+def round_robin_order(blocks_per_rank: Sequence[int]) -> List[Tuple[int, int]]:
+    """Deterministic block order: round k = k-th block of every rank, ranks ascending."""
+    order = []
+    for k in range(max(blocks_per_rank, default=0)):
+        for r, nb in enumerate(blocks_per_rank):
+            if k < nb:
+                order.append((r, k))
+    return order
+
+
+def assemble_container(res: DeviceResult, P: int, fastq_size: int) -> bytes:
+    """Single-process assembly of a complete .ngsc file from a whole-file DeviceResult."""
+    host = res.out[:res.total_bytes].cpu().numpy()
+    assert len(res.ranks) == P
+    rank_blocks = []
+    for rk in res.ranks:
+        sizes = [res.subblocks[rk.first_subblock + k].size for k in range(rk.n_subblocks)]
+        rank_blocks.append(plan_blocks(P, rk.rank, sizes))
+    parts = []
+    cbo = []
+    for r, k in round_robin_order([len(b) for b in rank_blocks]):
+        b = rank_blocks[r][k]
+        base = res.ranks[r].stream_off + b.stream_off
+        parts.append(bytes(b.header[:b.header_len]))
+        parts.append(host[base:base + b.payload].tobytes())
+        cbo.append(r)
+    lb = [bl[-1].size if bl else 0 for bl in rank_blocks]
+    footer = make_footer(P, fastq_size, sum(rk.n_subblocks for rk in res.ranks),
+                         [rk.overlap_used for rk in res.ranks], cbo, lb)
+    return b"".join(parts) + footer
+
+
+def compress_bytes(data, P: int = 8, engine: Optional[Engine] = None, device: int = 0) -> bytes:
+    """FASTQ bytes -> .ngsc bytes through the GPU (upload, compress, assemble)."""
+    import torch
+    eng = engine or Engine(device)
+    arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else np.ascontiguousarray(data)
+    d_in = torch.from_numpy(arr.copy()).to(f"cuda:{eng.device}")
+    res = eng.compress_device(d_in, arr.size, P)
+    torch.cuda.synchronize()
+    return assemble_container(res, P, arr.size)
+
+
+# ---- multi-process (one process per GPU) ------------------------------------------------------------
+def ranks_of_process(P: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous virtual ranks [lo, hi) owned by process ``rank`` of ``world`` (P % world == 0)."""
+    assert P % world == 0, "virtual rank count must be a multiple of the process count"
+    per = P // world
+    return rank * per, (rank + 1) * per
+
+
+def exchange_block_sizes(local_sizes: List[List[int]], local_meta: List[Tuple[int, int]], dist, device=None):
+    """The only cross-GPU step: all-gather of per-rank block sizes + (n_subblocks, overlap_used).
+
+    Replaces MPI_Gather / MPI_Gatherv of phyNGSC.cpp:964, 994 and the arrival-order shared file
+    pointer: every process learns every rank's block sizes and derives the same file offsets.
+    local_sizes: for each local virtual rank the sizes of its blocks; local_meta likewise.
+    Returns (sizes per global rank, meta per global rank) in WRID order.
+    """
+    import torch
+    world = dist.get_world_size()
+    per = len(local_sizes)
+    maxb = max((len(s) for s in local_sizes), default=0)
+    t = torch.tensor([maxb], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    maxb = int(t.item())
+    payload = torch.zeros(per, maxb + 3, dtype=torch.int64, device=device)
+    for i, (s, m) in enumerate(zip(local_sizes, local_meta)):
+        payload[i, 0] = len(s)
+        payload[i, 1] = m[0]
+        payload[i, 2] = m[1]
+        if s:
+            payload[i, 3:3 + len(s)] = torch.tensor(s, dtype=torch.int64)
+    gathered = [torch.zeros_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload)
+    sizes, meta = [], []
+    for g in gathered:
+        g = g.cpu()
+        for i in range(per):
+            nb = int(g[i, 0])
+            sizes.append([int(x) for x in g[i, 3:3 + nb]])
+            meta.append((int(g[i, 1]), int(g[i, 2])))
+    return sizes, meta
+
+
+def file_offsets(sizes_per_rank: Sequence[Sequence[int]]):
+    """Exclusive prefix sum over the deterministic block order -> {(rank, k): file offset}, cbo, end."""
+    off = 0
+    table, cbo = {}, []
+    for r, k in round_robin_order([len(s) for s in sizes_per_rank]):
+        table[(r, k)] = off
+        off += sizes_per_rank[r][k]
+        cbo.append(r)
+    return table, cbo, off

@@ -1,0 +1,238 @@
+// container.cpp - host side of the .ngsc container: 8 MiB block assembly (phyNGSC.cpp:842-928),
+// MakeHeader (tasks.cpp:1179-1200), MakeFooter (tasks.cpp:1104-1176) and the file-to-file driver that
+// stands in for main() (phyNGSC.cpp:30-1076) with P virtual ranks on one GPU.
+//
+// Block order: the reference appends blocks with MPI_File_write_shared in arrival order and records
+// it in the footer's CBO list; any order that keeps each rank's blocks in sequence is a valid file
+// (tasks.cpp:1282-1292).  We use the deterministic order "round k = k-th block of every rank".
+#include "../../include/ngsc.h"
+#include "ngsc_common.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+using namespace ngsc;
+
+extern "C" {
+
+uint32_t ngsc_make_header(uint8_t *out, uint32_t wrid, uint32_t bewr, uint32_t bhs, uint32_t beso, uint32_t bcss,
+                          const uint32_t *sbol, uint32_t nosb)
+{
+    ByteWriter w(out);
+    w.put(wrid, bewr);
+    w.put(bhs, 12);
+    w.put(nosb, 6);
+    w.put(beso, 5);
+    w.put(bcss, 2);
+    for (uint32_t i = 0; i < nosb; ++i) w.put(sbol[i], beso);
+    w.align();
+    return (uint32_t)w.nbytes();
+}
+
+uint32_t ngsc_make_footer(uint8_t *out, uint32_t P, uint64_t fastq_size, uint32_t n_blocks, uint32_t n_subblocks,
+                          const int32_t *overlaps, const uint32_t *cbo, const uint32_t *lb_sizes)
+{
+    uint32_t lb_max = 0, lb_min = 0xffffffffu;
+    int32_t ov_max = overlaps[0];
+    for (uint32_t i = 0; i < P; ++i) {
+        lb_max = std::max(lb_max, lb_sizes[i]);
+        lb_min = std::min(lb_min, lb_sizes[i]);
+        ov_max = std::max(ov_max, overlaps[i]);
+    }
+    // floor(log2(x)) + 1 (tasks.cpp:1108-1118)
+    uint32_t BEPS = floor_log2_plus1(P), BEFS = floor_log2_plus1(fastq_size), BEBS = floor_log2_plus1(n_blocks);
+    uint32_t BESS = floor_log2_plus1(n_subblocks), BELB = floor_log2_plus1(lb_max);
+    uint32_t BEOV = floor_log2_plus1((uint64_t)(ov_max > 0 ? ov_max : 0));
+    uint32_t LBES = lb_max != lb_min ? 0 : 1;
+    ByteWriter w(out);
+    w.put(BEPS, 4); w.put(BEFS, 6); w.put(BEBS, 4); w.put(BESS, 4); w.put(BELB, 5); w.put(BEOV, 4); w.put(LBES, 1);
+    w.put(P, BEPS);
+    if (BEFS > 32) {
+        w.put((uint32_t)(fastq_size >> 32), BEFS - 32);
+        w.put((uint32_t)(fastq_size & 0xffffffffu), 32);
+    } else {
+        w.put((uint32_t)fastq_size, BEFS);
+    }
+    w.put(n_blocks, BEBS);
+    w.put(n_subblocks, BESS);
+    for (uint32_t i = 1; i < P; ++i) w.put((uint32_t)overlaps[i], BEOV);
+    uint32_t cb = ceil_log2(P);  // tasks.cpp:1156
+    for (uint32_t i = 0; i < n_blocks; ++i) w.put(cbo[i], cb);
+    if (!LBES)
+        for (uint32_t i = 0; i < P; ++i) w.put(lb_sizes[i], BELB);
+    w.align();
+    uint32_t len = (uint32_t)w.nbytes();
+    out[len] = (uint8_t)(len >> 8);  // Put2Bytes(footer length), tasks.cpp:1175
+    out[len + 1] = (uint8_t)len;
+    return len + 2;
+}
+
+int ngsc_plan_blocks(uint32_t P, uint32_t wrid, const uint32_t *sb_sizes, uint32_t n_sb, ngsc_block_t *blocks,
+                     uint32_t cap, uint32_t *n_blocks)
+{
+    if (!sb_sizes || !blocks || !n_blocks || P < 2) return NGSC_ERR_ARG;
+    const uint64_t W = NGSC_BLOCK_SIZE;
+    const uint32_t bewr = ceil_log2(P);  // phyNGSC.cpp:163
+    uint32_t sbol[64];
+    uint32_t nsb = 0, beso = 0, bcss = 0, nb = 0;
+    uint64_t written = 0;     // payload bytes in the open block
+    uint64_t stream_pos = 0;  // bytes of the rank's stream already placed in closed blocks + open block
+    uint64_t open_start = 0;  // stream offset where the open block's payload starts
+    for (uint32_t i = 0; i < n_sb; ++i) {
+        uint64_t S = sb_sizes[i];
+        if (nsb >= 63) return NGSC_ERR_UNSUPPORTED;  // NOSB is a 6-bit field
+        sbol[nsb++] = (uint32_t)S;                   // phyNGSC.cpp:843
+        uint32_t mx = 0;
+        for (uint32_t k = 0; k < nsb; ++k) mx = std::max(mx, sbol[k]);
+        beso = floor_log2_plus1(mx);                 // :844
+        uint32_t h = header_size(bewr, beso, nsb);
+        if (written + S + h > W) {                   // :852
+            if (written + h > W) return NGSC_ERR_UNSUPPORTED;  // reference would underflow bytes_fill_buffer
+            bcss |= 1;                               // LSBS
+            uint32_t fill = (uint32_t)(W - (written + h));
+            sbol[nsb - 1] = fill;
+            if (nb >= cap) return NGSC_ERR_CAPACITY;
+            ngsc_block_t &b = blocks[nb++];
+            b.wrid = wrid;
+            b.header_len = ngsc_make_header(b.header, wrid, bewr, h, beso, bcss, sbol, nsb);
+            b.payload = (uint32_t)(written + fill);
+            b.size = b.header_len + b.payload;
+            b.stream_off = open_start;
+            stream_pos += fill;
+            open_start = stream_pos;
+            written = S - fill;
+            stream_pos += written;
+            bcss |= 2;                               // FSBS
+            bcss &= ~1u;
+            nsb = 0;
+            sbol[nsb++] = (uint32_t)written;
+        } else {
+            written += S;
+            stream_pos += S;
+        }
+    }
+    if (written > 0) {                               // :910-928
+        uint32_t h = header_size(bewr, beso, nsb);
+        if (nb >= cap) return NGSC_ERR_CAPACITY;
+        ngsc_block_t &b = blocks[nb++];
+        b.wrid = wrid;
+        b.header_len = ngsc_make_header(b.header, wrid, bewr, h, beso, bcss, sbol, nsb);
+        b.payload = (uint32_t)written;
+        b.size = b.header_len + b.payload;
+        b.stream_off = open_start;
+    }
+    *n_blocks = nb;
+    return NGSC_OK;
+}
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static bool write_all(int fd, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    while (n) {
+        ssize_t w = ::write(fd, b, n);
+        if (w <= 0) return false;
+        b += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out)
+{
+    if (!ctx || !in_path || !out_path || P < 2) return NGSC_ERR_ARG;
+    double t0 = now_s();
+    int fd = ::open(in_path, O_RDONLY);
+    if (fd < 0) return NGSC_ERR_IO;
+    struct stat sbuf;
+    if (fstat(fd, &sbuf) != 0 || sbuf.st_size <= 0) { ::close(fd); return NGSC_ERR_IO; }
+    const uint64_t FS = (uint64_t)sbuf.st_size;
+    if (FS >= 0xFFFFFF00ull) { ::close(fd); return NGSC_ERR_UNSUPPORTED; }  // one job per call: < 4 GiB
+    void *h_in = nullptr;
+    if (hipHostMalloc(&h_in, FS + 64, hipHostMallocDefault) != hipSuccess) { ::close(fd); return NGSC_ERR_HIP; }
+    uint64_t got = 0;
+    while (got < FS) {
+        ssize_t r = ::read(fd, (uint8_t *)h_in + got, (size_t)std::min<uint64_t>(FS - got, 1u << 30));
+        if (r <= 0) break;
+        got += (uint64_t)r;
+    }
+    ::close(fd);
+    if (got != FS) { (void)hipHostFree(h_in); return NGSC_ERR_IO; }
+    void *d_in = nullptr, *d_out = nullptr;
+    uint64_t out_cap = FS + (FS >> 2) + (64u << 20);
+    int rc = NGSC_OK;
+    if (hipMalloc(&d_in, FS + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess) rc = NGSC_ERR_HIP;
+    if (!rc && hipMemcpy(d_in, h_in, FS, hipMemcpyHostToDevice) != hipSuccess) rc = NGSC_ERR_HIP;
+    (void)hipHostFree(h_in);
+    double t1 = now_s();
+    if (!rc) rc = ngsc_compress_device(ctx, d_in, FS, 0, FS, P, 0, P, d_out, out_cap, nullptr);
+    double t2 = now_s();
+    std::vector<uint8_t> host;
+    if (!rc) {
+        uint64_t total = ngsc_result_bytes(ctx);
+        host.resize(total);
+        if (total && hipMemcpy(host.data(), d_out, total, hipMemcpyDeviceToHost) != hipSuccess) rc = NGSC_ERR_HIP;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+
+    const ngsc_subblock_t *sbs = ngsc_result_subblocks(ctx);
+    const ngsc_rank_t *rks = ngsc_result_ranks(ctx);
+    std::vector<std::vector<ngsc_block_t>> rb(P);
+    std::vector<int32_t> ov(P);
+    std::vector<uint32_t> lbs(P);
+    uint32_t n_sub_total = 0, max_blocks = 0, n_blocks_total = 0;
+    for (uint32_t r = 0; r < P; ++r) {
+        std::vector<uint32_t> sizes(rks[r].n_subblocks);
+        for (uint32_t k = 0; k < rks[r].n_subblocks; ++k) {
+            const ngsc_subblock_t &s = sbs[rks[r].first_subblock + k];
+            sizes[k] = s.info_len + s.title_len + s.qual_len + s.dna_len;
+        }
+        uint32_t capb = (uint32_t)(rks[r].stream_bytes / (NGSC_BLOCK_SIZE - 4096)) + 4, nb = 0;
+        rb[r].resize(capb);
+        rc = ngsc_plan_blocks(P, r, sizes.data(), (uint32_t)sizes.size(), rb[r].data(), capb, &nb);
+        if (rc) return rc;
+        rb[r].resize(nb);
+        ov[r] = rks[r].overlap_used;
+        lbs[r] = nb ? rb[r][nb - 1].size : 0;
+        n_sub_total += rks[r].n_subblocks;
+        n_blocks_total += nb;
+        max_blocks = std::max(max_blocks, nb);
+    }
+    int ofd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (ofd < 0) return NGSC_ERR_IO;
+    std::vector<uint32_t> cbo;
+    bool okw = true;
+    for (uint32_t k = 0; k < max_blocks && okw; ++k)
+        for (uint32_t r = 0; r < P && okw; ++r)
+            if (k < rb[r].size()) {
+                const ngsc_block_t &b = rb[r][k];
+                okw = write_all(ofd, b.header, b.header_len) &&
+                      write_all(ofd, host.data() + rks[r].stream_off + b.stream_off, b.payload);
+                cbo.push_back(r);
+            }
+    std::vector<uint8_t> footer(256 + 4 * (size_t)n_blocks_total + 8 * (size_t)P);
+    uint32_t fl = ngsc_make_footer(footer.data(), P, FS, n_blocks_total, n_sub_total, ov.data(), cbo.data(), lbs.data());
+    okw = okw && write_all(ofd, footer.data(), fl);
+    ::close(ofd);
+    double t3 = now_s();
+    if (seconds_out) { seconds_out[0] = t1 - t0; seconds_out[1] = t2 - t1; seconds_out[2] = t3 - t2; }
+    return okw ? NGSC_OK : NGSC_ERR_IO;
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// engine.cpp - host orchestration of the HIP kernels + the C ABI of libngsc_hip.so (include/ngsc.h).
+//
+// One context = one GPU + one stream + a grow-only device workspace.  A call to
+// ngsc_compress_device() runs, for a range of virtual ranks:
+//   sync_first -> nl_count/scan -> [sync: line count] -> nl_write, validate, cuts -> [sync: cut list]
+//   -> title_stats, seq_qual_stats, finalize, title_hist, huffman, measure, scan/layout
+//   -> [sync: sizes] -> memset(out), headers, length table, title pack, quality/DNA pack -> [sync]
+// There is no CPU implementation of any of these stages in this library.
+#include "../../include/ngsc.h"
+#include "ngsc_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+using namespace ngsc;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct KTime {
+    const char *name;
+    double ms = 0;
+    uint32_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct ngsc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    std::string hip_err;
+    bool profiling = false;
+    std::vector<KTime> ktimes;
+    std::vector<hipEvent_t> event_pool;
+
+    // workspace
+    DevBuf small, tiles, recs, persb, zero, slots, misc;
+    // pinned host staging
+    void *h_pin = nullptr;
+    size_t h_pin_cap = 0;
+
+    // results
+    std::vector<ngsc_subblock_t> res_sb;
+    std::vector<ngsc_rank_t> res_rank;
+    uint64_t res_bytes = 0;
+};
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (ctx)->hip_err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return NGSC_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+static int ensure(ngsc_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return NGSC_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return NGSC_OK;
+}
+
+static int ensure_pinned(ngsc_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return NGSC_OK;
+    if (c->h_pin) HIPCHK(c, hipHostFree(c->h_pin));
+    c->h_pin = nullptr;
+    c->h_pin_cap = 0;
+    HIPCHK(c, hipHostMalloc(&c->h_pin, bytes + 4096, hipHostMallocDefault));
+    c->h_pin_cap = bytes + 4096;
+    return NGSC_OK;
+}
+
+// carve helper: 256-byte aligned sub-allocations of one DevBuf
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes)
+    {
+        size_t o = off;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+// ---- profiling ------------------------------------------------------------------------------------
+struct KScope {
+    ngsc_ctx *c;
+    hipStream_t st;
+    int idx = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    KScope(ngsc_ctx *ctx, hipStream_t s, const char *name) : c(ctx), st(s)
+    {
+        if (!c->profiling) return;
+        for (size_t i = 0; i < c->ktimes.size(); ++i)
+            if (c->ktimes[i].name == name || !strcmp(c->ktimes[i].name, name)) idx = (int)i;
+        if (idx < 0) {
+            KTime k;
+            k.name = name;
+            c->ktimes.push_back(k);
+            idx = (int)c->ktimes.size() - 1;
+        }
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        e0 = get();
+        e1 = get();
+        (void)hipEventRecord(e0, st);
+    }
+    ~KScope()
+    {
+        if (idx < 0) return;
+        (void)hipEventRecord(e1, st);
+        c->ktimes[idx].pending.emplace_back(e0, e1);
+        c->ktimes[idx].launches++;
+    }
+};
+
+static void collect_times(ngsc_ctx *c)
+{
+    for (auto &k : c->ktimes) {
+        for (auto &pr : k.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) k.ms += ms;
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        k.pending.clear();
+    }
+}
+
+// ====================================================================================================
+extern "C" {
+
+int ngsc_version(void) { return NGSC_VERSION; }
+
+const char *ngsc_strerror(int code)
+{
+    switch (code) {
+    case NGSC_OK: return "ok";
+    case NGSC_ERR_FORMAT: return "input is not 4-line FASTQ with bare '+' lines and equal sequence/quality lengths";
+    case NGSC_ERR_FIELDS: return "title separator count differs inside a sub-block";
+    case NGSC_ERR_TOOMANY: return "more than 100000 records in one sub-block";
+    case NGSC_ERR_COLORSPACE: return "colour-space (SOLiD) reads are not supported";
+    case NGSC_ERR_RANGE: return "numeric title field out of int32 range";
+    case NGSC_ERR_NOMEM: return "out of memory";
+    case NGSC_ERR_ARG: return "invalid argument";
+    case NGSC_ERR_UNSUPPORTED: return "engine limit exceeded (title fields / text field length / code length)";
+    case NGSC_ERR_HIP: return "HIP runtime error";
+    case NGSC_ERR_CAPACITY: return "output buffer too small";
+    case NGSC_ERR_IO: return "I/O error";
+    default: return "unknown error";
+    }
+}
+
+int ngsc_ctx_create(int device_id, ngsc_ctx **out)
+{
+    if (!out) return NGSC_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return NGSC_ERR_HIP;
+    ngsc_ctx *c = new ngsc_ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        return NGSC_ERR_HIP;
+    }
+    *out = c;
+    return NGSC_OK;
+}
+
+void ngsc_ctx_destroy(ngsc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->persb, &c->zero, &c->slots, &c->misc})
+        if (b->p) (void)hipFree(b->p);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    collect_times(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *ngsc_last_hip_error(ngsc_ctx *c) { return c ? c->hip_err.c_str() : ""; }
+
+int ngsc_set_profiling(ngsc_ctx *c, int enable)
+{
+    if (!c) return NGSC_ERR_ARG;
+    c->profiling = enable != 0;
+    return NGSC_OK;
+}
+
+int ngsc_reset_kernel_times(ngsc_ctx *c)
+{
+    if (!c) return NGSC_ERR_ARG;
+    collect_times(c);
+    for (auto &k : c->ktimes) { k.ms = 0; k.launches = 0; }
+    return NGSC_OK;
+}
+
+uint32_t ngsc_get_kernel_times(ngsc_ctx *c, ngsc_kernel_time_t *out, uint32_t cap)
+{
+    if (!c) return 0;
+    collect_times(c);
+    uint32_t n = 0;
+    for (auto &k : c->ktimes) {
+        if (out && n < cap) { out[n].name = k.name; out[n].ms = k.ms; out[n].launches = k.launches; }
+        ++n;
+    }
+    return n;
+}
+
+uint64_t ngsc_result_bytes(ngsc_ctx *c) { return c ? c->res_bytes : 0; }
+uint32_t ngsc_result_num_subblocks(ngsc_ctx *c) { return c ? (uint32_t)c->res_sb.size() : 0; }
+uint32_t ngsc_result_num_ranks(ngsc_ctx *c) { return c ? (uint32_t)c->res_rank.size() : 0; }
+const ngsc_subblock_t *ngsc_result_subblocks(ngsc_ctx *c) { return c ? c->res_sb.data() : nullptr; }
+const ngsc_rank_t *ngsc_result_ranks(ngsc_ctx *c) { return c ? c->res_rank.data() : nullptr; }
+
+int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
+                         uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream)
+{
+    if (!c || !d_buf || !d_out || P < 2 || rank_lo >= rank_hi || rank_hi > P || !file_size) return NGSC_ERR_ARG;
+    if (buf_len == 0 || buf_len >= 0xFFFFFF00ull || buf_off + buf_len > file_size) return NGSC_ERR_ARG;
+    if (((uintptr_t)d_buf & 15) || ((uintptr_t)d_out & 15)) return NGSC_ERR_ARG;
+    if (file_size / P == 0) return NGSC_ERR_ARG;
+    const uint32_t n_ranks = rank_hi - rank_lo;
+    {
+        RankGeom g0 = rank_geometry(file_size, P, rank_lo), g1 = rank_geometry(file_size, P, rank_hi - 1);
+        if (rank_lo == 0 ? buf_off != 0 : (int64_t)buf_off > g0.wr_start) return NGSC_ERR_ARG;
+        // the buffer must reach the end of the last rank's region (+ the reference's overlap) or EOF
+        uint64_t need_end = (uint64_t)g1.wr_end + 1;
+        if (need_end > file_size) need_end = file_size;
+        if (buf_off + buf_len < need_end) return NGSC_ERR_ARG;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->res_sb.clear();
+    c->res_rank.clear();
+    c->res_bytes = 0;
+    const uint8_t *buf = (const uint8_t *)d_buf;
+    const uint32_t len = (uint32_t)buf_len;
+
+    // ---- small device state ----
+    const uint64_t region = file_size / P;
+    const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
+    Carver cs;
+    size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
+    size_t o_outtot = cs.take(8);
+    size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
+    size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
+    size_t o_cuts = cs.take(sizeof(Cut) * (size_t)n_ranks * max_cuts);
+    int rc = ensure(c, c->small, cs.off);
+    if (rc) return rc;
+    uint8_t *sm = (uint8_t *)c->small.p;
+    int32_t *d_err = (int32_t *)(sm + o_err);
+    uint32_t *d_total = (uint32_t *)(sm + o_total), *d_start = (uint32_t *)(sm + o_start);
+    uint32_t *d_maxq = (uint32_t *)(sm + o_maxq), *d_slotc = (uint32_t *)(sm + o_slotc);
+    uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
+    RankPlan *d_plans = (RankPlan *)(sm + o_plans);
+    Cut *d_cuts = (Cut *)(sm + o_cuts);
+    HIPCHK(c, hipMemsetAsync(sm, 0, o_first, st));
+
+    const uint32_t ntiles = index_num_tiles(len);
+    rc = ensure(c, c->tiles, sizeof(uint32_t) * (size_t)ntiles);
+    if (rc) return rc;
+    uint32_t *d_tiles = (uint32_t *)c->tiles.p;
+
+    // ---- stage A: line index ----
+    {
+        KScope k(c, st, "k_sync_first");
+        launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err);
+    }
+    { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles); }
+    { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
+    rc = ensure_pinned(c, cs.off);
+    if (rc) return rc;
+    uint8_t *hp = (uint8_t *)c->h_pin;
+    HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
+    const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
+    if (!n_rec_total) return NGSC_ERR_FORMAT;
+
+    // record table + per-record arrays
+    const size_t rec_cap = (size_t)n_rec_total + 2;
+    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
+    Carver cr;
+    size_t o_te = cr.take(4 * rec_cap), o_se = cr.take(4 * rec_cap), o_ls = cr.take(4 * (rec_cap + 1));
+    size_t o_slen = cr.take(4 * rec_cap), o_qoff = cr.take(4 * rec_cap), o_doff = cr.take(4 * rec_cap);
+    size_t o_goff = cr.take(4 * grp_cap);
+    rc = ensure(c, c->recs, cr.off);
+    if (rc) return rc;
+    uint8_t *rb = (uint8_t *)c->recs.p;
+    uint32_t *d_te = (uint32_t *)(rb + o_te), *d_se = (uint32_t *)(rb + o_se), *d_ls = (uint32_t *)(rb + o_ls);
+    {
+        KScope k(c, st, "k_nl_write");
+        launch_nl_write(st, buf, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_cap);
+    }
+    {
+        KScope k(c, st, "k_validate");
+        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_err);
+    }
+    {
+        KScope k(c, st, "k_cuts");
+        launch_cuts(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_ls, d_total, d_first, d_cuts, max_cuts, d_plans, d_err);
+    }
+    // ---- sync 2: cut list ----
+    size_t plan_bytes = cs.off - o_plans;
+    HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hp + o_plans, sm + o_plans, plan_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
+    const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
+    const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
+    const Cut *h_cuts = (const Cut *)(hp + o_cuts);
+    std::vector<Cut> cuts;
+    c->res_rank.resize(n_ranks);
+    for (uint32_t i = 0; i < n_ranks; ++i) {
+        ngsc_rank_t &rk = c->res_rank[i];
+        rk.rank = rank_lo + i;
+        rk.n_subblocks = h_plans[i].n_cuts;
+        rk.first_subblock = (uint32_t)cuts.size();
+        rk.overlap_used = h_plans[i].overlap_used;
+        rk.stream_off = rk.stream_bytes = 0;
+        for (uint32_t k = 0; k < h_plans[i].n_cuts; ++k) cuts.push_back(h_cuts[(size_t)i * max_cuts + k]);
+    }
+    const uint32_t S = (uint32_t)cuts.size();
+    if (!S) return NGSC_ERR_FORMAT;
+    const uint32_t qrows = max_q + 1;
+    uint32_t max_rec = 0;
+    for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);
+
+    // ---- per-sub-block arena ----
+    const uint32_t n_slots = std::max<uint32_t>(64, 2 * S);
+    Carver cz;  // zero-initialised every call
+    size_t z_fstat = cz.take(sizeof(FieldStat) * (size_t)S * MAX_FIELDS);
+    size_t z_occ = cz.take(4 * (size_t)S * 256);
+    size_t z_qhist = cz.take(4 * (size_t)S * qrows * 256);
+    size_t z_nhist = cz.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
+    size_t z_chist = cz.take(4 * (size_t)n_slots * TEXT_TREES * 256);
+    rc = ensure(c, c->zero, cz.off);
+    if (rc) return rc;
+    Carver cp;
+    size_t p_sb = cp.take(sizeof(SbState) * (size_t)S);
+    size_t p_fdesc = cp.take(sizeof(FieldDesc) * (size_t)S * MAX_FIELDS);
+    size_t p_grplo = cp.take(4 * (size_t)S);
+    size_t p_qcodes = cp.take(4 * (size_t)S * qrows * 256);
+    size_t p_qblob = cp.take((size_t)S * qrows * BLOB_SLOT_256);
+    size_t p_qblen = cp.take(4 * (size_t)S * qrows);
+    size_t p_qrowoff = cp.take(4 * (size_t)S * qrows);
+    size_t p_dcodes = cp.take(4 * (size_t)S * 256);
+    size_t p_dblob = cp.take((size_t)S * BLOB_SLOT_256);
+    size_t p_dblen = cp.take(4 * (size_t)S);
+    size_t p_ncodes = cp.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
+    size_t p_nblob = cp.take((size_t)S * MAX_FIELDS * BLOB_SLOT_512);
+    size_t p_nblen = cp.take(4 * (size_t)S * MAX_FIELDS);
+    rc = ensure(c, c->persb, cp.off);
+    if (rc) return rc;
+    Carver ct;
+    size_t t_codes = ct.take(4 * (size_t)n_slots * TEXT_TREES * 256);
+    size_t t_blob = ct.take((size_t)n_slots * TEXT_TREES * BLOB_SLOT_256);
+    size_t t_blen = ct.take(4 * (size_t)n_slots * TEXT_TREES);
+    size_t t_owner = ct.take(4 * (size_t)n_slots);
+    rc = ensure(c, c->slots, ct.off);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->zero.p, 0, cz.off, st));
+
+    uint8_t *zb = (uint8_t *)c->zero.p, *pb = (uint8_t *)c->persb.p, *tb = (uint8_t *)c->slots.p;
+    Arena A;
+    memset(&A, 0, sizeof A);
+    A.buf = buf; A.buf_len = len;
+    A.te = d_te; A.se = d_se; A.ls = d_ls;
+    A.slen = (uint32_t *)(rb + o_slen); A.qoff = (uint32_t *)(rb + o_qoff); A.doff = (uint32_t *)(rb + o_doff);
+    A.goff = (uint32_t *)(rb + o_goff);
+    A.grp_lo = (uint32_t *)(pb + p_grplo);
+    A.err = d_err;
+    A.sb = (SbState *)(pb + p_sb);
+    A.fstat = (FieldStat *)(zb + z_fstat);
+    A.fdesc = (FieldDesc *)(pb + p_fdesc);
+    A.dna_occ = (uint32_t *)(zb + z_occ);
+    A.qhist = (uint32_t *)(zb + z_qhist);
+    A.nhist = (uint32_t *)(zb + z_nhist);
+    A.qcodes = (uint32_t *)(pb + p_qcodes);
+    A.qblob = pb + p_qblob;
+    A.qblob_len = (uint32_t *)(pb + p_qblen);
+    A.dcodes = (uint32_t *)(pb + p_dcodes);
+    A.dblob = pb + p_dblob;
+    A.dblob_len = (uint32_t *)(pb + p_dblen);
+    A.ncodes = (uint32_t *)(pb + p_ncodes);
+    A.nblob = pb + p_nblob;
+    A.nblob_len = (uint32_t *)(pb + p_nblen);
+    A.slot_counter = d_slotc;
+    A.slot_owner = (uint32_t *)(tb + t_owner);
+    A.n_slots = n_slots;
+    A.chist = (uint32_t *)(zb + z_chist);
+    A.tcodes = (uint32_t *)(tb + t_codes);
+    A.tblob = tb + t_blob;
+    A.tblob_len = (uint32_t *)(tb + t_blen);
+    A.qrows = qrows;
+    A.n_sb = S;
+    A.out = (uint8_t *)d_out;
+    uint32_t *d_qrowoff = (uint32_t *)(pb + p_qrowoff);
+
+    // host-initialised SbState + group offsets
+    size_t sb_bytes = sizeof(SbState) * (size_t)S;
+    rc = ensure_pinned(c, cs.off + sb_bytes + 4 * (size_t)S + 4096);
+    if (rc) return rc;
+    hp = (uint8_t *)c->h_pin;
+    SbState *h_sb = (SbState *)hp;
+    uint32_t *h_grp = (uint32_t *)(hp + sb_bytes);
+    memset(h_sb, 0, sb_bytes);
+    uint32_t gacc = 0;
+    for (uint32_t s = 0; s < S; ++s) {
+        h_sb[s].rec_lo = cuts[s].rec_lo;
+        h_sb[s].n_rec = cuts[s].n_rec;
+        h_sb[s].rank = cuts[s].rank;
+        h_grp[s] = gacc;
+        gacc += (cuts[s].n_rec + GROUP - 1) / GROUP;
+    }
+    if (gacc > grp_cap) return NGSC_ERR_NOMEM;
+    HIPCHK(c, hipMemcpyAsync(A.sb, h_sb, sb_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(A.grp_lo, h_grp, 4 * (size_t)S, hipMemcpyHostToDevice, st));
+
+    // ---- stage C ----
+    { KScope k(c, st, "k_title_stats"); launch_title_stats(st, A, max_rec); }
+    { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
+    { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
+    { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
+    { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec); }
+    { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
+    { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
+    { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
+    { KScope k(c, st, "k_title_measure"); launch_title_measure(st, A, max_rec); }
+    { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
+    { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
+    // ---- sync 3: sizes ----
+    HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);
+    const uint64_t total = *(uint64_t *)(hp + sb_bytes + o_outtot);
+    c->res_bytes = total;
+    if (err3) return err3;
+    c->res_sb.resize(S);
+    for (uint32_t s = 0; s < S; ++s) {
+        const SbState &x = h_sb[s];
+        ngsc_subblock_t &r = c->res_sb[s];
+        r.rank = x.rank; r.n_records = x.n_rec; r.win_pos = cuts[s].win_pos; r.wsize = cuts[s].wsize;
+        r.out_off = x.out_off;
+        r.info_len = x.info_len; r.title_len = x.title_len; r.qual_len = x.qual_len; r.dna_len = x.dna_len;
+        r.max_qlen = x.max_q; r.max_slen = x.max_s; r.nsym = x.nsym; r.nqual = x.nqual; r.flags = x.flags;
+        r.n_fields = x.nf;
+    }
+    for (auto &rk : c->res_rank) {
+        if (!rk.n_subblocks) continue;
+        rk.stream_off = c->res_sb[rk.first_subblock].out_off;
+        uint64_t b = 0;
+        for (uint32_t k = 0; k < rk.n_subblocks; ++k) {
+            const ngsc_subblock_t &r = c->res_sb[rk.first_subblock + k];
+            b += (uint64_t)r.info_len + r.title_len + r.qual_len + r.dna_len;
+        }
+        rk.stream_bytes = b;
+    }
+    // ---- pack ----
+    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)std::min<uint64_t>(out_cap, (total + 15) & ~15ull), st));
+    { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
+    { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
+    { KScope k(c, st, "k_title_pack"); launch_title_pack(st, A, max_rec); }
+    { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    if (*(int32_t *)hp) return *(int32_t *)hp;
+    return NGSC_OK;
+}
+
+}  // extern "C"

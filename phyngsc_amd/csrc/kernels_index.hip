@@ -1,0 +1,269 @@
+// kernels_index.hip - record index of a FASTQ job and the sub-block cut plan.
+//
+// Replaces the per-thread newline scan of phyNGSC.cpp:254-331 (K0 in SURVEY.md): instead of walking
+// each 8 MiB window serially, every newline of the job is found in one coalesced pass, numbered by a
+// device-wide scan, and lines 4r / 4r+1 / 4r+3 give record r's title end, sequence end and the next
+// record's line start.  HBM-bound: 1 B read per input byte (twice: count + write), 12 B written per
+// record.  No MFMA - integer byte classification.
+#include "ngsc_kernels.h"
+
+namespace ngsc {
+
+constexpr int TILE_THREADS = 256;
+constexpr int BYTES_PER_THREAD = 32;
+constexpr uint32_t TILE_BYTES = TILE_THREADS * BYTES_PER_THREAD;  // 8 KiB per workgroup
+
+// exact per-byte "== 0" flags (bit 7 of each byte) of a 32-bit word
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t y)
+{
+    return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+
+// Newline flags of the 32 bytes starting at `base` (restricted to [start, len)): 8 words of bit-7 flags.
+__device__ __forceinline__ uint32_t load_nl_flags(const uint8_t *buf, uint32_t base, uint32_t start, uint32_t len,
+                                                  uint32_t flags[8])
+{
+    uint32_t cnt = 0;
+    if (base >= start && base + BYTES_PER_THREAD <= len) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(buf + base);
+        uint4 a = p[0], b = p[1];
+        uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            flags[i] = zero_bytes(w[i] ^ 0x0A0A0A0Au);
+            cnt += __popc(flags[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t f = 0;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t pos = base + i * 4 + k;
+                if (pos >= start && pos < len && buf[pos] == '\n') f |= 0x80u << (8 * k);
+            }
+            flags[i] = f;
+            cnt += __popc(f);
+        }
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
+                                                           uint32_t *tile_cnt)
+{
+    __shared__ uint32_t s_part[TILE_THREADS / 64];
+    const uint32_t start = *start_ptr;
+    const uint32_t base = blockIdx.x * TILE_BYTES + threadIdx.x * BYTES_PER_THREAD;
+    uint32_t flags[8];
+    uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+    c = wave_reduce_add(c);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+// Single workgroup exclusive scan of the tile counts (n up to ~524k); total -> *total_out.
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *tile_cnt, uint32_t n, uint32_t *total_out)
+{
+    __shared__ uint32_t s_wave[16];
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += tile_cnt[i];
+    uint32_t incl = wave_scan_incl(sum);
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t v = threadIdx.x < 16 ? s_wave[threadIdx.x] : 0;
+        uint32_t sc = wave_scan_incl(v);
+        if (threadIdx.x < 16) s_wave[threadIdx.x] = sc - v;  // exclusive wave offsets
+        if (threadIdx.x == 15) *total_out = sc;
+    }
+    __syncthreads();
+    uint32_t run = s_wave[threadIdx.x >> 6] + incl - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t c = tile_cnt[i];
+        tile_cnt[i] = run;
+        run += c;
+    }
+}
+
+// Writes the record table.  Line L (0-based from *start_ptr) ends at a newline; L&3 == 0: title end of
+// record L>>2, 1: sequence end, 3: the next record's line start.
+__global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
+                                                           const uint32_t *tile_off, uint32_t *te, uint32_t *se,
+                                                           uint32_t *ls, uint32_t rec_cap)
+{
+    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    const uint32_t start = *start_ptr;
+    const uint32_t base = blockIdx.x * TILE_BYTES + threadIdx.x * BYTES_PER_THREAD;
+    uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+    uint32_t incl = wave_scan_incl(c);
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += s_wave[w];
+    uint32_t line = tile_off[blockIdx.x] + wbase + incl - c;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = start;
+    if (!c) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t f = flags[i];
+        while (f) {
+            uint32_t k = (uint32_t)(__ffs(f) - 1) >> 3;
+            f &= f - 1;
+            uint32_t pos = base + i * 4 + k;
+            uint32_t r = line >> 2, kind = line & 3;
+            if (r < rec_cap) {
+                if (kind == 0) te[r] = pos;
+                else if (kind == 1) se[r] = pos;
+                else if (kind == 3) ls[r + 1] = pos + 1;
+            }
+            ++line;
+        }
+    }
+}
+
+// Structural validation of every record + job-wide max quality length.
+//   line 2 must be a bare '+', quality length must equal sequence length (README.md:97-103).
+// The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
+__global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint32_t *te, const uint32_t *se,
+                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, int32_t *err)
+{
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t L = 0;
+    bool bad = false;
+    if (r < n_rec) {
+        uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
+        L = s - t - 1;
+        bad = !(t >= l0 && s > t) || buf[s + 1] != '+' || buf[s + 2] != '\n' || l1 != 2 * s - t + 3;
+    }
+    if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
+    uint32_t m = L;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_q, m);
+}
+
+// First-record synchronisation of every virtual rank > 0 (phyNGSC.cpp:131-156): first '@' at or after
+// the region start, then the first newline after it; if the byte after that newline is '@' the record
+// starts there, otherwise at the first '@'.  One wave per rank, 64 bytes per step.
+__global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size,
+                                                   uint32_t P, uint32_t rank_lo, uint64_t *first_abs, uint32_t *start_rel,
+                                                   int32_t *err)
+{
+    const uint32_t r = rank_lo + blockIdx.x;
+    const int lane = threadIdx.x;
+    RankGeom g = rank_geometry(file_size, P, r);
+    if (r == 0) {
+        if (lane == 0) { first_abs[blockIdx.x] = 0; if (blockIdx.x == 0) *start_rel = 0; }
+        return;
+    }
+    int64_t rel0 = g.wr_start - (int64_t)buf_off;
+    int64_t lim64 = rel0 + g.bsize;
+    if (rel0 < 0) { if (lane == 0) atomicMin(err, (int32_t)ERR_ARG); return; }
+    uint32_t limit = lim64 < (int64_t)len ? (uint32_t)lim64 : len;
+    uint32_t pos = (uint32_t)rel0;
+    int64_t at = -1, nl = -1;
+    for (; pos < limit && at < 0; pos += 64) {
+        uint32_t p = pos + lane;
+        bool hit = p < limit && buf[p] == '@';
+        unsigned long long m = __ballot(hit);
+        if (m) at = (int64_t)pos + (__ffsll((long long)m) - 1);
+    }
+    if (at >= 0) {
+        for (pos = (uint32_t)at; pos < limit && nl < 0; pos += 64) {
+            uint32_t p = pos + lane;
+            bool hit = p < limit && buf[p] == '\n';
+            unsigned long long m = __ballot(hit);
+            if (m) nl = (int64_t)pos + (__ffsll((long long)m) - 1);
+        }
+    }
+    if (lane == 0) {
+        if (at < 0 || nl < 0) { atomicMin(err, (int32_t)ERR_FORMAT); first_abs[blockIdx.x] = 0; return; }
+        uint64_t res = (nl + 1 < (int64_t)len && buf[nl + 1] == '@') ? (uint64_t)(nl + 1) : (uint64_t)at;
+        first_abs[blockIdx.x] = res + buf_off;
+        if (blockIdx.x == 0) *start_rel = (uint32_t)res;
+    }
+}
+
+// Sub-block cuts: one thread per rank (binary searches over the record table; see plan_rank()).
+__global__ __launch_bounds__(64) void k_cuts(uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks,
+                                             uint64_t buf_off, const uint32_t *te, const uint32_t *ls,
+                                             const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
+                                             uint32_t max_cuts, RankPlan *plans, int32_t *err)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ranks) return;
+    uint32_t n_rec_total = *total_lines / 4;
+    int rc = plan_rank(file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i], cuts + (size_t)i * max_cuts,
+                       max_cuts, &plans[i]);
+    plans[i].err = rc;
+    if (rc) atomicMin(err, (int32_t)rc);
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+uint32_t index_num_tiles(uint32_t len) { return (len + TILE_BYTES - 1) / TILE_BYTES; }
+
+void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err)
+{
+    hipLaunchKernelGGL(k_sync_first, dim3(n_ranks), dim3(64), 0, st, buf, len, buf_off, file_size, P, rank_lo, first_abs,
+                       start_rel, err);
+}
+
+void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt)
+{
+    uint32_t nt = index_num_tiles(len);
+    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt);
+}
+
+void launch_scan_tiles(hipStream_t st, uint32_t *tile_cnt, uint32_t n_tiles, uint32_t *total_lines)
+{
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, total_lines);
+}
+
+void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, const uint32_t *tile_off,
+                     uint32_t *te, uint32_t *se, uint32_t *ls, uint32_t rec_cap)
+{
+    uint32_t nt = index_num_tiles(len);
+    hipLaunchKernelGGL(k_nl_write, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_off, te, se, ls, rec_cap);
+}
+
+void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
+                     uint32_t n_rec, uint32_t *max_q, int32_t *err)
+{
+    if (!n_rec) return;
+    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, err);
+}
+
+void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
+                 const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
+                 uint32_t max_cuts, RankPlan *plans, int32_t *err)
+{
+    hipLaunchKernelGGL(k_cuts, dim3((n_ranks + 63) / 64), dim3(64), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, ls,
+                       total_lines, first_abs, cuts, max_cuts, plans, err);
+}
+
+}  // namespace ngsc

@@ -1,0 +1,427 @@
+// kernels_pack.hip - bit-length measurement, offset scans, stream layout and the packed emit.
+//
+// Replaces the BitStream::PutBits hot loops of StoreQuality / StoreDNA / StoreTitle (tasks.cpp:609-619,
+// 544-557, 427-507), the info header + length table (phyNGSC.cpp:719-742) and the stream concatenation
+// (phyNGSC.cpp:793-840).  Output bytes are produced directly at their final place:
+//   sub-block = info | title | quality | DNA, sub-blocks back to back in (rank, sequence) order.
+//
+// Quality / DNA: one wavefront per record, one lane per symbol (coalesced byte loads).  Code tables
+// live in LDS ((max_len+1) x nqual words).  Bit offsets come from a wave inclusive scan of the code
+// lengths on top of the record's offset (workgroup scan of per-record bit counts).  Symbols are merged
+// into whole big-endian 32-bit words by a segmented OR-scan across lanes; complete interior words are
+// stored plainly, the first/last word of every 64-symbol step is merged with atomicOr.  HBM-bound
+// integer work, no MFMA: algorithmic traffic per record = its bytes read once + its code bits written.
+#include "ngsc_kernels.h"
+
+namespace ngsc {
+
+constexpr int PK_THREADS = 256;
+constexpr int PK_WAVES = PK_THREADS / 64;
+constexpr uint32_t PK_REC_PER_WG = 1024;
+constexpr uint32_t PK_LDS_MAX_ENTRIES = 24576;  // 96 KB of quality code table
+
+__device__ __forceinline__ uint32_t amb_fast2(uint8_t c)
+{
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 1u : amb_code(c);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_scan_incl_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Shared table setup for measure and pack.
+struct SqTables {
+    uint32_t *qtab;      // LDS [(max_q+1)][nq] or nullptr
+    const uint32_t *qglob;  // global [(qrows)][256]
+    uint32_t nq;
+    bool in_lds;
+};
+
+__device__ __forceinline__ uint32_t qentry(const SqTables &T, uint32_t row, uint32_t idx)
+{
+    return T.in_lds ? T.qtab[row * T.nq + idx] : T.qglob[(size_t)row * 256 + idx];
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PK_THREADS) void k_measure_sq(Arena A, uint32_t lds_entries)
+{
+    if (*A.err) return;
+    extern __shared__ __align__(16) uint32_t s_qtab[];
+    __shared__ uint32_t s_dcode[256];
+    __shared__ uint8_t s_qcode[256];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t r_begin = blockIdx.x * PK_REC_PER_WG;
+    if (r_begin >= n) return;
+    const uint32_t r_end = r_begin + PK_REC_PER_WG < n ? r_begin + PK_REC_PER_WG : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *buf = A.buf;
+    SqTables T;
+    T.nq = sb.nqual;
+    T.qglob = A.qcodes + (size_t)s * A.qrows * 256;
+    T.qtab = s_qtab;
+    const uint32_t entries = (sb.max_q + 1) * T.nq;
+    T.in_lds = entries <= lds_entries;
+    if (T.in_lds)
+        for (uint32_t k = tid; k < entries; k += PK_THREADS) s_qtab[k] = T.qglob[(size_t)(k / T.nq) * 256 + (k % T.nq)];
+    s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
+    s_qcode[tid] = sb.qua_code[tid];
+    __syncthreads();
+    for (uint32_t r = r_begin + wave; r < r_end; r += PK_WAVES) {
+        const uint32_t g = rec_lo + r;
+        const uint32_t t = A.te[g], e = A.se[g];
+        const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
+        const bool xfer = A.slen[g] >> 31;
+        uint32_t qb = 0, db = 0;
+        for (uint32_t base = 0; base < L; base += 64) {
+            uint32_t j = base + lane;
+            if (j < L) {
+                uint8_t c = buf[s0 + j], q = buf[q0 + j];
+                uint32_t a = xfer ? amb_fast2(c) : 1u;
+                bool drop = xfer && a > 1;
+                uint32_t qv = drop ? transfer_quality(a, q) : q;
+                qb += qentry(T, j + 1, s_qcode[qv]) & 31;
+                if (!drop) db += s_dcode[c] & 31;
+            }
+        }
+        qb = wave_sum(qb);
+        db = wave_sum(db);
+        if (lane == 0) { A.qoff[g] = qb; A.doff[g] = db; }
+    }
+}
+
+// One thread per group of 32 records: byte size of the group's title bits (tasks.cpp:393-509).
+__global__ __launch_bounds__(64) void k_title_measure(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ngrp = (sb.n_rec + GROUP - 1) / GROUP;
+    if (k >= ngrp) return;
+    uint32_t g0 = sb.rec_lo + k * GROUP;
+    uint32_t g1 = k * GROUP + GROUP < sb.n_rec ? g0 + GROUP : sb.rec_lo + sb.n_rec;
+    BitCounter bc;
+    title_group(A, s, g0, g1, bc);
+    A.goff[A.grp_lo[s] + k] = (uint32_t)bc.nbytes();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// In-place exclusive scan of a[0..n) by one workgroup of 1024 threads; returns the total (all threads).
+__device__ uint32_t wg_scan_excl(uint32_t *a, uint32_t n, uint32_t *s_wave /*[17]*/)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        uint32_t i = base + tid;
+        uint32_t v = i < n ? a[i] : 0;
+        uint32_t incl = wave_scan_incl_u32(v);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t w = tid < 16 ? s_wave[tid] : 0;
+            uint32_t sc = wave_scan_incl_u32(w);
+            if (tid < 16) s_wave[tid] = sc - w;
+            if (tid == 15) s_wave[16] = sc;
+        }
+        __syncthreads();
+        if (i < n) a[i] = run + s_wave[wave] + incl - v;
+        run += s_wave[16];
+        __syncthreads();
+    }
+    return run;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sb(Arena A)
+{
+    if (*A.err) return;
+    __shared__ uint32_t s_wave[17];
+    const uint32_t s = blockIdx.x;
+    SbState &sb = A.sb[s];
+    uint32_t tq = wg_scan_excl(A.qoff + sb.rec_lo, sb.n_rec, s_wave);
+    uint32_t td = wg_scan_excl(A.doff + sb.rec_lo, sb.n_rec, s_wave);
+    uint32_t tg = wg_scan_excl(A.goff + A.grp_lo[s], (sb.n_rec + GROUP - 1) / GROUP, s_wave);
+    if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
+}
+
+// One thread per sub-block: stream sizes.  qrow_off[s][row] = byte offset of tree `row` inside the quality header.
+__global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_sb) return;
+    SbState &sb = A.sb[s];
+    uint32_t off = sb.nqual;  // alphabet bytes (tasks.cpp:577-581)
+    for (uint32_t row = 0; row <= sb.max_q; ++row) {
+        qrow_off[(size_t)s * A.qrows + row] = off;
+        off += 4 + A.qblob_len[(size_t)s * A.qrows + row];
+    }
+    sb.qual_hdr = off;
+    sb.qual_len = off + (sb.qbits + 7) / 8;
+    uint32_t dh = sb.nsym;
+    if (!(sb.flags & F_DNA_PLAIN)) dh += 4 + A.dblob_len[s];
+    sb.dna_hdr = dh;
+    sb.dna_len = dh + (sb.dbits + 7) / 8;
+    BitCounter bc;
+    title_header(A, s, bc);
+    sb.title_hdr = (uint32_t)bc.nbytes();
+    sb.title_len = sb.title_hdr + sb.title_body;
+    sb.info_len = 19 + (uint32_t)(((uint64_t)sb.n_rec * sb.lt_bits + 7) / 8);  // phyNGSC.cpp:719-742
+    sb.total = sb.info_len + sb.title_len + sb.qual_len + sb.dna_len;
+}
+
+__global__ void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
+{
+    if (*A.err) return;
+    if (blockIdx.x || threadIdx.x) return;
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < A.n_sb; ++s) {
+        A.sb[s].out_off = off;
+        off += A.sb[s].total;
+    }
+    *total_out = off;
+    if (off > out_cap) atomicMin(A.err, (int32_t)ERR_CAPACITY);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Headers: info (19 B), title header, quality alphabet + trees, DNA alphabet + tree.
+__global__ __launch_bounds__(256) void k_write_headers(Arena A, const uint32_t *qrow_off)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.x;
+    const SbState &sb = A.sb[s];
+    const int tid = threadIdx.x;
+    uint8_t *o = A.out + sb.out_off;
+    if (tid == 0) {
+        ByteWriter w(o);  // phyNGSC.cpp:719-731
+        w.word(sb.n_rec); w.word(sb.max_q); w.word(sb.max_s);
+        w.byte((uint8_t)sb.nsym); w.byte(0 /* QUALITY_PLAIN */); w.byte((uint8_t)sb.nqual);
+        w.word(sb.flags);
+    } else if (tid == 64) {
+        ByteWriter w(o + sb.info_len);
+        title_header(A, s, w);
+    } else if (tid == 128) {
+        ByteWriter w(o + sb.info_len + sb.title_len + sb.qual_len);  // tasks.cpp:519-542
+        w.bytes(sb.symbols, sb.nsym);
+        if (!(sb.flags & F_DNA_PLAIN)) {
+            w.word(A.dblob_len[s]);
+            w.bytes(A.dblob + (size_t)s * BLOB_SLOT_256, A.dblob_len[s]);
+        }
+    }
+    // quality header: alphabet, then one tree per row (tasks.cpp:577-605); threads stride over rows
+    uint8_t *q = o + sb.info_len + sb.title_len;
+    for (uint32_t k = tid; k < sb.nqual; k += 256) q[k] = sb.qualities[k];
+    for (uint32_t row = tid; row <= sb.max_q; row += 256) {
+        size_t t = (size_t)s * A.qrows + row;
+        ByteWriter w(q + qrow_off[t]);
+        w.word(A.qblob_len[t]);
+        w.bytes(A.qblob + t * BLOB_SLOT_256, A.qblob_len[t]);
+    }
+}
+
+// Length table: n_rec values of lt_bits bits each (phyNGSC.cpp:733-742).  One thread per aligned 32-bit
+// word of the output buffer that intersects the table.
+__global__ __launch_bounds__(256) void k_pack_lentable(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t b = sb.lt_bits;
+    if (!b) return;
+    const uint64_t t0 = (sb.out_off + 19) * 8, t1 = t0 + (uint64_t)sb.n_rec * b;  // absolute bit range
+    const uint64_t w0 = t0 >> 5;
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((w << 5) >= t1) return;
+    const uint64_t lo = (w << 5) > t0 ? (w << 5) : t0, hi = ((w + 1) << 5) < t1 ? ((w + 1) << 5) : t1;
+    uint32_t val = 0;
+    uint64_t r = (lo - t0) / b;
+    for (;; ++r) {
+        uint64_t rb = t0 + r * b;  // first bit of record r
+        if (rb >= hi) break;
+        uint32_t g = sb.rec_lo + (uint32_t)r;
+        uint64_t v = A.se[g] - A.te[g] - 1;  // qua_len
+        // place v's b bits at absolute bits [rb, rb+b); keep those inside [w<<5, (w+1)<<5)
+        int64_t sh = (int64_t)((w + 1) << 5) - (int64_t)(rb + b);  // left shift of v's LSB inside the word
+        uint64_t x = sh >= 0 ? (v << sh) : (v >> (-sh));
+        val |= (uint32_t)x;
+    }
+    uint32_t *outw = reinterpret_cast<uint32_t *>(A.out) + w;
+    uint32_t be = __builtin_bswap32(val);
+    if (lo == (w << 5) && hi == ((w + 1) << 5)) *outw = be; else if (be) atomicOr(outw, be);
+}
+
+// One thread per group of 32 records writes the group's title bits (byte aligned, exclusive range).
+__global__ __launch_bounds__(64) void k_title_pack(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ngrp = (sb.n_rec + GROUP - 1) / GROUP;
+    if (k >= ngrp) return;
+    uint32_t g0 = sb.rec_lo + k * GROUP;
+    uint32_t g1 = k * GROUP + GROUP < sb.n_rec ? g0 + GROUP : sb.rec_lo + sb.n_rec;
+    ByteWriter w(A.out + sb.out_off + sb.info_len + sb.title_hdr + A.goff[A.grp_lo[s] + k]);
+    title_group(A, s, g0, g1, w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave-cooperative emit of up to 64 variable-length codes starting at absolute bit `bitpos`.
+// Every lane passes (code, len) with len <= 26 (0 for "nothing").  Returns the number of bits emitted.
+__device__ __forceinline__ uint32_t wave_emit(uint32_t *outw, uint64_t bitpos, uint32_t code, uint32_t len)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t incl = wave_scan_incl_u32(len);
+    const uint32_t total = __shfl(incl, 63);
+    if (!total) return 0;
+    const uint64_t o = bitpos + (incl - len);
+    const uint32_t key = (uint32_t)(o >> 5), sh = (uint32_t)(o & 31);
+    uint32_t hi = 0, lo = 0;
+    if (len) {
+        uint64_t x = (uint64_t)code << (64 - len - sh);
+        hi = (uint32_t)(x >> 32);
+        lo = (uint32_t)x;  // spill into word key+1 (non-zero only when sh + len > 32)
+    }
+    // a spill always lands in the word the next lane starts in (len <= 32): hand it to that lane
+    const uint32_t key_prev = __shfl_up(key, 1), lo_prev = __shfl_up(lo, 1);
+    if (lane > 0 && key_prev != key) hi |= lo_prev;
+    // segmented inclusive OR-scan keyed by word index (keys are non-decreasing across lanes)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t ko = __shfl_up(key, d), vo = __shfl_up(hi, d);
+        if (lane >= d && ko == key) hi |= vo;
+    }
+    const uint32_t key_next = __shfl_down(key, 1);
+    const bool tail = lane == 63 || key_next != key;
+    const uint32_t first_key = __shfl(key, 0), last_key = __shfl(key, 63);
+    if (tail) {
+        uint32_t be = __builtin_bswap32(hi);
+        if (key != first_key && key != last_key) outw[key] = be;     // complete interior word
+        else if (be) atomicOr(&outw[key], be);                        // shared with the neighbours
+    }
+    if (lane == 63 && lo) atomicOr(&outw[key + 1], __builtin_bswap32(lo));
+    return total;
+}
+
+__global__ __launch_bounds__(PK_THREADS) void k_pack_sq(Arena A, uint32_t lds_entries)
+{
+    if (*A.err) return;
+    extern __shared__ __align__(16) uint32_t s_qtab[];
+    __shared__ uint32_t s_dcode[256];
+    __shared__ uint8_t s_qcode[256];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t r_begin = blockIdx.x * PK_REC_PER_WG;
+    if (r_begin >= n) return;
+    const uint32_t r_end = r_begin + PK_REC_PER_WG < n ? r_begin + PK_REC_PER_WG : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *buf = A.buf;
+    SqTables T;
+    T.nq = sb.nqual;
+    T.qglob = A.qcodes + (size_t)s * A.qrows * 256;
+    T.qtab = s_qtab;
+    const uint32_t entries = (sb.max_q + 1) * T.nq;
+    T.in_lds = entries <= lds_entries;
+    if (T.in_lds)
+        for (uint32_t k = tid; k < entries; k += PK_THREADS) s_qtab[k] = T.qglob[(size_t)(k / T.nq) * 256 + (k % T.nq)];
+    s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
+    s_qcode[tid] = sb.qua_code[tid];
+    __syncthreads();
+    uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
+    const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
+    const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
+    for (uint32_t r = r_begin + wave; r < r_end; r += PK_WAVES) {
+        const uint32_t g = rec_lo + r;
+        const uint32_t t = A.te[g], e = A.se[g];
+        const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
+        const bool xfer = A.slen[g] >> 31;
+        uint64_t qpos = qbase + A.qoff[g], dpos = dbase + A.doff[g];
+        for (uint32_t base = 0; base < L; base += 64) {
+            uint32_t j = base + lane;
+            uint32_t qe = 0, de = 0;
+            if (j < L) {
+                uint8_t c = buf[s0 + j], q = buf[q0 + j];
+                uint32_t a = xfer ? amb_fast2(c) : 1u;
+                bool drop = xfer && a > 1;
+                uint32_t qv = drop ? transfer_quality(a, q) : q;
+                qe = qentry(T, j + 1, s_qcode[qv]);       // tasks.cpp:614-618
+                if (!drop) de = s_dcode[c];               // tasks.cpp:549-556
+            }
+            qpos += wave_emit(outw, qpos, qe >> 5, qe & 31);
+            dpos += wave_emit(outw, dpos, de >> 5, de & 31);
+        }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+static uint32_t lds_entries_for(uint32_t qrows)
+{
+    uint64_t e = (uint64_t)qrows * 96;
+    return (uint32_t)(e < PK_LDS_MAX_ENTRIES ? e : PK_LDS_MAX_ENTRIES);
+}
+
+void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t le = lds_entries_for(A.qrows);
+    dim3 grid((max_rec + PK_REC_PER_WG - 1) / PK_REC_PER_WG, A.n_sb);
+    hipLaunchKernelGGL(k_measure_sq, grid, dim3(PK_THREADS), le * sizeof(uint32_t), st, A, le);
+}
+
+void launch_title_measure(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t max_grp = (max_rec + GROUP - 1) / GROUP;
+    hipLaunchKernelGGL(k_title_measure, dim3((max_grp + 63) / 64, A.n_sb), dim3(64), 0, st, A);
+}
+
+void launch_scan_sb(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_scan_sb, dim3(A.n_sb), dim3(1024), 0, st, A);
+}
+
+void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out)
+{
+    hipLaunchKernelGGL(k_sizes, dim3((A.n_sb + 63) / 64), dim3(64), 0, st, A, qrow_off);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, st, A, out_cap, total_out);
+}
+
+void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off)
+{
+    hipLaunchKernelGGL(k_write_headers, dim3(A.n_sb), dim3(256), 0, st, A, qrow_off);
+}
+
+void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t lt_words = max_rec + 2;  // at most 32 bits per record, plus misalignment
+    hipLaunchKernelGGL(k_pack_lentable, dim3((lt_words + 255) / 256, A.n_sb), dim3(256), 0, st, A);
+}
+
+void launch_title_pack(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t max_grp = (max_rec + GROUP - 1) / GROUP;
+    hipLaunchKernelGGL(k_title_pack, dim3((max_grp + 63) / 64, A.n_sb), dim3(64), 0, st, A);
+}
+
+void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t le = lds_entries_for(A.qrows);
+    dim3 grid((max_rec + PK_REC_PER_WG - 1) / PK_REC_PER_WG, A.n_sb);
+    hipLaunchKernelGGL(k_pack_sq, grid, dim3(PK_THREADS), le * sizeof(uint32_t), st, A, le);
+}
+
+}  // namespace ngsc

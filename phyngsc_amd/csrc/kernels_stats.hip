@@ -1,0 +1,439 @@
+// kernels_stats.hip - per-sub-block statistics of the FASTQ compressor (batched over sub-blocks:
+// blockIdx.y = sub-block).
+//
+//   k_title_stats      AnalyzeTitleFields reductions (tasks.cpp:22-193): per-field min/max length,
+//                      constant / numeric flags, value and delta ranges, Hamming mask
+//   k_seq_qual_stats   DNA/quality prepass (phyNGSC.cpp:462-653) + AnalyzeQuality (tasks.cpp:260-286):
+//                      N-transfer decision, DNA symbol counts, per-position quality histograms staged
+//                      in LDS (row stride 65 words so the 64 lanes of one record hit distinct banks)
+//   k_sq_finalize      alphabets, codes, flags (phyNGSC.cpp:659-687, tasks.cpp:226-257)
+//   k_field_finalize   per-field coding decisions (tasks.cpp:196-222, 324-338)
+//   k_title_hist       value / delta / per-position character histograms for the title Huffman trees
+//
+// All of it is integer, branchy, HBM/LDS-bound work: no MFMA.
+#include "ngsc_kernels.h"
+
+namespace ngsc {
+
+constexpr int TS_THREADS = 256;
+constexpr int TS_OWNED = TS_THREADS - 1;  // thread 0 of a workgroup re-parses the previous record (delta halo)
+
+__device__ __forceinline__ void lds_max(uint32_t *p, uint32_t v) { if (v > *p) atomicMax(p, v); }
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { if ((*p & v) != v) atomicOr(p, v); }
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TS_THREADS) void k_title_stats(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    if (blockIdx.x * TS_OWNED >= n) return;
+    const int tid = threadIdx.x;
+    const uint8_t *buf = A.buf;
+
+    __shared__ uint32_t s_val[MAX_FIELDS][TS_THREADS];
+    __shared__ uint32_t s_nummask[TS_THREADS];
+    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
+    __shared__ uint32_t s_nf0;
+
+    for (int k = tid; k < (int)(MAX_FIELDS * 24); k += TS_THREADS) s_stat[k] = 0;
+    if (tid == 0) {
+        uint32_t nf0 = count_fields(buf, A.ls[rec_lo], A.te[rec_lo]);
+        s_nf0 = nf0;
+        if (blockIdx.x == 0) A.sb[s].nf = nf0;
+        if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
+    }
+    __syncthreads();
+    const uint32_t nf0 = s_nf0;
+    if (nf0 > MAX_FIELDS) return;
+
+    const int64_t i = (int64_t)blockIdx.x * TS_OWNED + tid - 1;  // record index inside the sub-block
+    const bool valid = i >= 0 && i < (int64_t)n;
+    const bool owned = valid && tid >= 1;
+    uint32_t nummask = 0;
+    if (valid) {
+        const uint32_t g = rec_lo + (uint32_t)i;
+        uint32_t pc = A.ls[g], p0 = A.ls[rec_lo];
+        const uint32_t tec = A.te[g];
+        uint32_t nfields = 0;
+        while (pc <= tec) {
+            uint32_t ec = field_end(buf, pc);
+            if (nfields < nf0) {
+                const uint32_t f = nfields;
+                uint32_t e0 = field_end(buf, p0);
+                uint32_t len = ec - pc, len0 = e0 - p0;
+                uint32_t v = 0;
+                bool ovf = false;
+                bool isnum = parse_num(buf, pc, ec, v, ovf);
+                s_val[f][tid] = v;
+                nummask |= (uint32_t)isnum << f;
+                if (owned) {
+                    uint32_t *st = s_stat + f * 24;
+                    lds_max(st + 0, len);
+                    lds_max(st + 1, ~len);
+                    uint32_t m = len < len0 ? len : len0;
+                    bool diff = false;
+                    for (uint32_t p = 0; p < m; ++p) {
+                        if (buf[pc + p] != buf[p0 + p]) {
+                            diff = true;
+                            if (p < 256) lds_or(st + 10 + (p >> 5), 1u << (p & 31));
+                        }
+                    }
+                    if (len != len0) { lds_max(st + 3, 1); lds_max(st + 2, 1); }
+                    else if (diff) lds_max(st + 2, 1);
+                    if (!isnum) lds_max(st + 4, 1);
+                    else {
+                        if (ovf) lds_max(st + 5, 1);
+                        lds_max(st + 6, bias((int32_t)v));
+                        lds_max(st + 7, ~bias((int32_t)v));
+                    }
+                }
+                p0 = e0 + 1;
+            }
+            ++nfields;
+            pc = ec + 1;
+        }
+        if (nfields != nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    }
+    s_nummask[tid] = nummask;
+    __syncthreads();
+    if (owned && i >= 1) {
+        uint32_t both = nummask & s_nummask[tid - 1];
+        for (uint32_t f = 0; f < nf0; ++f) {
+            if ((both >> f) & 1) {
+                int32_t d = (int32_t)(s_val[f][tid] - s_val[f][tid - 1]);  // tasks.cpp:149-166
+                lds_max(s_stat + f * 24 + 8, bias(d));
+                lds_max(s_stat + f * 24 + 9, ~bias(d));
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
+    for (uint32_t k = tid; k < nf0 * 24; k += TS_THREADS) {
+        uint32_t v = s_stat[k];
+        if (!v) continue;
+        uint32_t w = k % 24;
+        if (w >= 10 && w < 18) atomicOr(gst + k, v);
+        else if (w < 10) atomicMax(gst + k, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+constexpr int SQ_THREADS = 256;
+constexpr int SQ_WAVES = SQ_THREADS / 64;
+constexpr uint32_t SQ_REC_PER_WG = 1024;
+constexpr uint32_t HIST_COLS = 64;           // quality bytes '!' (33) .. '`' (96) are staged in LDS
+constexpr uint32_t HIST_STRIDE = 65;         // odd stride: lanes of one record (consecutive rows) spread over banks
+constexpr uint32_t HIST_MAX_ROWS = 360;      // 360*65*4 = 93.6 KB
+
+__device__ __forceinline__ uint32_t amb_fast(uint8_t c)
+{
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 1u : amb_code(c);
+}
+
+__global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t lds_rows)
+{
+    if (*A.err) return;
+    extern __shared__ __align__(16) uint32_t s_hist[];  // [lds_rows][HIST_STRIDE]
+    __shared__ uint32_t s_occ[256];
+    __shared__ uint32_t s_max[2];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t r_begin = blockIdx.x * SQ_REC_PER_WG;
+    if (r_begin >= n) return;
+    const uint32_t r_end = r_begin + SQ_REC_PER_WG < n ? r_begin + SQ_REC_PER_WG : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *buf = A.buf;
+
+    for (uint32_t k = tid; k < lds_rows * HIST_STRIDE; k += SQ_THREADS) s_hist[k] = 0;
+    s_occ[tid] = 0;
+    if (tid < 2) s_max[tid] = 0;
+    __syncthreads();
+
+    uint32_t cA = 0, cC = 0, cG = 0, cT = 0, wmax_q = 0, wmax_s = 0;
+    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
+    for (uint32_t r = r_begin + wave; r < r_end; r += SQ_WAVES) {
+        const uint32_t g = rec_lo + r;
+        const uint32_t t = A.te[g], e = A.se[g];
+        const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
+        if (r == 0 && lane == 0) {
+            uint8_t c1 = buf[s0 + 1];  // colour-space detection, phyNGSC.cpp:478
+            if (L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+        }
+        // pass 1: transfer test (phyNGSC.cpp:549-571).  The serial loop breaks at the first failure, so
+        // the outcome is "some ambiguous base" && "no failure anywhere" - order independent.
+        bool any = false, bad = false;
+        for (uint32_t base = 0; base < L; base += 64) {
+            uint32_t j = base + lane;
+            if (j < L) {
+                uint8_t c = buf[s0 + j];
+                uint32_t a = amb_fast(c);
+                if (a == 0) bad = true;
+                else if (a > 1) {
+                    uint8_t q = buf[q0 + j];
+                    if (q < 33 || q > 40) bad = true; else any = true;
+                }
+            }
+        }
+        const bool xfer = __any(any) && !__any(bad);
+        // pass 2: counts
+        uint32_t kept = 0;
+        for (uint32_t base = 0; base < L; base += 64) {
+            uint32_t j = base + lane;
+            bool act = j < L;
+            uint8_t c = 0, q = 0;
+            uint32_t a = 1;
+            if (act) { c = buf[s0 + j]; q = buf[q0 + j]; a = amb_fast(c); }
+            bool drop = xfer && a > 1;
+            bool keep = act && !drop;
+            if (act) {
+                uint32_t qv = drop ? transfer_quality(a, q) : q;  // phyNGSC.cpp:579
+                uint32_t row = j + 1, col = qv - 33;
+                if (col < HIST_COLS && row < lds_rows) atomicAdd(&s_hist[row * HIST_STRIDE + col], 1u);
+                else atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
+            }
+            cA += __popcll(__ballot(keep && c == 'A'));
+            cC += __popcll(__ballot(keep && c == 'C'));
+            cG += __popcll(__ballot(keep && c == 'G'));
+            cT += __popcll(__ballot(keep && c == 'T'));
+            if (keep && a != 1) atomicAdd(&s_occ[c], 1u);
+            kept += __popcll(__ballot(keep));
+        }
+        if (lane == 0) A.slen[g] = kept | ((uint32_t)xfer << 31);
+        wmax_q = L > wmax_q ? L : wmax_q;
+        wmax_s = kept > wmax_s ? kept : wmax_s;
+    }
+    if (lane == 0) {
+        atomicAdd(&s_occ['A'], cA); atomicAdd(&s_occ['C'], cC); atomicAdd(&s_occ['G'], cG); atomicAdd(&s_occ['T'], cT);
+        atomicMax(&s_max[0], wmax_q); atomicMax(&s_max[1], wmax_s);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < lds_rows * HIST_COLS; k += SQ_THREADS) {
+        uint32_t row = k / HIST_COLS, col = k % HIST_COLS;
+        uint32_t v = s_hist[row * HIST_STRIDE + col];
+        if (v) atomicAdd(&qh[(size_t)row * 256 + 33 + col], v);
+    }
+    if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
+    if (tid == 0) { atomicMax(&A.sb[s].max_q, s_max[0]); atomicMax(&A.sb[s].max_s, s_max[1]); }
+}
+
+// One workgroup of 256 threads per sub-block; thread = byte value.
+__global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SbState &sb = A.sb[s];
+    __shared__ uint32_t s_cnt[2][4];
+    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
+    const uint32_t max_q = sb.max_q;
+    uint32_t tot = 0;
+    for (uint32_t row = 1; row <= max_q; ++row) tot += qh[(size_t)row * 256 + tid];
+    qh[tid] = tot;  // row 0: position-independent histogram (quality_stats[0], tasks.cpp:283)
+    const bool hasq = tot != 0;
+    const bool hass = A.dna_occ[(size_t)s * 256 + tid] != 0;
+    unsigned long long mq = __ballot(hasq), ms = __ballot(hass);
+    if (lane == 0) { s_cnt[0][wave] = __popcll(mq); s_cnt[1][wave] = __popcll(ms); }
+    __syncthreads();
+    uint32_t bq = 0, bs = 0;
+    for (int w = 0; w < wave; ++w) { bq += s_cnt[0][w]; bs += s_cnt[1][w]; }
+    unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t iq = bq + __popcll(mq & below), is = bs + __popcll(ms & below);
+    // alphabets in ascending byte order, codes = rank (phyNGSC.cpp:674-686)
+    sb.qua_code[tid] = hasq ? (uint8_t)iq : 0;
+    sb.sym_code[tid] = hass ? (uint8_t)is : 0;
+    if (hasq) sb.qualities[iq] = (uint8_t)tid;
+    if (hass) sb.symbols[is] = (uint8_t)tid;
+    const uint32_t nqual = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const uint32_t nsym = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    // flags: phyNGSC.cpp:433-435, 645-667 (VARIABLE_LENGTH and DELTA_CONSTANT always end up set, Q1);
+    // AnalyzeDNA (tasks.cpp:226-257) keeps DNA_PLAIN iff <= 4 symbols (its skew test compares zeros, Q4)
+    uint32_t flags = F_PLUS_ONLY | F_CONST_NUM_FIELDS | F_DELTA_CONSTANT | F_VARIABLE_LENGTH;
+    if (nsym <= 4) flags |= F_DNA_PLAIN;
+    // DNA code LUT by raw byte; the Huffman case is overwritten by the tree kernel
+    A.dcodes[(size_t)s * 256 + tid] = hass ? ((is << 5) | 2u) : 0u;
+    if (tid == 0) {
+        sb.nqual = nqual;
+        sb.nsym = nsym;
+        sb.flags = flags;
+        sb.lt_bits = bit_length(max_q);
+        if (!nqual || !nsym) atomicMin(A.err, (int32_t)ERR_FORMAT);
+    }
+}
+
+// One thread per (sub-block, field).
+__global__ __launch_bounds__(64) void k_field_finalize(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.x, f = threadIdx.x;
+    const SbState &sb = A.sb[s];
+    if (f >= sb.nf || f >= MAX_FIELDS) return;
+    const uint8_t *buf = A.buf;
+    uint32_t p = A.ls[sb.rec_lo], e = 0;
+    for (uint32_t k = 0; k <= f; ++k) { e = field_end(buf, p); if (k < f) p = e + 1; }
+    FieldDesc d;
+    for (int k = 0; k < 5; ++k) d.pad[k] = 0;
+    int rc = finalize_field(A.fstat[(size_t)s * MAX_FIELDS + f], p, e - p, buf[e], sb.n_rec, f, sb.nf, d);
+    if (rc == OK && d.kind == KIND_TEXT) {
+        uint32_t slot = atomicAdd(A.slot_counter, 1u);
+        if (slot >= A.n_slots) rc = ERR_UNSUPPORTED;
+        else { d.slot = slot; A.slot_owner[slot] = s * MAX_FIELDS + f; }
+    }
+    if (rc) atomicMin(A.err, (int32_t)rc);
+    A.fdesc[(size_t)s * MAX_FIELDS + f] = d;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Title histograms.  Numeric Huffman fields: LDS-privatised [8][512] counters; text fields: global
+// atomics aggregated per wave and distinct character.
+constexpr uint32_t NH_LDS_FIELDS = 8;
+
+__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
+    if (blockIdx.x * TS_OWNED >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint8_t *buf = A.buf;
+    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
+
+    __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
+    __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
+    __shared__ uint32_t s_need;       // bit f: field needs a histogram
+    __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields (0xff: global atomics)
+
+    for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
+    if (tid == 0) {
+        uint32_t need = 0, kk = 0;
+        for (uint32_t f = 0; f < nf; ++f) {
+            s_k[f] = 0xff;
+            if (fd[f].kind == KIND_NUM && fd[f].has_huff && fd[f].n_sym > 1) {
+                need |= 1u << f;
+                if (kk < NH_LDS_FIELDS) s_k[f] = (uint8_t)kk++;
+            } else if (fd[f].kind == KIND_TEXT) need |= 1u << f;
+        }
+        s_need = need;
+    }
+    __syncthreads();
+    const uint32_t need = s_need;
+    if (!need) return;
+
+    const int64_t i = (int64_t)blockIdx.x * TS_OWNED + tid - 1;
+    const bool valid = i >= 0 && i < (int64_t)n;
+    const bool owned = valid && tid >= 1;
+    const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
+    uint32_t pc = A.ls[g];
+    // lockstep over fields so that the lanes of a wave look at the same field together
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t ec = field_end(buf, pc);
+        const FieldDesc &d = fd[f];
+        if ((need >> f) & 1) {
+            if (d.kind == KIND_NUM) {
+                uint32_t v = 0;
+                bool o;
+                parse_num(buf, pc, ec, v, o);
+                uint32_t k = s_k[f];
+                if (k != 0xff) {
+                    s_val[k][tid] = v;
+                } else if (owned) {  // more than 8 numeric Huffman fields: slow path, previous value re-parsed
+                    uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+                    if (!d.delta_coding) {
+                        uint32_t idx = v - (uint32_t)d.min_v;
+                        if (idx < d.n_sym) atomicAdd(&nh[idx], i == 0 ? 2u : 1u);
+                    } else if (i >= 1) {
+                        uint32_t pp = A.ls[g - 1], ep = 0;
+                        for (uint32_t k2 = 0; k2 <= f; ++k2) { ep = field_end(buf, pp); if (k2 < f) pp = ep + 1; }
+                        uint32_t pv = 0;
+                        parse_num(buf, pp, ep, pv, o);
+                        uint32_t idx = v - pv - (uint32_t)d.min_d;
+                        if (idx < d.n_sym) atomicAdd(&nh[idx], 1u);
+                    }
+                }
+            } else {
+                // text: chars[min(x,128)][c]++ (tasks.cpp:83-93), one atomic per wave and distinct character
+                uint32_t len = owned ? ec - pc : 0;
+                uint32_t wmax = len;
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) { uint32_t o2 = __shfl_xor(wmax, dd); wmax = o2 > wmax ? o2 : wmax; }
+                uint32_t *ch = A.chist + (size_t)d.slot * TEXT_TREES * 256;
+                for (uint32_t x = 0; x < wmax; ++x) {
+                    bool act = x < len;
+                    uint32_t c = act ? buf[pc + x] : 0x100u;
+                    uint32_t row = x < MAX_STAT_LEN ? x : MAX_STAT_LEN;
+                    unsigned long long m = __ballot(act);
+                    while (m) {
+                        int leader = __ffsll((long long)m) - 1;
+                        uint32_t c0 = __shfl(c, leader);
+                        unsigned long long same = __ballot(act && c == c0);
+                        if (lane == leader) atomicAdd(&ch[row * 256 + c0], (uint32_t)__popcll(same));
+                        if (c == c0) act = false;
+                        m &= ~same;
+                    }
+                }
+            }
+        }
+        pc = ec + 1;
+    }
+    __syncthreads();
+    // numeric histograms staged in LDS: value coding counts record 0 twice (phyNGSC.cpp:368 + tasks.cpp:175-177)
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t k = s_k[f];
+        if (k == 0xff || !((need >> f) & 1) || fd[f].kind != KIND_NUM) continue;
+        const FieldDesc &d = fd[f];
+        if (owned) {
+            uint32_t v = s_val[k][tid];
+            if (!d.delta_coding) {
+                uint32_t idx = v - (uint32_t)d.min_v;
+                if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], i == 0 ? 2u : 1u);
+            } else if (i >= 1) {
+                uint32_t idx = v - s_val[k][tid - 1] - (uint32_t)d.min_d;
+                if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t k = s_k[f];
+        if (k == 0xff) continue;
+        uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+        for (uint32_t x = tid; x < fd[f].n_sym; x += TS_THREADS)
+            if (s_nh[k][x]) atomicAdd(&nh[x], s_nh[k][x]);
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+void launch_title_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TS_OWNED - 1) / TS_OWNED, A.n_sb);
+    hipLaunchKernelGGL(k_title_stats, grid, dim3(TS_THREADS), 0, st, A);
+}
+
+void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    uint32_t rows = A.qrows < HIST_MAX_ROWS ? A.qrows : HIST_MAX_ROWS;
+    dim3 grid((max_rec + SQ_REC_PER_WG - 1) / SQ_REC_PER_WG, A.n_sb);
+    size_t lds = (size_t)rows * HIST_STRIDE * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_seq_qual_stats, grid, dim3(SQ_THREADS), lds, st, A, rows);
+}
+
+void launch_sq_finalize(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_sq_finalize, dim3(A.n_sb), dim3(256), 0, st, A);
+}
+
+void launch_field_finalize(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_field_finalize, dim3(A.n_sb), dim3(64), 0, st, A);
+}
+
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TS_OWNED - 1) / TS_OWNED, A.n_sb);
+    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A);
+}
+
+}  // namespace ngsc

@@ -1,0 +1,669 @@
+// ngsc_common.h - constants, device-visible structures and the per-thread format logic shared by
+// the HIP kernels of the MI355X FASTQ sub-block compressor.
+//
+// Everything marked NGSC_HD is plain per-thread logic without wave intrinsics.  The kernels in
+// kernels_*.hip call these helpers from device code; tests/harness/ compiles the same helpers
+// with g++ to unit-test the format logic against the oracle on machines without a GPU.  There is
+// no CPU execution path in the product library: only __global__ kernels call these functions.
+//
+// Reference citations are file:line into pcdslab/PHYNGSC.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NGSC_HD __host__ __device__ inline
+#else
+#define NGSC_HD inline
+#endif
+
+namespace ngsc {
+
+// ---- format constants ---------------------------------------------------------------------------
+constexpr uint32_t WINDOW = 1u << 23;       // READ/WRITE_BUFFER_SIZE, defs.h:20-21
+constexpr uint32_t OVERLAP = 500;           // phyNGSC.cpp:48
+constexpr uint32_t MAX_RECORDS = 100000;    // records_per_th, phyNGSC.cpp:51
+constexpr uint32_t GROUP = 32;              // DEFAULT_B_SIZE, tasks.cpp:26
+constexpr uint32_t MAX_STAT_LEN = 128;      // MAX_FIELD_STAT_LEN, tasks.cpp:25
+constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
+
+// ---- engine limits (inputs beyond them get NGSC_ERR_UNSUPPORTED, never a wrong stream) ------------
+constexpr uint32_t MAX_FIELDS = 32;         // separators per title
+constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant text field (Hamming mask bits)
+constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
+
+constexpr uint32_t BLOB_SLOT_256 = 336;     // >= 9 + ceil((256*9 + 255)/8) = 329
+constexpr uint32_t BLOB_SLOT_512 = 720;     // >= 9 + ceil((512*10 + 511)/8) = 713
+constexpr uint32_t TEXT_TREES = MAX_STAT_LEN + 1;
+
+// fastq_flags, defs.h:69-80
+enum : uint32_t {
+    F_TRY_LZ = 1, F_DNA_PLAIN = 2, F_CONST_NUM_FIELDS = 4, F_PLUS_ONLY = 8, F_USE_DELTA = 16,
+    F_DELTA_CONSTANT = 32, F_DELTA_NO_BEGIN_NUC = 64, F_VARIABLE_LENGTH = 128, F_LINE_BREAKS = 256
+};
+
+// error codes (mirrored in include/ngsc.h)
+enum : int {
+    OK = 0,
+    ERR_FORMAT = -1,       // not 4-line FASTQ with a bare '+' line / quality length != sequence length
+    ERR_FIELDS = -2,       // title with a different separator count than the sub-block's first record
+    ERR_TOOMANY = -3,      // > 100000 records in one sub-block
+    ERR_COLORSPACE = -4,   // SOLiD colour-space reads (phyNGSC.cpp:473-547): out of scope
+    ERR_RANGE = -5,        // numeric title value >= 2^31 or delta range >= 2^31
+    ERR_NOMEM = -6,
+    ERR_ARG = -7,
+    ERR_UNSUPPORTED = -8,  // engine limit exceeded (MAX_FIELDS, MAX_TEXT_LEN0, MAX_CODE_LEN, text slots)
+    ERR_HIP = -9,
+    ERR_CAPACITY = -10     // output buffer too small
+};
+
+enum : uint32_t { KIND_CONST = 0, KIND_NUM = 1, KIND_TEXT = 2 };
+
+// ---- small helpers --------------------------------------------------------------------------------
+// title separators " ._,=:/-#\n" (phyNGSC.cpp:208) as a 128-bit membership bitmap
+NGSC_HD bool is_sep(uint8_t c)
+{
+    const uint64_t lo = (1ull << 10) | (1ull << 32) | (1ull << 35) | (1ull << 44) | (1ull << 45) | (1ull << 46) |
+                        (1ull << 47) | (1ull << 58) | (1ull << 61);
+    const uint64_t hi = (1ull << (95 - 64));
+    return c < 64 ? ((lo >> c) & 1) : (c < 128 ? ((hi >> (c - 64)) & 1) : 0);
+}
+
+// trans_amb_codes (phyNGSC.cpp:184-206): 1 = ACGT, 2..16 = transferable IUPAC symbol, 0 = anything else
+NGSC_HD uint32_t amb_code(uint8_t c)
+{
+    switch (c) {
+    case 'A': case 'C': case 'G': case 'T': return 1;
+    case 'Y': return 2; case 'R': return 3; case 'W': return 4; case 'S': return 5;
+    case 'K': return 6; case 'M': return 7; case 'D': return 8; case 'V': return 9;
+    case 'H': return 10; case 'B': return 11; case 'N': return 12; case 'X': return 13;
+    case 'U': return 14; case '.': return 15; case '-': return 16;
+    default: return 0;
+    }
+}
+
+// quality byte of a transferred base (phyNGSC.cpp:579)
+NGSC_HD uint8_t transfer_quality(uint32_t amb, uint8_t q) { return (uint8_t)(128 + (amb << 3) - 16 + (q - 33)); }
+
+// BitStream::BitLength (bit_stream.h:268-277)
+NGSC_HD uint32_t bit_length(uint64_t x)
+{
+    for (uint32_t i = 0; i < 32; ++i)
+        if (x < (1ull << i)) return i;
+    return 64;
+}
+NGSC_HD uint32_t floor_log2_plus1(uint64_t x) { uint32_t b = 0; while (x) { ++b; x >>= 1; } return b; }
+NGSC_HD uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) ++b; return b; }
+
+// order-preserving int32 -> uint32 map, so every statistic is an unsigned max over zero-initialised memory
+NGSC_HD uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
+NGSC_HD int32_t unbias(uint32_t u) { return (int32_t)(u ^ 0x80000000u); }
+
+// utils::is_num + utils::to_num (utils.h:107-125).  v wraps like uint32; ovf is set when the true
+// value exceeds INT32_MAX (the reference then compares wrapped int32 values: unsupported).
+NGSC_HD bool parse_num(const uint8_t *b, uint32_t s, uint32_t e, uint32_t &v, bool &ovf)
+{
+    uint32_t len = e - s;
+    if (len == 0) return false;
+    uint64_t acc = 0;
+    bool big = false;
+    for (uint32_t i = s; i < e; ++i) {
+        uint32_t d = (uint32_t)b[i] - '0';
+        if (d > 9) return false;
+        acc = acc * 10 + d;
+        if (acc > 0x7fffffffull) { big = true; acc &= 0xffffffffull; }
+    }
+    if (len > 1 && b[s] == '0') return false;
+    v = (uint32_t)acc;
+    ovf = big;
+    return true;
+}
+
+// Number of separators in [ls, te] == number of title fields (phyNGSC.cpp:345-379, 409-415)
+NGSC_HD uint32_t count_fields(const uint8_t *b, uint32_t ls, uint32_t te)
+{
+    uint32_t n = 0;
+    for (uint32_t i = ls; i <= te; ++i) n += is_sep(b[i]);
+    return n;
+}
+
+// Advances over one field starting at pos: returns its end (position of the separator).
+NGSC_HD uint32_t field_end(const uint8_t *b, uint32_t pos)
+{
+    while (!is_sep(b[pos])) ++pos;
+    return pos;
+}
+
+NGSC_HD bool bytes_equal(const uint8_t *b, uint32_t s1, uint32_t s2, uint32_t len)
+{
+    for (uint32_t i = 0; i < len; ++i)
+        if (b[s1 + i] != b[s2 + i]) return false;
+    return true;
+}
+
+// ---- device-visible structures --------------------------------------------------------------------
+struct Cut {            // one sub-block (one iteration of the loop phyNGSC.cpp:168-906)
+    uint32_t rank;
+    uint32_t rec_lo;    // first record (index into the job's record table)
+    uint32_t n_rec;
+    uint32_t overlap;   // overlap value in force (informational)
+    uint64_t win_pos;   // file offset of the window
+    uint64_t wsize;     // r_buffer_size of the window
+};
+
+struct RankPlan {
+    uint32_t n_cuts;
+    int32_t overlap_used;  // wr_ov_used, phyNGSC.cpp:160
+    uint32_t first_rec;
+    int32_t err;
+};
+
+// Per (sub-block, field) statistics accumulated with unsigned atomicMax / atomicOr over zeroed memory.
+struct FieldStat {
+    uint32_t max_len;
+    uint32_t inv_min_len;   // max of ~len
+    uint32_t not_const;     // some record differs from record 0
+    uint32_t not_len_const;
+    uint32_t not_num;
+    uint32_t ovf;           // some numeric value >= 2^31
+    uint32_t max_v, inv_min_v;  // biased int32
+    uint32_t max_d, inv_min_d;  // biased int32 (deltas between consecutive records)
+    uint32_t not_ham[8];    // bit p set: some record differs from record 0 at position p (< 256)
+    uint32_t pad[6];
+};
+static_assert(sizeof(FieldStat) == 96, "FieldStat layout");
+
+// Finalised field description (tasks.cpp:196-222 + the header decisions of tasks.cpp:304-390)
+struct FieldDesc {
+    uint32_t start0;        // record 0's field start (offset in the job buffer)
+    uint32_t len0;
+    uint32_t sep;
+    uint32_t kind;          // KIND_*
+    uint32_t is_len_const;
+    uint32_t min_len, max_len;
+    int32_t min_v, max_v, min_d, max_d;
+    uint32_t delta_coding;
+    uint32_t bits_num, bits_val, bits_len;
+    uint32_t has_huff;      // numeric Huffman tree stored (tasks.cpp:338)
+    uint32_t n_sym;         // its symbol count (diff)
+    int32_t base;           // min_v or min_d
+    uint32_t slot;          // text statistics / code slot, 0xffffffff if none
+    uint32_t ham[8];        // Hamming mask bits (1 = every record equals record 0 at that position)
+    uint32_t pad[5];
+};
+static_assert(sizeof(FieldDesc) == 128, "FieldDesc layout");
+
+struct SbState {        // per sub-block scalars
+    uint32_t rec_lo, n_rec, rank, nf;
+    uint32_t max_q, max_s;          // atomicMax
+    uint32_t nsym, nqual, flags, lt_bits;
+    uint32_t qbits, dbits;          // payload bit totals
+    uint32_t qual_hdr, dna_hdr;     // header byte counts (alphabet + trees)
+    uint32_t title_hdr, title_body; // bytes
+    uint32_t info_len, title_len, qual_len, dna_len;
+    uint32_t total, pad0;
+    uint64_t out_off;               // byte offset of the sub-block in the output buffer
+    uint8_t symbols[256];
+    uint8_t qualities[256];
+    uint8_t sym_code[256];
+    uint8_t qua_code[256];
+};
+
+// Everything a kernel needs to find a sub-block's working memory.
+struct Arena {
+    // job-wide
+    const uint8_t *buf;     // FASTQ bytes of the job
+    uint32_t buf_len;
+    const uint32_t *te, *se, *ls;   // record table: title end, sequence end, line start (ls has n+1 entries)
+    uint32_t *slen;         // per record: post-transfer sequence length | transfer flag << 31
+    uint32_t *qoff;         // per record: quality payload bits, then exclusive offsets
+    uint32_t *doff;         // per record: DNA payload bits, then exclusive offsets
+    uint32_t *goff;         // per title group: bytes, then exclusive offsets
+    uint32_t *grp_lo;       // per sub-block: first title group index
+    int32_t *err;           // job error word (min over error codes)
+    // per sub-block arrays (index by sub-block)
+    SbState *sb;
+    FieldStat *fstat;       // [S][MAX_FIELDS]
+    FieldDesc *fdesc;       // [S][MAX_FIELDS]
+    uint32_t *dna_occ;      // [S][256]
+    uint32_t *qhist;        // [S][qrows][256]  row 0 = totals, row k+1 = position k
+    uint32_t *nhist;        // [S][MAX_FIELDS][512]
+    uint32_t *qcodes;       // [S][qrows][256]  entry = code<<5|len, indexed by alphabet index
+    uint8_t *qblob;         // [S][qrows][BLOB_SLOT_256]
+    uint32_t *qblob_len;    // [S][qrows]
+    uint32_t *dcodes;       // [S][256] indexed by raw base byte (plain: len 2)
+    uint8_t *dblob;         // [S][BLOB_SLOT_256]
+    uint32_t *dblob_len;    // [S]
+    uint32_t *ncodes;       // [S][MAX_FIELDS][512]
+    uint8_t *nblob;         // [S][MAX_FIELDS][BLOB_SLOT_512]
+    uint32_t *nblob_len;    // [S][MAX_FIELDS]
+    // text-field slot pool
+    uint32_t *slot_counter;
+    uint32_t *slot_owner;   // [n_slots] -> sub-block * MAX_FIELDS + field
+    uint32_t n_slots;
+    uint32_t *chist;        // [n_slots][129][256]
+    uint32_t *tcodes;       // [n_slots][129][256]
+    uint8_t *tblob;         // [n_slots][129][BLOB_SLOT_256]
+    uint32_t *tblob_len;    // [n_slots][129]
+    uint32_t qrows;         // job max quality length + 1
+    uint32_t n_sb;
+    uint8_t *out;           // output buffer
+};
+
+// ---- MSB-first bit sinks (BitStream semantics, bit_stream.h:149-200) ---------------------------------
+// Counts bits only.
+struct BitCounter {
+    uint64_t bits = 0;
+    NGSC_HD void put(uint32_t, uint32_t n) { bits += n; }
+    NGSC_HD void align() { bits = (bits + 7) & ~7ull; }
+    NGSC_HD void byte(uint8_t) { align(); bits += 8; }
+    NGSC_HD void word(uint32_t) { align(); bits += 32; }
+    NGSC_HD void bytes(const uint8_t *, uint32_t n) { align(); bits += 8ull * n; }
+    NGSC_HD uint64_t nbytes() const { return (bits + 7) >> 3; }
+};
+
+// Writes bytes to memory owned exclusively by the calling thread.
+struct ByteWriter {
+    uint8_t *p;
+    uint64_t acc = 0;
+    uint32_t nacc = 0;
+    uint64_t n = 0;
+    NGSC_HD explicit ByteWriter(uint8_t *dst) : p(dst) {}
+    NGSC_HD void put(uint32_t v, uint32_t nb)
+    {
+        if (!nb) return;
+        if (nb < 32) v &= (1u << nb) - 1u;
+        acc = (acc << nb) | v;
+        nacc += nb;
+        while (nacc >= 8) { p[n++] = (uint8_t)(acc >> (nacc - 8)); nacc -= 8; }
+        acc &= (1ull << nacc) - 1ull;
+    }
+    NGSC_HD void align()
+    {
+        if (nacc) { p[n++] = (uint8_t)(acc << (8 - nacc)); nacc = 0; acc = 0; }
+    }
+    NGSC_HD void byte(uint8_t b) { align(); p[n++] = b; }
+    NGSC_HD void word(uint32_t v)
+    {
+        align();
+        p[n++] = (uint8_t)(v >> 24); p[n++] = (uint8_t)(v >> 16); p[n++] = (uint8_t)(v >> 8); p[n++] = (uint8_t)v;
+    }
+    NGSC_HD void bytes(const uint8_t *d, uint32_t len) { align(); for (uint32_t i = 0; i < len; ++i) p[n++] = d[i]; }
+    NGSC_HD uint64_t nbytes() const { return n; }
+};
+
+// =====================================================================================================
+// Title logic (phyNGSC.cpp:342-423, tasks.cpp:22-223, tasks.cpp:289-510)
+// =====================================================================================================
+
+// libstdc++ doubles std::vector capacity, so while the reference push_back()s its Field objects
+// (phyNGSC.cpp:350) every Field pushed before the last reallocation is copy-constructed, and Field's
+// copy constructor (structures.h:126-202) drops num_values.  Only fields with index >= this value
+// still hold record 0's entry and keep counting values (tasks.cpp:175), i.e. can get a value-coding
+// Huffman tree.  Returns the largest power of two <= nf-1 (0 for nf == 1).
+NGSC_HD uint32_t num_values_kept_from(uint32_t nf)
+{
+    if (nf < 2) return 0;
+    uint32_t p = 1;
+    while (p * 2 <= nf - 1) p *= 2;
+    return p;
+}
+
+// Finalises one field from its statistics (tasks.cpp:196-222 and the decisions at tasks.cpp:324-338).
+// n_rec: records in the sub-block; f: field index; nf: field count.  Returns an error code.
+NGSC_HD int finalize_field(const FieldStat &st, uint32_t start0, uint32_t len0, uint8_t sep, uint32_t n_rec,
+                           uint32_t f, uint32_t nf, FieldDesc &d)
+{
+    d.start0 = start0;
+    d.len0 = len0;
+    d.sep = sep;
+    d.max_len = st.max_len;
+    d.min_len = ~st.inv_min_len;
+    d.is_len_const = !st.not_len_const;
+    d.slot = 0xffffffffu;
+    d.has_huff = 0;
+    d.n_sym = 0;
+    d.base = 0;
+    d.delta_coding = 0;
+    d.bits_num = d.bits_val = d.bits_len = 0;
+    d.min_v = d.max_v = 0;
+    d.min_d = 1;   // Field() defaults, structures.h:103-106
+    d.max_d = -1;
+    for (int i = 0; i < 8; ++i) d.ham[i] = ~st.not_ham[i];
+    if (!st.not_const) { d.kind = KIND_CONST; return OK; }
+    if (!st.not_num) {
+        if (st.ovf) return ERR_RANGE;
+        d.kind = KIND_NUM;
+        d.min_v = unbias(~st.inv_min_v);
+        d.max_v = unbias(st.max_v);
+        if (n_rec >= 2) { d.min_d = unbias(~st.inv_min_d); d.max_d = unbias(st.max_d); }
+        int64_t vr = (int64_t)d.max_v - d.min_v, dr = (int64_t)d.max_d - d.min_d;
+        if (dr > 0x7fffffffll) return ERR_RANGE;
+        d.delta_coding = !(vr < dr);
+        int64_t diff = d.delta_coding ? dr : vr;
+        d.bits_num = bit_length((uint64_t)diff);
+        d.bits_val = bit_length((uint64_t)vr);
+        if (d.bits_num > 32 || d.bits_val > 32) return ERR_RANGE;
+        diff += 1;
+        bool have_map = d.delta_coding ? (n_rec >= 2) : (f >= num_values_kept_from(nf));
+        if (diff <= (int64_t)MAX_NUM_HUF && have_map) {
+            d.has_huff = 1;
+            d.n_sym = (uint32_t)diff;
+            d.base = d.delta_coding ? d.min_d : d.min_v;
+        }
+        return OK;
+    }
+    d.kind = KIND_TEXT;
+    if (len0 > MAX_TEXT_LEN0) return ERR_UNSUPPORTED;
+    d.bits_len = bit_length((uint64_t)(d.max_len - d.min_len));
+    return OK;
+}
+
+NGSC_HD bool ham_bit(const FieldDesc &d, uint32_t j) { return j < d.len0 && ((d.ham[j >> 5] >> (j & 31)) & 1); }
+
+// Does position j of a text field get a Huffman tree? (tasks.cpp:364-377; tree 128: 378-387)
+NGSC_HD bool text_tree_needed(const FieldDesc &d, uint32_t j)
+{
+    if (j < MAX_STAT_LEN) {
+        uint32_t npos = d.max_len < MAX_STAT_LEN ? d.max_len : MAX_STAT_LEN;
+        return j < npos && !ham_bit(d, j);
+    }
+    return j == MAX_STAT_LEN && d.max_len >= MAX_STAT_LEN;
+}
+
+// Title header (tasks.cpp:302-390) written or measured through Sink.
+template <class Sink>
+NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
+{
+    const SbState &sb = A.sb[s];
+    const uint8_t *buf = A.buf;
+    w.word(sb.nf);
+    for (uint32_t f = 0; f < sb.nf; ++f) {
+        const FieldDesc &d = A.fdesc[(size_t)s * MAX_FIELDS + f];
+        w.byte((uint8_t)d.sep);
+        w.byte(d.kind == KIND_CONST);
+        if (d.kind == KIND_CONST) {
+            w.word(d.len0);
+            w.bytes(buf + d.start0, d.len0);
+            continue;
+        }
+        w.byte(d.kind == KIND_NUM);
+        if (d.kind == KIND_NUM) {
+            w.word((uint32_t)d.min_v);
+            w.word((uint32_t)d.max_v);
+            w.word((uint32_t)d.min_d);
+            w.word((uint32_t)d.max_d);
+            if (d.has_huff) {
+                size_t t = (size_t)s * MAX_FIELDS + f;
+                uint32_t bl = A.nblob_len[t];
+                w.align();
+                w.word(bl);
+                w.bytes(A.nblob + t * BLOB_SLOT_512, bl);
+            }
+            continue;
+        }
+        w.byte((uint8_t)d.is_len_const);
+        w.word(d.len0);
+        w.word(d.max_len);
+        w.word(d.min_len);
+        w.bytes(buf + d.start0, d.len0);
+        for (uint32_t j = 0; j < d.len0; ++j) w.put(ham_bit(d, j), 1);
+        for (uint32_t j = 0; j <= MAX_STAT_LEN; ++j) {
+            if (!text_tree_needed(d, j)) continue;
+            size_t t = (size_t)d.slot * TEXT_TREES + j;
+            uint32_t bl = A.tblob_len[t];
+            w.align();
+            w.word(bl);
+            w.bytes(A.tblob + t * BLOB_SLOT_256, bl);
+        }
+        w.align();
+    }
+}
+
+// One group of up to 32 records (tasks.cpp:393-509).  g0/g1 are record indices inside the job's
+// record table; the group's first record index inside the sub-block is a multiple of 32 by
+// construction.  Walks the titles of (group first, previous, current) record in lockstep so that no
+// per-field arrays are needed.
+template <class Sink>
+NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, Sink &w)
+{
+    const SbState &sb = A.sb[s];
+    const uint8_t *buf = A.buf;
+    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
+    const uint32_t nf = sb.nf;
+    // ---- pass A: group flags (BlockDesc: tasks.cpp:63-81, 127-147; store-time fix-up 406-424) ----
+    uint32_t txt_diff = 0, val_diff = 0, dlt_diff = 0;  // bit f set: not constant in this group
+    for (uint32_t r = g0 + 1; r < g1; ++r) {
+        uint32_t pf = A.ls[g0], pp = A.ls[r - 1], pc = A.ls[r];
+        for (uint32_t f = 0; f < nf; ++f) {
+            uint32_t ef = field_end(buf, pf), ep = field_end(buf, pp), ec = field_end(buf, pc);
+            const FieldDesc &d = fd[f];
+            if (d.kind == KIND_TEXT) {
+                if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) txt_diff |= 1u << f;
+            } else if (d.kind == KIND_NUM) {
+                uint32_t vf = 0, vp = 0, vc = 0;
+                bool o;
+                parse_num(buf, pf, ef, vf, o);
+                parse_num(buf, pp, ep, vp, o);
+                parse_num(buf, pc, ec, vc, o);
+                if (vc != vf) val_diff |= 1u << f;
+                if ((int32_t)(vc - vp) != d.min_d) dlt_diff |= 1u << f;
+            }
+            pf = ef + 1; pp = ep + 1; pc = ec + 1;
+        }
+    }
+    uint32_t gconst = 0;  // bit f: the group's flag bit
+    for (uint32_t f = 0; f < nf; ++f) {
+        const FieldDesc &d = fd[f];
+        if (d.kind == KIND_CONST) continue;
+        uint32_t flag;
+        if (d.kind == KIND_TEXT) flag = !((txt_diff >> f) & 1);
+        else if (d.delta_coding) {
+            // a one-record group keeps block_delta_constant == 0, which must equal min_delta (tasks.cpp:415)
+            flag = (g1 - g0 == 1) ? (d.min_d == 0) : !((dlt_diff >> f) & 1);
+        } else flag = !((val_diff >> f) & 1);
+        gconst |= flag << f;
+        w.put(flag, 1);
+    }
+    // ---- pass B: records ----
+    for (uint32_t r = g0; r < g1; ++r) {
+        uint32_t pp = r > g0 ? A.ls[r - 1] : A.ls[r], pc = A.ls[r];
+        for (uint32_t f = 0; f < nf; ++f) {
+            uint32_t ep = field_end(buf, pp), ec = field_end(buf, pc);
+            const FieldDesc &d = fd[f];
+            if (d.kind == KIND_NUM) {
+                uint32_t vp = 0, vc = 0;
+                bool o;
+                parse_num(buf, pc, ec, vc, o);
+                if (r == g0) {
+                    w.put(vc - (uint32_t)d.min_v, d.bits_val);               // tasks.cpp:457
+                } else if (!((gconst >> f) & 1)) {
+                    parse_num(buf, pp, ep, vp, o);
+                    uint32_t to_store = d.delta_coding ? (vc - vp - (uint32_t)d.min_d) : (vc - (uint32_t)d.min_v);
+                    if (d.has_huff) {
+                        uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                        w.put(e >> 5, e & 31);
+                    } else {
+                        w.put(to_store, d.bits_num);
+                    }
+                }
+            } else if (d.kind == KIND_TEXT) {
+                if (r == g0 || !((gconst >> f) & 1)) {                     // tasks.cpp:487
+                    uint32_t len = ec - pc;
+                    if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
+                    const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
+                    for (uint32_t j = 0; j < len; ++j) {
+                        if (!ham_bit(d, j)) {
+                            uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + buf[pc + j]];
+                            w.put(e >> 5, e & 31);
+                        }
+                    }
+                }
+            }
+            pp = ep + 1; pc = ec + 1;
+        }
+    }
+    w.align();  // tasks.cpp:508
+}
+
+// =====================================================================================================
+// Huffman: sequential part executed by one lane per tree (huffman.cpp:18-118)
+// =====================================================================================================
+// Inputs: sorted[n] = (freq << 32 | symbol) ascending.  Work arrays: ifreq[n], lc[2n], rc[2n], code[2n], len[2n],
+// stack[2n+2], blob (>= BLOB_SLOT bytes).  Outputs: code/len per node, blob bytes, returns blob length;
+// *max_len_out = longest code.
+NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t *ifreq, uint16_t *lc, uint16_t *rc,
+                                    uint32_t *code, uint8_t *len, uint16_t *stack, uint8_t *blob,
+                                    uint32_t *max_len_out)
+{
+    // compact: drop zero-frequency symbols while more than two remain (huffman.cpp:44-50)
+    uint32_t zeros = 0;
+    while (zeros < n && (sorted[zeros] >> 32) == 0) ++zeros;
+    uint32_t drop = n > 2 ? (zeros < n - 2 ? zeros : n - 2) : 0;
+    uint32_t present = n - drop;
+    for (uint32_t i = 0; i < 2 * n - 1; ++i) { code[i] = 0; len[i] = 0; }
+    // merge (huffman.cpp:57-70) as a two-queue merge; ties go to the smaller node id and a leaf id is
+    // always smaller than an internal id, which is the heap's (frequency, symbol) order
+    uint32_t lq = drop, iq = 0, made = 0;
+    for (uint32_t k = 0; k + 1 < present; ++k) {
+        uint32_t f2[2];
+        uint16_t id2[2];
+        for (int t = 0; t < 2; ++t) {
+            bool take_leaf;
+            if (lq < n && iq < made) take_leaf = (uint32_t)(sorted[lq] >> 32) <= ifreq[iq];
+            else take_leaf = lq < n;
+            if (take_leaf) { f2[t] = (uint32_t)(sorted[lq] >> 32); id2[t] = (uint16_t)(sorted[lq] & 0xffffu); ++lq; }
+            else { f2[t] = ifreq[iq]; id2[t] = (uint16_t)(n + iq); ++iq; }
+        }
+        ifreq[made] = f2[0] + f2[1];
+        lc[n + made] = id2[0];
+        rc[n + made] = id2[1];
+        ++made;
+    }
+    int root = (int)(n + present) - 2;
+    uint32_t mx = 0;
+    for (int i = root; i >= (int)n; --i) {  // huffman.cpp:73-79
+        uint8_t l = (uint8_t)(len[i] + 1);
+        len[lc[i]] = l; code[lc[i]] = code[i] << 1;
+        len[rc[i]] = l; code[rc[i]] = (code[i] << 1) | 1;
+        if (l > mx) mx = l;
+    }
+    *max_len_out = mx;
+    // blob (huffman.cpp:88-118): root_id, n_symbols, min_len, pre-order bits
+    uint32_t bits_per_id = 0;
+    while ((2u << bits_per_id) <= n) ++bits_per_id;
+    if (n & (n - 1)) ++bits_per_id;
+    uint32_t min_len = n;
+    for (uint32_t i = 0; i < n; ++i)
+        if (len[i] < min_len && len[i] > 0) min_len = len[i];
+    ByteWriter w(blob);
+    w.word((uint32_t)root);
+    w.word(n);
+    w.byte((uint8_t)min_len);
+    int sp = 0;
+    stack[sp++] = (uint16_t)root;
+    while (sp) {
+        uint16_t node = stack[--sp];
+        if (node < n) {
+            w.put(1, 1);
+            w.put(node, bits_per_id);
+        } else {
+            w.put(0, 1);
+            stack[sp++] = rc[node];
+            stack[sp++] = lc[node];
+        }
+    }
+    w.align();
+    return (uint32_t)w.nbytes();
+}
+
+// =====================================================================================================
+// Sub-block cuts for one virtual rank (phyNGSC.cpp:113-124, 168, 303-318, 745-755)
+// =====================================================================================================
+NGSC_HD uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct RankGeom {
+    int64_t region, wr_start, wr_end, bsize;
+    uint32_t overlap;
+};
+
+NGSC_HD RankGeom rank_geometry(uint64_t file_size, uint32_t P, uint32_t r)
+{
+    RankGeom g;
+    g.region = (int64_t)(file_size / P);
+    g.wr_start = (int64_t)r * g.region;
+    g.overlap = OVERLAP;
+    g.wr_end = (r != P - 1) ? g.wr_start + g.region + g.overlap - 1 : (int64_t)file_size - 1;
+    g.bsize = (int64_t)WINDOW;
+    if (g.region < g.bsize) {
+        g.bsize = g.wr_end - g.wr_start + 1;
+        if (r == P - 1) g.overlap = 0;
+    }
+    return g;
+}
+
+// te/ls are offsets inside the job buffer whose first byte is file offset buf_off; ls has n_rec+1 entries.
+// first_abs: file offset of the rank's first record (from the sync heuristic).  Returns an error code.
+NGSC_HD int plan_rank(uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_off, const uint32_t *te,
+                      const uint32_t *ls, uint32_t n_rec_total, uint64_t first_abs, Cut *cuts, uint32_t max_cuts,
+                      RankPlan *plan)
+{
+    RankGeom g = rank_geometry(file_size, P, r);
+    plan->n_cuts = 0;
+    plan->overlap_used = (int32_t)((int64_t)first_abs - g.wr_start);
+    uint32_t cur = lower_bound_u32(ls, n_rec_total + 1, first_abs - buf_off);
+    plan->first_rec = cur;
+    if (cur > n_rec_total || (uint64_t)ls[cur] + buf_off != first_abs) return ERR_FORMAT;
+    int64_t bytes_read = 0, win_pos = g.wr_start, bsize = g.bsize;
+    uint32_t overlap = g.overlap;
+    while (bytes_read < g.region) {
+        if (cur >= n_rec_total) return ERR_FORMAT;
+        int64_t wend = win_pos + bsize, stop_at = win_pos + bsize - (int64_t)overlap;
+        uint32_t last = cur;
+        // candidates after the first record need their title end inside the window (phyNGSC.cpp:268, 303-306)
+        int64_t wend_rel = wend - (int64_t)buf_off;
+        uint32_t m = wend_rel > 0 ? lower_bound_u32(te, n_rec_total, (uint64_t)wend_rel) : 0;  // te[m-1] < wend
+        if (m > cur + 1) {
+            // first record (other than `cur`, which is never tested: :295-300) whose next offset >= stop_at
+            int64_t stop_rel = stop_at - (int64_t)buf_off;
+            uint32_t lb = stop_rel > 0 ? lower_bound_u32(ls, n_rec_total + 1, (uint64_t)stop_rel) : 0;
+            uint32_t j = lb > 0 ? lb - 1 : 0;
+            if (j < cur + 1) j = cur + 1;
+            last = j < m - 1 ? j : m - 1;
+        }
+        uint32_t cnt = last - cur + 1;
+        if (cnt > MAX_RECORDS) return ERR_TOOMANY;
+        if (plan->n_cuts >= max_cuts) return ERR_NOMEM;
+        Cut &c = cuts[plan->n_cuts++];
+        c.rank = r; c.rec_lo = cur; c.n_rec = cnt; c.overlap = overlap;
+        c.win_pos = (uint64_t)win_pos; c.wsize = (uint64_t)bsize;
+        int64_t next_abs = (int64_t)ls[last + 1] + (int64_t)buf_off;
+        bytes_read = next_abs - g.wr_start;   // :745-746
+        win_pos = next_abs;
+        if (win_pos + bsize > g.wr_end) {      // :748-755
+            if (r == P - 1) overlap = 0;
+            bsize = g.wr_end - win_pos;
+        }
+        cur = last + 1;
+    }
+    return OK;
+}
+
+// =====================================================================================================
+// Block header / footer bit layouts (host side of the container: tasks.cpp:1104-1200)
+// =====================================================================================================
+NGSC_HD uint32_t header_size(uint32_t bewr, uint32_t beso, uint32_t nosb)
+{
+    return (bewr + 6 + 12 + beso * nosb + 5 + 2 + 7) / 8;  // structures.h:323-333
+}
+
+}  // namespace ngsc

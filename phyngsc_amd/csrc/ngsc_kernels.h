@@ -1,0 +1,43 @@
+// ngsc_kernels.h - launch entry points of the HIP kernels (internal to libngsc_hip.so).
+#pragma once
+#include "ngsc_common.h"
+#include <hip/hip_runtime.h>
+
+namespace ngsc {
+
+// ---- kernels_index.hip ----
+uint32_t index_num_tiles(uint32_t len);
+void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err);
+void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt);
+void launch_scan_tiles(hipStream_t st, uint32_t *tile_cnt, uint32_t n_tiles, uint32_t *total_lines);
+void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, const uint32_t *tile_off,
+                     uint32_t *te, uint32_t *se, uint32_t *ls, uint32_t rec_cap);
+void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
+                     uint32_t n_rec, uint32_t *max_q, int32_t *err);
+void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
+                 const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
+                 uint32_t max_cuts, RankPlan *plans, int32_t *err);
+
+// ---- kernels_stats.hip ----
+void launch_title_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_sq_finalize(hipStream_t st, const Arena &A);
+void launch_field_finalize(hipStream_t st, const Arena &A);
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec);
+
+// ---- kernels_huffman.hip ----
+void launch_huffman_sb(hipStream_t st, const Arena &A);
+void launch_huffman_text(hipStream_t st, const Arena &A);
+
+// ---- kernels_pack.hip ----
+void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_measure(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_scan_sb(hipStream_t st, const Arena &A);
+void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out);
+void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off);
+void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_pack(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
+
+}  // namespace ngsc
