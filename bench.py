@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py - GB/s of raw FASTQ compressed on MI355X (BASELINE.json metric), inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the whole hot path (record index, sub-block cuts, statistics, Huffman build, packed
+emit) over this process' share of the workload, with the FASTQ bytes already in HBM and the .ngsc
+sub-block bytes left in HBM.  N=1: BASELINE configs[1], 1 GB synthetic 36 bp ERR005195-style FASTQ,
+8 virtual ranks.  N>1 (weak scaling): a logical file of N x 1 GB (fixed-width variant of the same
+generator so that every process can produce its own byte range), 8 virtual ranks per GPU; the only
+collective is the block-size all-gather that assigns file offsets (RCCL).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from phyngsc_amd import api, fastq_gen, ngsc_format as nf  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
+    """Algorithmic HBM bytes of one launch of each kernel on this workload (kernel table)."""
+    n_rec = sum(sb.n_records for sb in res.subblocks)
+    bases = sum(sb.n_bases for sb in res.subblocks)
+    title_in = raw - 2 * bases - 4 * n_rec   # title lines incl. their newline
+    title_out = sum(sb.title_len for sb in res.subblocks)
+    sq_out = sum(sb.qual_len + sb.dna_len for sb in res.subblocks)
+    return {
+        "k_nl_count": raw,
+        "k_nl_write": raw + 12 * n_rec,
+        "k_validate": 12 * n_rec,
+        "k_title_stats": title_in,
+        "k_title_hist": title_in,
+        "k_title_measure": title_in,
+        "k_title_pack": title_in + title_out,
+        "k_seq_qual_stats": 2 * bases,
+        "k_measure_sq": 2 * bases + 8 * n_rec,
+        "k_pack_sq": 2 * bases + sq_out,
+    }
+
+
+def cpu_baseline(data: np.ndarray, P: int) -> dict:
+    """Reported-only CPU baseline on the host cores of the GPU box: the unmodified reference binary
+    (oracle/_ref, built in the build container) if it runs here, else the oracle port."""
+    cores = os.cpu_count() or 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "phyNGSC")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    sample = f"whole workload ({data.size} B), page-cached file"
+    if os.path.exists(ref) and os.path.exists(mpiexec):
+        try:
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                fq, out = os.path.join(tmp, "in.fastq"), os.path.join(tmp, "out.ngsc")
+                data.tofile(fq)
+                npn = min(P, cores)
+                t0 = time.time()
+                r = subprocess.run([mpiexec, "-np", str(npn), ref, fq, out, "1"], capture_output=True, text=True, timeout=600)
+                dt = time.time() - t0
+                if r.returncode == 0 and os.path.getsize(out) > 0:
+                    times = [float(l.split()[1]) for l in r.stdout.splitlines() if l[:1].isdigit() and len(l.split()) >= 4]
+                    comp = max(times) if times else dt
+                    return {"value": data.size / comp / 1e9, "unit": "GB/s", "cores": npn, "kind": "reference",
+                            "sample": sample + f"; mpiexec -np {npn} x 1 thread, slowest-rank COMP_TIME {comp:.2f} s "
+                                               f"(wall {dt:.2f} s)"}
+        except Exception:  # noqa: BLE001
+            pass
+    from oracle import binding as orc
+    thr = min(P, cores)
+    _, st = orc.compress_file(data, P, threads=thr)
+    return {"value": data.size / st.seconds / 1e9, "unit": "GB/s", "cores": thr, "kind": "port",
+            "sample": sample + f"; oracle/ngsc_oracle.c, {thr} OpenMP threads over {P} virtual ranks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size-mb", type=int, default=1000, help="raw FASTQ MB per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    per_gpu = args.size_mb * 1_000_000
+    RANKS_PER_GPU = 8
+    P = RANKS_PER_GPU * world
+    if world == 1:
+        cfg = fastq_gen.CFG2
+        host = fastq_gen.generate(cfg, target_bytes=per_gpu)
+        file_size, buf_off = int(host.size), 0
+        workload = f"cfg2: {host.size} B synthetic FASTQ, 36 bp ERR005195-style (seed 2), {P} virtual ranks, 1 GPU"
+    else:
+        cfg = fastq_gen.CFG2_FIXED
+        rs = fastq_gen.record_size(cfg)
+        n_per = per_gpu // rs
+        file_size = world * n_per * rs
+        lo, hi = api.job_byte_range(file_size, P, rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU)
+        buf_off = lo & ~15
+        host = fastq_gen.generate_range(cfg, buf_off, hi - buf_off)
+        workload = (f"cfg2-fixed: {file_size} B logical FASTQ ({world} x {n_per * rs} B), 36 bp, {P} virtual ranks, "
+                    f"{RANKS_PER_GPU} per GPU")
+    lo_rank, hi_rank = rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU
+    my_raw = (api.region_bounds(file_size, P, hi_rank - 1)[1] + 1 if hi_rank < P else file_size) - \
+        api.region_bounds(file_size, P, lo_rank)[0]
+    if hi_rank < P:
+        my_raw -= api.OVERLAP  # count each byte once: regions, not regions + overlap
+    d_in = torch.from_numpy(host).to(dev)
+    d_out = torch.empty(int(host.size * 0.45) + (32 << 20), dtype=torch.uint8, device=dev)
+    eng = api.Engine(local_rank)
+
+    def step():
+        return eng.compress_device(d_in, file_size, P, rank_lo=lo_rank, rank_hi=hi_rank, buf_off=buf_off, out=d_out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    eng.set_profiling(True)
+    eng.reset_kernel_times()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if world > 1:
+        # the one data-path-free collective: block sizes -> file offsets (RCCL all-gather over xGMI)
+        sizes_local = [[b.size for b in api.plan_blocks(P, rk.rank, [res.subblocks[rk.first_subblock + k].size
+                                                                     for k in range(rk.n_subblocks)])] for rk in res.ranks]
+        meta_local = [(rk.n_subblocks, rk.overlap_used) for rk in res.ranks]
+        sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=dev)
+        api.file_offsets(sizes_all)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([my_raw, res.total_bytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_raw, total_out = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_raw, total_out = file_size, res.total_bytes
+
+    ktimes = eng.kernel_times()
+    if rank == 0:
+        alg = algorithmic_bytes(res, my_raw)
+        per_kernel = {k: {"ms_avg": ms / max(n, 1), "launches": n} for k, (ms, n) in ktimes.items() if n}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_avg"])
+        dom_ms = per_kernel[dom]["ms_avg"]
+        achieved = alg.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if world == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        kernel_sum_ms = sum(v["ms_avg"] for v in per_kernel.values())
+        line = {
+            "metric": "GB/s raw FASTQ compressed at 1/2/4/8 MI355X; bit-exact .ngsc vs ref",
+            "value": total_raw * args.steps / dt / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": workload, "virtual_ranks": P, "raw_bytes": total_raw, "ngsc_bytes": total_out,
+                       "ratio": total_out / total_raw, "subblocks_rank0": len(res.subblocks)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_ms": dom_ms},
+            "pipeline": {"kernel_ms_sum": kernel_sum_ms, "raw_GBps_over_kernel_time": my_raw / (kernel_sum_ms * 1e-3) / 1e9
+                         if kernel_sum_ms else None, "frac_of_hbm_read_roofline": my_raw / (kernel_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                         if kernel_sum_ms else None},
+            "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])},
+        }
+        if world == 1 and not args.no_verify:
+            out = api.assemble_container(res, P, file_size)
+            man_path = os.path.join(ROOT, "tests", "golden", "manifest_cfg2_1GB.json")
+            verdict = None
+            if os.path.exists(man_path):
+                with open(man_path) as f:
+                    man = json.load(f)
+                if man["fastq_bytes"] == file_size and str(P) in man["ranks"]:
+                    verdict = nf.manifest(out) == man["ranks"][str(P)]
+            line["bit_exact_vs_reference_manifest"] = verdict
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host, P)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

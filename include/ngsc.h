@@ -64,6 +64,8 @@ typedef struct {
     uint64_t out_off;
     uint32_t info_len, title_len, qual_len, dna_len; /* stream order info|title|quality|DNA */
     uint32_t max_qlen, max_slen, nsym, nqual, flags, n_fields;
+    uint32_t n_bases;    /* sum of read lengths: sequence bytes == quality bytes of the sub-block */
+    uint32_t reserved;
 } ngsc_subblock_t;
 
 typedef struct {

@@ -27,7 +27,8 @@ class SubBlock(ctypes.Structure):
                 ("wsize", ctypes.c_uint64), ("out_off", ctypes.c_uint64), ("info_len", ctypes.c_uint32),
                 ("title_len", ctypes.c_uint32), ("qual_len", ctypes.c_uint32), ("dna_len", ctypes.c_uint32),
                 ("max_qlen", ctypes.c_uint32), ("max_slen", ctypes.c_uint32), ("nsym", ctypes.c_uint32),
-                ("nqual", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("n_fields", ctypes.c_uint32)]
+                ("nqual", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("n_fields", ctypes.c_uint32),
+                ("n_bases", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
     @property
     def size(self) -> int:

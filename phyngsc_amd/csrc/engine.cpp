@@ -471,6 +471,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         r.info_len = x.info_len; r.title_len = x.title_len; r.qual_len = x.qual_len; r.dna_len = x.dna_len;
         r.max_qlen = x.max_q; r.max_slen = x.max_s; r.nsym = x.nsym; r.nqual = x.nqual; r.flags = x.flags;
         r.n_fields = x.nf;
+        r.n_bases = x.n_bases;
     }
     for (auto &rk : c->res_rank) {
         if (!rk.n_subblocks) continue;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
     if (*A.err) return;
     extern __shared__ __align__(16) uint32_t s_hist[];  // [lds_rows][HIST_STRIDE]
     __shared__ uint32_t s_occ[256];
-    __shared__ uint32_t s_max[2];
+    __shared__ uint32_t s_max[3];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
 
     for (uint32_t k = tid; k < lds_rows * HIST_STRIDE; k += SQ_THREADS) s_hist[k] = 0;
     s_occ[tid] = 0;
-    if (tid < 2) s_max[tid] = 0;
+    if (tid < 3) s_max[tid] = 0;
     __syncthreads();
 
-    uint32_t cA = 0, cC = 0, cG = 0, cT = 0, wmax_q = 0, wmax_s = 0;
+    uint32_t cA = 0, cC = 0, cG = 0, cT = 0, wmax_q = 0, wmax_s = 0, wbases = 0;
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     for (uint32_t r = r_begin + wave; r < r_end; r += SQ_WAVES) {
         const uint32_t g = rec_lo + r;
@@ -202,12 +202,13 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
             kept += __popcll(__ballot(keep));
         }
         if (lane == 0) A.slen[g] = kept | ((uint32_t)xfer << 31);
+        wbases += L;
         wmax_q = L > wmax_q ? L : wmax_q;
         wmax_s = kept > wmax_s ? kept : wmax_s;
     }
     if (lane == 0) {
         atomicAdd(&s_occ['A'], cA); atomicAdd(&s_occ['C'], cC); atomicAdd(&s_occ['G'], cG); atomicAdd(&s_occ['T'], cT);
-        atomicMax(&s_max[0], wmax_q); atomicMax(&s_max[1], wmax_s);
+        atomicMax(&s_max[0], wmax_q); atomicMax(&s_max[1], wmax_s); atomicAdd(&s_max[2], wbases);
     }
     __syncthreads();
     for (uint32_t k = tid; k < lds_rows * HIST_COLS; k += SQ_THREADS) {
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
         if (v) atomicAdd(&qh[(size_t)row * 256 + 33 + col], v);
     }
     if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
-    if (tid == 0) { atomicMax(&A.sb[s].max_q, s_max[0]); atomicMax(&A.sb[s].max_s, s_max[1]); }
+    if (tid == 0) { atomicMax(&A.sb[s].max_q, s_max[0]); atomicMax(&A.sb[s].max_s, s_max[1]); atomicAdd(&A.sb[s].n_bases, s_max[2]); }
 }
 
 // One workgroup of 256 threads per sub-block; thread = byte value.

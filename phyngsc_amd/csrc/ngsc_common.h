@@ -202,7 +202,8 @@ struct SbState {        // per sub-block scalars
     uint32_t qual_hdr, dna_hdr;     // header byte counts (alphabet + trees)
     uint32_t title_hdr, title_body; // bytes
     uint32_t info_len, title_len, qual_len, dna_len;
-    uint32_t total, pad0;
+    uint32_t total;
+    uint32_t n_bases;               // sum of sequence lengths (= quality bytes) of the sub-block
     uint64_t out_off;               // byte offset of the sub-block in the output buffer
     uint8_t symbols[256];
     uint8_t qualities[256];

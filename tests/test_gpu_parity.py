@@ -1,0 +1,218 @@
+"""Parity tests proper (-m gpu): the HIP engine, called through the C ABI of libngsc_hip.so, against
+ (1) the committed outputs of the unmodified reference (tests/golden/small/*.ngsc),
+ (2) reference manifests of generator-made inputs up to BASELINE's 1 GB configuration,
+ (3) the oracle on further seeded inputs,
+ (4) size-independent properties: rank-split invariance, repeatability, record conservation,
+ plus the error behaviour of the boundary.  Bar: bit-exact (integer / byte work)."""
+import ctypes
+import glob
+import json
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import binding as orc  # noqa: E402
+from phyngsc_amd import _lib, api, fastq_gen, ngsc_format as nf  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SMALL = sorted(glob.glob(os.path.join(GOLDEN, "small", "*.ngsc")))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    e = api.Engine(0)
+    yield e
+    e.close()
+
+
+def _gpu(eng, data, P):
+    arr = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data
+    d_in = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    res = eng.compress_device(d_in, arr.size, P)
+    return res, api.assemble_container(res, P, arr.size)
+
+
+def test_native_library_is_loaded():
+    L = _lib.lib()
+    assert L.ngsc_version() == 100
+    with open("/proc/self/maps") as f:
+        assert "libngsc_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("ngsc_path", SMALL, ids=[os.path.basename(p) for p in SMALL])
+def test_reference_goldens(eng, ngsc_path):
+    m = re.match(r"(.*)\.p(\d+)\.ngsc$", ngsc_path)
+    with open(m.group(1) + ".fastq", "rb") as f:
+        data = f.read()
+    with open(ngsc_path, "rb") as f:
+        ref = f.read()
+    _, out = _gpu(eng, data, int(m.group(2)))
+    ok, msg = nf.equivalent(ref, out)
+    assert ok, msg
+
+
+def _manifest_params():
+    res = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "manifest_*.json"))):
+        with open(p) as f:
+            man = json.load(f)
+        for P in sorted(man["ranks"], key=int):
+            res.append(pytest.param(p, int(P), id=f"{os.path.basename(p)[9:-5]}-P{P}"))
+    return res
+
+
+@pytest.mark.parametrize("man_path,P", _manifest_params())
+def test_reference_manifests(eng, man_path, P):
+    """Generator-made inputs (10 MiB .. 1 GB): per-(WRID,k) block hashes + footer of the reference."""
+    with open(man_path) as f:
+        man = json.load(f)
+    data = fastq_gen.generate(fastq_gen.GenConfig(**man["generator"]), target_bytes=man["target_bytes"])
+    assert data.size == man["fastq_bytes"]
+    _, out = _gpu(eng, data, P)
+    got = nf.manifest(out)
+    assert got["footer"] == man["ranks"][str(P)]["footer"]
+    assert got["blocks"] == man["ranks"][str(P)]["blocks"]
+
+
+ORACLE_CASES = [
+    # (name, config, bytes, P)
+    ("36bp_P3", fastq_gen.GenConfig(seed=11, style=0), 20_000_000, 3),
+    ("150bp_N_P5", fastq_gen.GenConfig(seed=12, style=1, len_min=150, len_max=150, qual_model=1, n_rate_ppm=5000,
+                                       n_lowq_pct=50), 40_000_000, 5),
+    ("mixed_36_200_P8", fastq_gen.GenConfig(seed=13, style=2, len_min=36, len_max=200, qual_model=2, n_rate_ppm=3000,
+                                            n_lowq_pct=90), 50_000_000, 8),
+    ("short_20_60_P2", fastq_gen.GenConfig(seed=14, style=1, len_min=20, len_max=60, qual_model=0), 30_000_000, 2),
+    ("long_300_P8", fastq_gen.GenConfig(seed=15, style=0, len_min=100, len_max=220, qual_model=2, n_rate_ppm=100000,
+                                        n_lowq_pct=100), 20_000_000, 8),
+]
+
+
+@pytest.mark.parametrize("name,cfg,size,P", ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
+def test_against_oracle(eng, name, cfg, size, P):
+    data = fastq_gen.generate(cfg, target_bytes=size)
+    _, out = _gpu(eng, data, P)
+    want, _ = orc.compress_file(data, P, threads=8)
+    assert out == want
+
+
+def test_rank_split_invariance_and_repeatability(eng):
+    """Compressing ranks [0,4) and [4,8) in separate calls (as two processes would) gives the same
+    sub-block bytes as one whole-file call; a second identical call gives identical bytes."""
+    data = fastq_gen.generate(fastq_gen.GenConfig(seed=21, style=0), target_bytes=120_000_000)
+    P = 8
+    d_in = torch.from_numpy(data).cuda()
+    whole = eng.compress_device(d_in, data.size, P)
+    whole_host = whole.out[:whole.total_bytes].cpu().numpy().copy()
+    again = eng.compress_device(d_in, data.size, P)
+    assert np.array_equal(again.out[:again.total_bytes].cpu().numpy(), whole_host)
+    parts = []
+    for lo, hi in ((0, 4), (4, 8)):
+        b0, b1 = api.job_byte_range(data.size, P, lo, hi)
+        # 16-byte aligned start for the device buffer
+        b0a = b0 & ~15
+        part = torch.from_numpy(data[b0a:b1].copy()).cuda()
+        r = eng.compress_device(part, data.size, P, rank_lo=lo, rank_hi=hi, buf_off=b0a)
+        parts.append(r.out[:r.total_bytes].cpu().numpy().copy())
+        assert [rk.rank for rk in r.ranks] == list(range(lo, hi))
+    assert np.array_equal(np.concatenate(parts), whole_host)
+    # record conservation: every record of the file is in exactly one sub-block
+    n_rec = int((data == 10).sum()) // 4
+    assert sum(sb.n_records for sb in whole.subblocks) == n_rec
+
+
+def test_full_size_properties_1gb(eng):
+    """BASELINE configs[1] size (1 GB, 36 bp): structure checks that do not need the reference -
+    sizes add up, every sub-block header carries its record count, total records conserved."""
+    data = fastq_gen.generate(fastq_gen.CFG2, target_bytes=1_000_000_000)
+    d_in = torch.from_numpy(data).cuda()
+    res = eng.compress_device(d_in, data.size, 8)
+    host = res.out[:res.total_bytes].cpu().numpy()
+    off = 0
+    for sb in res.subblocks:
+        assert sb.out_off == off
+        n, maxq = struct.unpack(">II", host[off:off + 8].tobytes())
+        assert n == sb.n_records and maxq == 36
+        off += sb.size
+    assert off == res.total_bytes
+    assert sum(sb.n_records for sb in res.subblocks) == int((data == 10).sum()) // 4
+    assert sum(sb.n_bases for sb in res.subblocks) == 36 * (int((data == 10).sum()) // 4)
+
+
+# ---- error behaviour of the boundary -----------------------------------------------------------------
+def _expect_error(eng, data: bytes, P: int, code: int):
+    arr = np.frombuffer(data, dtype=np.uint8)
+    d_in = torch.from_numpy(arr.copy()).cuda()
+    with pytest.raises(api.NgscError) as ei:
+        eng.compress_device(d_in, arr.size, P)
+    assert ei.value.code == code, ei.value
+
+
+def _fq(n, title=lambda i: f"@r.{i}", seq="ACGTACGTAC", qual="IIIIIIIIII", plus="+"):
+    return "".join(f"{title(i)}\n{seq}\n{plus}\n{qual}\n" for i in range(n)).encode()
+
+
+def test_error_plus_line_repeats_title(eng):
+    # README.md:129-151: '+title' records are invalid input for the reference; we report NGSC_ERR_FORMAT
+    _expect_error(eng, _fq(400, plus="+r"), 2, -1)
+
+
+def test_error_quality_length_mismatch(eng):
+    _expect_error(eng, _fq(400, qual="IIIIIIIII"), 2, -1)
+
+
+def test_error_field_count_changes(eng):
+    _expect_error(eng, _fq(400, title=lambda i: f"@r.{i}" if i % 7 else f"@r.{i}.x"), 2, -2)
+
+
+def test_error_colorspace(eng):
+    _expect_error(eng, _fq(400, seq="T012301230", qual="IIIIIIIIII"), 2, -4)
+
+
+def test_error_numeric_overflow(eng):
+    _expect_error(eng, _fq(400, title=lambda i: f"@r:{3_000_000_000 + i}"), 2, -5)
+
+
+def test_error_output_capacity(eng):
+    data = fastq_gen.generate(fastq_gen.CFG1, target_bytes=2 << 20)
+    d_in = torch.from_numpy(data).cuda()
+    small = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.NgscError) as ei:
+        eng.compress_device(d_in, data.size, 2, out=small)
+    assert ei.value.code == -10
+    # the engine still works afterwards and reports the size that was needed
+    res = eng.compress_device(d_in, data.size, 2)
+    assert res.total_bytes > 4096
+
+
+def test_error_bad_arguments(eng):
+    data = fastq_gen.generate(fastq_gen.CFG1, target_bytes=1 << 20)
+    d_in = torch.from_numpy(data).cuda()
+    for kwargs in (dict(P=1), dict(P=4, rank_lo=3, rank_hi=2), dict(P=4, rank_lo=0, rank_hi=5)):
+        with pytest.raises(api.NgscError) as ei:
+            eng.compress_device(d_in, data.size, **kwargs)
+        assert ei.value.code == -7
+
+
+def test_cli_file_to_file(tmp_path):
+    """`ngsc <in.fastq> <out.ngsc>`: the command line the reference exposes (phyNGSC.cpp:61-108)."""
+    data = fastq_gen.generate(fastq_gen.CFG1, target_bytes=12_000_000)
+    inp, outp = tmp_path / "in.fastq", tmp_path / "out.ngsc"
+    data.tofile(inp)
+    exe = os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc")
+    r = subprocess.run([exe, str(inp), str(outp), "1", "--ranks", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _ = orc.compress_file(data, 4, threads=4)
+    assert outp.read_bytes() == want
+    # usage error -> exit code 1 like the reference
+    assert subprocess.run([exe], capture_output=True).returncode == 1
+    assert subprocess.run([exe, "/nonexistent.fastq", str(outp)], capture_output=True).returncode == 2
