@@ -266,6 +266,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
     Carver cs;
     size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
+    size_t o_maxrec = cs.take(4);
     size_t o_outtot = cs.take(8);
     size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
     size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
@@ -276,6 +277,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     int32_t *d_err = (int32_t *)(sm + o_err);
     uint32_t *d_total = (uint32_t *)(sm + o_total), *d_start = (uint32_t *)(sm + o_start);
     uint32_t *d_maxq = (uint32_t *)(sm + o_maxq), *d_slotc = (uint32_t *)(sm + o_slotc);
+    uint32_t *d_maxrec = (uint32_t *)(sm + o_maxrec);
     uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
     RankPlan *d_plans = (RankPlan *)(sm + o_plans);
     Cut *d_cuts = (Cut *)(sm + o_cuts);
@@ -308,7 +310,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     Carver cr;
     size_t o_te = cr.take(4 * rec_cap), o_se = cr.take(4 * rec_cap), o_ls = cr.take(4 * (rec_cap + 1));
     size_t o_slen = cr.take(4 * rec_cap), o_qoff = cr.take(4 * rec_cap), o_doff = cr.take(4 * rec_cap);
-    size_t o_goff = cr.take(4 * grp_cap);
+    size_t o_goff = cr.take(4 * grp_cap), o_gflags = cr.take(4 * grp_cap), o_tbits = cr.take(4 * rec_cap);
     rc = ensure(c, c->recs, cr.off);
     if (rc) return rc;
     uint8_t *rb = (uint8_t *)c->recs.p;
@@ -319,7 +321,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     {
         KScope k(c, st, "k_validate");
-        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_err);
+        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_maxrec, d_err);
     }
     {
         KScope k(c, st, "k_cuts");
@@ -332,6 +334,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipStreamSynchronize(st));
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
     const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
+    const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
     const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
     const Cut *h_cuts = (const Cut *)(hp + o_cuts);
     std::vector<Cut> cuts;
@@ -375,6 +378,15 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_ncodes = cp.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
     size_t p_nblob = cp.take((size_t)S * MAX_FIELDS * BLOB_SLOT_512);
     size_t p_nblen = cp.take(4 * (size_t)S * MAX_FIELDS);
+    // tiled fast path: R records per tile (0 = records too long for the LDS budget -> untiled kernels)
+    uint32_t r_max = 256;
+    if (const char *ev = getenv("NGSC_TILE_RECORDS")) r_max = (uint32_t)atoi(ev);
+    const uint32_t R = tile_records_for(max_rec_bytes, r_max);
+    uint32_t n_tiles = 0;
+    std::vector<uint32_t> tile_lo(S);
+    for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
+    size_t p_tilelo = cp.take(4 * (size_t)S);
+    size_t p_wq = cp.take(4 * ((size_t)n_tiles * 4 + 8)), p_wd = cp.take(4 * ((size_t)n_tiles * 4 + 8));
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
     Carver ct;
@@ -394,6 +406,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.slen = (uint32_t *)(rb + o_slen); A.qoff = (uint32_t *)(rb + o_qoff); A.doff = (uint32_t *)(rb + o_doff);
     A.goff = (uint32_t *)(rb + o_goff);
     A.grp_lo = (uint32_t *)(pb + p_grplo);
+    A.tbits = (uint32_t *)(rb + o_tbits);
+    A.gflags = (uint32_t *)(rb + o_gflags);
+    A.wq = (uint32_t *)(pb + p_wq);
+    A.wd = (uint32_t *)(pb + p_wd);
+    A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;
     A.sb = (SbState *)(pb + p_sb);
     A.fstat = (FieldStat *)(zb + z_fstat);
@@ -424,7 +441,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
 
     // host-initialised SbState + group offsets
     size_t sb_bytes = sizeof(SbState) * (size_t)S;
-    rc = ensure_pinned(c, cs.off + sb_bytes + 4 * (size_t)S + 4096);
+    rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + 4096);
     if (rc) return rc;
     hp = (uint8_t *)c->h_pin;
     SbState *h_sb = (SbState *)hp;
@@ -441,18 +458,30 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (gacc > grp_cap) return NGSC_ERR_NOMEM;
     HIPCHK(c, hipMemcpyAsync(A.sb, h_sb, sb_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(A.grp_lo, h_grp, 4 * (size_t)S, hipMemcpyHostToDevice, st));
+    memcpy(h_grp + S, tile_lo.data(), 4 * (size_t)S);
+    HIPCHK(c, hipMemcpyAsync(A.tile_lo, h_grp + S, 4 * (size_t)S, hipMemcpyHostToDevice, st));
 
     // ---- stage C ----
-    { KScope k(c, st, "k_title_stats"); launch_title_stats(st, A, max_rec); }
-    { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
+    if (R) {
+        { KScope k(c, st, "k_title_stats_tile"); launch_title_stats_tile(st, A, max_rec, R, max_rec_bytes); }
+        { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
+    } else {
+        { KScope k(c, st, "k_title_stats"); launch_title_stats(st, A, max_rec); }
+        { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
+    }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
     { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
     { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec); }
     { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-    { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
-    { KScope k(c, st, "k_title_measure"); launch_title_measure(st, A, max_rec); }
-    { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
+    if (R) {
+        { KScope k(c, st, "k_measure_tile"); launch_measure_tile(st, A, max_rec, R, max_rec_bytes); }
+        { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
+    } else {
+        { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
+        { KScope k(c, st, "k_title_measure"); launch_title_measure(st, A, max_rec); }
+        { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
+    }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
     // ---- sync 3: sizes ----
     HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, st));
@@ -487,8 +516,12 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)std::min<uint64_t>(out_cap, (total + 15) & ~15ull), st));
     { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
-    { KScope k(c, st, "k_title_pack"); launch_title_pack(st, A, max_rec); }
-    { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    if (R) {
+        { KScope k(c, st, "k_pack_tile"); launch_pack_tile(st, A, max_rec, R, max_rec_bytes); }
+    } else {
+        { KScope k(c, st, "k_title_pack"); launch_title_pack(st, A, max_rec); }
+        { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    }
     HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());

@@ -149,14 +149,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
 //   line 2 must be a bare '+', quality length must equal sequence length (README.md:97-103).
 // The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
 __global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint32_t *te, const uint32_t *se,
-                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, int32_t *err)
+                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, int32_t *err)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t L = 0;
+    uint32_t L = 0, RB = 0;
     bool bad = false;
     if (r < n_rec) {
         uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
         L = s - t - 1;
+        RB = l1 - l0;
         bad = !(t >= l0 && s > t) || buf[s + 1] != '+' || buf[s + 2] != '\n' || l1 != 2 * s - t + 3;
     }
     if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_q, m);
+    uint32_t mb = RB;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mb, d); mb = o > mb ? o : mb; }
+    if ((threadIdx.x & 63) == 0 && mb) atomicMax(max_rec, mb);
 }
 
 // First-record synchronisation of every virtual rank > 0 (phyNGSC.cpp:131-156): first '@' at or after
@@ -252,10 +257,10 @@ void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uin
 }
 
 void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
-                     uint32_t n_rec, uint32_t *max_q, int32_t *err)
+                     uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, int32_t *err)
 {
     if (!n_rec) return;
-    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, err);
+    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, max_rec, err);
 }
 
 void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,

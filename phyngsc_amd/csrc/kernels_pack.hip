@@ -380,6 +380,7 @@ void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     uint32_t le = lds_entries_for(A.qrows);
     dim3 grid((max_rec + PK_REC_PER_WG - 1) / PK_REC_PER_WG, A.n_sb);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_measure_sq), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
     hipLaunchKernelGGL(k_measure_sq, grid, dim3(PK_THREADS), le * sizeof(uint32_t), st, A, le);
 }
 
@@ -421,6 +422,7 @@ void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     uint32_t le = lds_entries_for(A.qrows);
     dim3 grid((max_rec + PK_REC_PER_WG - 1) / PK_REC_PER_WG, A.n_sb);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_pack_sq), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
     hipLaunchKernelGGL(k_pack_sq, grid, dim3(PK_THREADS), le * sizeof(uint32_t), st, A, le);
 }
 

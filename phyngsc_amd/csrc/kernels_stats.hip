@@ -418,6 +418,7 @@ void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
     uint32_t rows = A.qrows < HIST_MAX_ROWS ? A.qrows : HIST_MAX_ROWS;
     dim3 grid((max_rec + SQ_REC_PER_WG - 1) / SQ_REC_PER_WG, A.n_sb);
     size_t lds = (size_t)rows * HIST_STRIDE * sizeof(uint32_t);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_seq_qual_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 100 << 10);
     hipLaunchKernelGGL(k_seq_qual_stats, grid, dim3(SQ_THREADS), lds, st, A, rows);
 }
 

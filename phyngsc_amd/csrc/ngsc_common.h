@@ -222,6 +222,10 @@ struct Arena {
     uint32_t *doff;         // per record: DNA payload bits, then exclusive offsets
     uint32_t *goff;         // per title group: bytes, then exclusive offsets
     uint32_t *grp_lo;       // per sub-block: first title group index
+    uint32_t *tbits;        // per record: title bits (tiled path)
+    uint32_t *gflags;       // per title group: flag bits (tiled path)
+    uint32_t *wq, *wd;      // per (tile, wave): quality / DNA payload bits of the wave's symbol chunk, then offsets
+    uint32_t *tile_lo;      // per sub-block: first tile index
     int32_t *err;           // job error word (min over error codes)
     // per sub-block arrays (index by sub-block)
     SbState *sb;
@@ -422,89 +426,126 @@ NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
     }
 }
 
-// One group of up to 32 records (tasks.cpp:393-509).  g0/g1 are record indices inside the job's
-// record table; the group's first record index inside the sub-block is a multiple of 32 by
-// construction.  Walks the titles of (group first, previous, current) record in lockstep so that no
-// per-field arrays are needed.
-template <class Sink>
-NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, Sink &w)
+// ---- 32-record title groups (tasks.cpp:393-509), decomposed per record --------------------------------
+// All functions take the byte buffer explicitly (`buf[pos]`, pos = offset inside the job buffer) so that a
+// kernel can hand in an LDS-resident tile (pointer rebased by the tile's first offset).
+
+struct TitleDiffs {
+    uint32_t txt, val, dlt;  // bit f set: field f of this record breaks the group's constancy
+};
+
+// Record at p_cur (not the group's first record) against the group's first record (p_first) and its
+// predecessor (p_prev): BlockDesc updates of tasks.cpp:63-81 and 127-147, plus the store-time rule that a
+// constant delta only counts when it equals min_delta (tasks.cpp:415).
+NGSC_HD TitleDiffs title_record_diffs(const uint8_t *buf, const FieldDesc *fd, uint32_t nf, uint32_t p_first,
+                                      uint32_t p_prev, uint32_t p_cur)
 {
-    const SbState &sb = A.sb[s];
-    const uint8_t *buf = A.buf;
-    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
-    const uint32_t nf = sb.nf;
-    // ---- pass A: group flags (BlockDesc: tasks.cpp:63-81, 127-147; store-time fix-up 406-424) ----
-    uint32_t txt_diff = 0, val_diff = 0, dlt_diff = 0;  // bit f set: not constant in this group
-    for (uint32_t r = g0 + 1; r < g1; ++r) {
-        uint32_t pf = A.ls[g0], pp = A.ls[r - 1], pc = A.ls[r];
-        for (uint32_t f = 0; f < nf; ++f) {
-            uint32_t ef = field_end(buf, pf), ep = field_end(buf, pp), ec = field_end(buf, pc);
-            const FieldDesc &d = fd[f];
-            if (d.kind == KIND_TEXT) {
-                if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) txt_diff |= 1u << f;
-            } else if (d.kind == KIND_NUM) {
-                uint32_t vf = 0, vp = 0, vc = 0;
-                bool o;
-                parse_num(buf, pf, ef, vf, o);
-                parse_num(buf, pp, ep, vp, o);
-                parse_num(buf, pc, ec, vc, o);
-                if (vc != vf) val_diff |= 1u << f;
-                if ((int32_t)(vc - vp) != d.min_d) dlt_diff |= 1u << f;
-            }
-            pf = ef + 1; pp = ep + 1; pc = ec + 1;
+    TitleDiffs r = {0, 0, 0};
+    uint32_t pf = p_first, pp = p_prev, pc = p_cur;
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t ef = field_end(buf, pf), ep = field_end(buf, pp), ec = field_end(buf, pc);
+        const FieldDesc &d = fd[f];
+        if (d.kind == KIND_TEXT) {
+            if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) r.txt |= 1u << f;
+        } else if (d.kind == KIND_NUM) {
+            uint32_t vf = 0, vp = 0, vc = 0;
+            bool o;
+            parse_num(buf, pf, ef, vf, o);
+            parse_num(buf, pp, ep, vp, o);
+            parse_num(buf, pc, ec, vc, o);
+            if (vc != vf) r.val |= 1u << f;
+            if ((int32_t)(vc - vp) != d.min_d) r.dlt |= 1u << f;
         }
+        pf = ef + 1; pp = ep + 1; pc = ec + 1;
     }
-    uint32_t gconst = 0;  // bit f: the group's flag bit
+    return r;
+}
+
+// Group flag bits from the OR of its records' diffs.  bit f = the flag written for field f (1 = constant).
+NGSC_HD uint32_t title_group_const(const FieldDesc *fd, uint32_t nf, TitleDiffs g, uint32_t group_size)
+{
+    uint32_t gconst = 0;
     for (uint32_t f = 0; f < nf; ++f) {
         const FieldDesc &d = fd[f];
         if (d.kind == KIND_CONST) continue;
         uint32_t flag;
-        if (d.kind == KIND_TEXT) flag = !((txt_diff >> f) & 1);
+        if (d.kind == KIND_TEXT) flag = !((g.txt >> f) & 1);
         else if (d.delta_coding) {
             // a one-record group keeps block_delta_constant == 0, which must equal min_delta (tasks.cpp:415)
-            flag = (g1 - g0 == 1) ? (d.min_d == 0) : !((dlt_diff >> f) & 1);
-        } else flag = !((val_diff >> f) & 1);
+            flag = group_size == 1 ? (d.min_d == 0) : !((g.dlt >> f) & 1);
+        } else flag = !((g.val >> f) & 1);
         gconst |= flag << f;
-        w.put(flag, 1);
     }
-    // ---- pass B: records ----
-    for (uint32_t r = g0; r < g1; ++r) {
-        uint32_t pp = r > g0 ? A.ls[r - 1] : A.ls[r], pc = A.ls[r];
-        for (uint32_t f = 0; f < nf; ++f) {
-            uint32_t ep = field_end(buf, pp), ec = field_end(buf, pc);
-            const FieldDesc &d = fd[f];
-            if (d.kind == KIND_NUM) {
-                uint32_t vp = 0, vc = 0;
-                bool o;
-                parse_num(buf, pc, ec, vc, o);
-                if (r == g0) {
-                    w.put(vc - (uint32_t)d.min_v, d.bits_val);               // tasks.cpp:457
-                } else if (!((gconst >> f) & 1)) {
-                    parse_num(buf, pp, ep, vp, o);
-                    uint32_t to_store = d.delta_coding ? (vc - vp - (uint32_t)d.min_d) : (vc - (uint32_t)d.min_v);
-                    if (d.has_huff) {
-                        uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
-                        w.put(e >> 5, e & 31);
-                    } else {
-                        w.put(to_store, d.bits_num);
-                    }
+    return gconst;
+}
+
+// The group's flag bits: one per non-constant field, in field order (tasks.cpp:401-425).
+template <class Sink>
+NGSC_HD void title_put_flags(const FieldDesc *fd, uint32_t nf, uint32_t gconst, Sink &w)
+{
+    for (uint32_t f = 0; f < nf; ++f)
+        if (fd[f].kind != KIND_CONST) w.put((gconst >> f) & 1, 1);
+}
+
+// One record's title bits (tasks.cpp:427-507).  first: it is the group's first record.
+template <class Sink>
+NGSC_HD void title_record_emit(const uint8_t *buf, const Arena &A, uint32_t s, const FieldDesc *fd, uint32_t nf,
+                               bool first, uint32_t p_prev, uint32_t p_cur, uint32_t gconst, Sink &w)
+{
+    uint32_t pp = p_prev, pc = p_cur;
+    for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t ep = field_end(buf, pp), ec = field_end(buf, pc);
+        const FieldDesc &d = fd[f];
+        if (d.kind == KIND_NUM) {
+            uint32_t vp = 0, vc = 0;
+            bool o;
+            parse_num(buf, pc, ec, vc, o);
+            if (first) {
+                w.put(vc - (uint32_t)d.min_v, d.bits_val);               // tasks.cpp:457
+            } else if (!((gconst >> f) & 1)) {
+                parse_num(buf, pp, ep, vp, o);
+                uint32_t to_store = d.delta_coding ? (vc - vp - (uint32_t)d.min_d) : (vc - (uint32_t)d.min_v);
+                if (d.has_huff) {
+                    uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                    w.put(e >> 5, e & 31);
+                } else {
+                    w.put(to_store, d.bits_num);
                 }
-            } else if (d.kind == KIND_TEXT) {
-                if (r == g0 || !((gconst >> f) & 1)) {                     // tasks.cpp:487
-                    uint32_t len = ec - pc;
-                    if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
-                    const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
-                    for (uint32_t j = 0; j < len; ++j) {
-                        if (!ham_bit(d, j)) {
-                            uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + buf[pc + j]];
-                            w.put(e >> 5, e & 31);
-                        }
+            }
+        } else if (d.kind == KIND_TEXT) {
+            if (first || !((gconst >> f) & 1)) {                          // tasks.cpp:487
+                uint32_t len = ec - pc;
+                if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
+                const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
+                for (uint32_t j = 0; j < len; ++j) {
+                    if (!ham_bit(d, j)) {
+                        uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + buf[pc + j]];
+                        w.put(e >> 5, e & 31);
                     }
                 }
             }
-            pp = ep + 1; pc = ec + 1;
         }
+        pp = ep + 1; pc = ec + 1;
     }
+}
+
+// One whole group, sequentially (used by the per-group fallback kernels and by the CPU harness).
+// g0/g1 are record indices inside the job's record table.
+template <class Sink>
+NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, Sink &w)
+{
+    const uint8_t *buf = A.buf;
+    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
+    const uint32_t nf = A.sb[s].nf;
+    TitleDiffs acc = {0, 0, 0};
+    for (uint32_t r = g0 + 1; r < g1; ++r) {
+        TitleDiffs d = title_record_diffs(buf, fd, nf, A.ls[g0], A.ls[r - 1], A.ls[r]);
+        acc.txt |= d.txt; acc.val |= d.val; acc.dlt |= d.dlt;
+    }
+    const uint32_t gconst = title_group_const(fd, nf, acc, g1 - g0);
+    title_put_flags(fd, nf, gconst, w);
+    for (uint32_t r = g0; r < g1; ++r)
+        title_record_emit(buf, A, s, fd, nf, r == g0, r > g0 ? A.ls[r - 1] : A.ls[r], A.ls[r], gconst, w);
     w.align();  // tasks.cpp:508
 }
 
