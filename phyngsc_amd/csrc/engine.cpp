@@ -386,7 +386,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     std::vector<uint32_t> tile_lo(S);
     for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
     size_t p_tilelo = cp.take(4 * (size_t)S);
-    size_t p_wq = cp.take(4 * ((size_t)n_tiles * 4 + 8)), p_wd = cp.take(4 * ((size_t)n_tiles * 4 + 8));
+    size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
+    size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
     Carver ct;
@@ -410,6 +411,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.gflags = (uint32_t *)(rb + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);
+    A.ubits = (uint32_t *)(pb + p_ubits);
     A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;
     A.sb = (SbState *)(pb + p_sb);

@@ -1,20 +1,21 @@
-// kernels_tile.hip - LDS-tiled versions of the per-record kernels (the fast path).
+// kernels_tile.hip - LDS-tiled per-record kernels (the fast path).
 //
-// A tile is a run of R consecutive records of one sub-block (R = 64..256, a multiple of 32 so that the
+// A tile is a run of R consecutive records of one sub-block (R = 256, 128 or 64: a multiple of 32, so the
 // 32-record title groups never straddle tiles) whose bytes [ls[i0], ls[i1]) are staged into LDS with
-// coalesced 16-byte loads.  Every record-oriented stage then reads bytes from LDS instead of walking
-// HBM/L2 with per-lane byte loads:
+// coalesced 16-byte loads.  Every stage then works out of LDS with one thread per record (titles) or one
+// thread per record slice (sequence / quality; T = 256 / R threads share a record), so HBM sees each raw
+// byte once per kernel and all random access, histogramming, code lookup and bit merging stays on chip:
 //
-//   k_title_stats_tile     AnalyzeTitleFields reductions, thread per record            (tasks.cpp:22-193)
-//   k_seq_qual_stats_tile  N-transfer + DNA counts + per-position quality histogram,    (phyNGSC.cpp:462-653,
-//                          lane per symbol over the tile's concatenated bases            tasks.cpp:260-286)
-//   k_measure_tile         title group flags + per-record title bits; quality / DNA bit totals per wave chunk
-//   k_scan_tile            per-sub-block exclusive scans of group bytes and wave-chunk bit totals
-//   k_pack_tile            StoreTitle body, StoreQuality and StoreDNA payloads into LDS staging, then one
-//                          coalesced copy-out per stream                               (tasks.cpp:427-507,
-//                                                                                       544-557, 609-619)
-// HBM traffic per launch = the raw bytes once (+ the stream bytes written by k_pack_tile); all shuffles,
-// histograms, code lookups and bit merging happen in LDS / registers.  Integer work, no MFMA.
+//   k_title_stats_tile     AnalyzeTitleFields reductions                                (tasks.cpp:22-193)
+//   k_seq_qual_stats_tile  N-transfer test, DNA counts, per-position quality histogram   (phyNGSC.cpp:462-653,
+//                                                                                         tasks.cpp:260-286)
+//   k_measure_tile         title group flags + title bits per record; quality / DNA bits per slice and tile
+//   k_scan_tile            per-sub-block exclusive scans of group bytes and tile bit totals
+//   k_pack_tile            StoreTitle body, StoreQuality and StoreDNA payloads: every lane accumulates its own
+//                          bits and ORs whole words into LDS staging; one coalesced copy-out per stream
+//                                                                                        (tasks.cpp:427-507,
+//                                                                                         544-557, 609-619)
+// Integer / byte work bounded by HBM (tile load) and LDS issue rate; no MFMA.
 #include "ngsc_kernels.h"
 
 namespace ngsc {
@@ -50,9 +51,29 @@ __device__ __forceinline__ uint32_t wscan_incl(uint32_t v)
     return v;
 }
 
-// Stages bytes [ls[i0] & ~15, ls[i1]) of the job buffer into s_tile; returns the rebased pointer p with
-// p[pos] == buf[pos] for every pos inside the tile.  Ends with a barrier.
-__device__ __forceinline__ const uint8_t *load_tile(const Arena &A, uint32_t i0, uint32_t i1, uint8_t *s_tile)
+// Workgroup (256 threads) exclusive scan; returns this thread's exclusive prefix, *total = sum.  s_part[TL_WAVES].
+__device__ __forceinline__ uint32_t wg_scan_excl256(uint32_t v, uint32_t *s_part, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wscan_incl(v);
+    __syncthreads();  // s_part may still be read from a previous call
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TL_WAVES; ++w) {
+        uint32_t p = s_part[w];
+        if (w < wave) base += p;
+        tot += p;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// Stages bytes [b0, ls[i1]) of the job buffer into s_tile, b0 = ls[i0] & ~15; returns b0, so that
+// s_tile[pos - b0] == buf[pos] for every pos inside the tile.  (No rebased pointer: a negative offset on an
+// LDS pointer that later gets widened to a flat address does not wrap back.)  Ends with a barrier.
+__device__ __forceinline__ uint32_t load_tile(const Arena &A, uint32_t i0, uint32_t i1, uint8_t *s_tile)
 {
     const uint32_t b0 = A.ls[i0] & ~15u, b1 = A.ls[i1];
     const uint32_t n16 = (b1 - b0 + 15) >> 4;
@@ -68,7 +89,7 @@ __device__ __forceinline__ const uint8_t *load_tile(const Arena &A, uint32_t i0,
         }
     }
     __syncthreads();
-    return s_tile - b0;
+    return b0;
 }
 
 __device__ __forceinline__ void lds_max_t(uint32_t *p, uint32_t v) { if (v > *p) atomicMax(p, v); }
@@ -78,8 +99,11 @@ __device__ __forceinline__ void lds_or_t(uint32_t *p, uint32_t v) { if ((*p & v)
 // Title statistics (the reductions of k_title_stats, bytes from LDS).  blockDim.x = R threads; a tile is
 // R-1 owned records plus the previous record as delta halo (thread 0).  All lanes walk the fields in
 // lockstep, so the previous record's value comes from the neighbouring lane (__shfl_up); the first lane of
-// each wave gets it from a small LDS edge buffer.
+// each wave gets it from a small LDS edge buffer.  Record 0's title (the comparison base of every record)
+// is copied to LDS once.
 // ====================================================================================================
+constexpr uint32_t REC0_TITLE_CAP = 1024;
+
 __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
 {
     if (*A.err) return;
@@ -96,17 +120,24 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     __shared__ uint32_t s_own_v[MAX_FIELDS][TL_WAVES];    // value of each wave's first lane
     __shared__ uint32_t s_edge_m[TL_WAVES], s_own_m[TL_WAVES];
     __shared__ uint32_t s_nf0;
+    __shared__ uint8_t s_t0[REC0_TITLE_CAP];
 
     const int64_t ifirst = (int64_t)blockIdx.x * owned_per_tile - 1;
     const uint32_t r0 = ifirst < 0 ? 0u : (uint32_t)ifirst;
     const uint64_t rend = ((uint64_t)blockIdx.x + 1) * owned_per_tile;
     const uint32_t r1 = rend < n ? (uint32_t)rend : n;  // exclusive
-    const uint8_t *tb = load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
-    const uint8_t *gbuf = A.buf;
-
+    const uint32_t ls0 = A.ls[rec_lo], te0 = A.te[rec_lo];
+    const bool t0_lds = te0 - ls0 + 1 <= REC0_TITLE_CAP;
+    if (t0_lds)
+        for (uint32_t k = tid; k <= te0 - ls0; k += blockDim.x) s_t0[k] = A.buf[ls0 + k];
     for (int k = tid; k < (int)(MAX_FIELDS * 24); k += blockDim.x) s_stat[k] = 0;
+    const uint32_t b0 = load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
+    const uint8_t *tb = s_dyn;   // tile bytes, indexed by (position - b0)
+    const uint8_t *b0p = s_t0;   // record 0's title, indexed from 0
+    if (!t0_lds) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
+
     if (tid == 0) {
-        uint32_t nf0 = count_fields(gbuf, A.ls[rec_lo], A.te[rec_lo]);
+        uint32_t nf0 = count_fields(b0p, 0, te0 - ls0);
         s_nf0 = nf0;
         if (blockIdx.x == 0) A.sb[s].nf = nf0;
         if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
@@ -119,14 +150,14 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     const bool valid = i >= 0 && i < (int64_t)n;
     const bool owned = valid && tid >= 1;
     const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
-    uint32_t pc = valid ? A.ls[g] : 0, p0 = A.ls[rec_lo];
-    const uint32_t tec = valid ? A.te[g] : 0;
+    uint32_t pc = valid ? A.ls[g] - b0 : 0, p0 = 0;   // tile-relative / title-relative cursors
+    const uint32_t tec = valid ? A.te[g] - b0 : 0;
     uint32_t nummask = 0;
     bool short_title = false;
     for (uint32_t f = 0; f < nf0; ++f) {
         uint32_t v = 0;
         bool isnum = false;
-        const uint32_t e0 = field_end(gbuf, p0);  // record 0 of the sub-block: same addresses in every lane
+        const uint32_t e0 = field_end(b0p, p0);
         if (valid && pc <= tec) {
             const uint32_t ec = field_end(tb, pc);
             const uint32_t len = ec - pc, len0 = e0 - p0;
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
                 uint32_t m = len < len0 ? len : len0;
                 bool diff = false;
                 for (uint32_t p = 0; p < m; ++p) {
-                    if (tb[pc + p] != gbuf[p0 + p]) {
+                    if (tb[pc + p] != b0p[p0 + p]) {
                         diff = true;
                         if (p < 256) lds_or_t(st + 10 + (p >> 5), 1u << (p & 31));
                     }
@@ -196,68 +227,52 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
 }
 
 // ====================================================================================================
-// Per-tile record bookkeeping shared by the symbol-parallel kernels
+// Slices: thread tid of a 256-thread workgroup works on record r = tid / T of the tile, positions
+// [j0, j1) = [t*L/T, (t+1)*L/T) with t = tid % T and T = 256 / R threads per record.
 // ====================================================================================================
-struct TileRecs {
-    uint32_t te[TL_THREADS];      // title end   (offset in the job buffer)
-    uint32_t se[TL_THREADS];      // sequence end
-    uint32_t cum[TL_THREADS + 1]; // exclusive prefix of read lengths inside the tile
-    uint32_t flag[TL_THREADS];    // per record scratch (transfer flags)
-    uint32_t wpart[TL_WAVES + 1];
+struct Slice {
+    bool valid;
+    uint32_t r;       // tile-relative record
+    uint32_t t;       // slice index inside the record
+    uint32_t s0, q0;  // first base / first quality byte (tile-relative offsets)
+    uint32_t L;       // read length
+    uint32_t j0, j1;
 };
 
-// Fills te/se/cum for records [i0, i0+nt); all threads must call.  Ends with a barrier.
-__device__ __forceinline__ void tile_records(const Arena &A, uint32_t i0, uint32_t nt, TileRecs &T)
+__device__ __forceinline__ Slice make_slice(const Arena &A, uint32_t i0, uint32_t nt, uint32_t T, uint32_t b0)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t L = 0;
-    if ((uint32_t)tid < nt) {
-        uint32_t t = A.te[i0 + tid], e = A.se[i0 + tid];
-        T.te[tid] = t;
-        T.se[tid] = e;
-        L = e - t - 1;
+    Slice S;
+    S.r = threadIdx.x / T;
+    S.t = threadIdx.x % T;
+    S.valid = S.r < nt;
+    S.s0 = S.q0 = S.L = S.j0 = S.j1 = 0;
+    if (S.valid) {
+        uint32_t te = A.te[i0 + S.r], se = A.se[i0 + S.r];
+        S.L = se - te - 1;
+        S.s0 = te + 1 - b0;   // tile-relative
+        S.q0 = se + 3 - b0;
+        S.j0 = (uint32_t)(((uint64_t)S.t * S.L) / T);
+        S.j1 = (uint32_t)(((uint64_t)(S.t + 1) * S.L) / T);
     }
-    T.flag[tid] = 0;
-    uint32_t incl = wscan_incl(L);
-    if (lane == 63) T.wpart[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += T.wpart[w];
-    T.cum[tid] = base + incl - L;
-    if (tid == TL_THREADS - 1) T.cum[TL_THREADS] = base + incl;
-    __syncthreads();
+    return S;
 }
 
-// Symbol cursor: maps the wave's current 64 symbols to (record, position).  `rs` is a wave-uniform hint.
-__device__ __forceinline__ bool locate(const TileRecs &T, uint32_t nt, uint32_t e, uint32_t total, uint32_t &rs,
-                                       uint32_t &r, uint32_t &j)
+// OR / add over the T adjacent lanes that share a record (T in {1, 2, 4})
+__device__ __forceinline__ uint32_t rec_or(uint32_t v, uint32_t T)
 {
-    bool act = e < total;
-    r = rs;
-    if (act) {
-        while (r + 1 < nt && e >= T.cum[r + 1]) ++r;
-        j = e - T.cum[r];
-    } else {
-        j = 0;
-    }
-    // next step starts at or after the record of the last active lane
-    uint32_t rl = act ? r : 0;
-    rs = wmax(rl);
-    return act;
+    if (T >= 2) v |= __shfl_xor(v, 1);
+    if (T >= 4) v |= __shfl_xor(v, 2);
+    return v;
 }
-
-__device__ __forceinline__ uint32_t first_record_of(const TileRecs &T, uint32_t nt, uint32_t e)
+__device__ __forceinline__ uint32_t rec_sum(uint32_t v, uint32_t T)
 {
-    uint32_t lo = 0, hi = nt;  // largest r with cum[r] <= e
-    while (lo + 1 < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (T.cum[mid] <= e) lo = mid; else hi = mid;
-    }
-    return lo;
+    if (T >= 2) v += __shfl_xor(v, 1);
+    if (T >= 4) v += __shfl_xor(v, 2);
+    return v;
 }
 
 // ====================================================================================================
-// DNA / quality statistics, lane per symbol
+// DNA / quality statistics
 // ====================================================================================================
 constexpr uint32_t HCOLS = 64, HSTRIDE = 65;
 
@@ -266,7 +281,6 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // [tile_bytes] tile, then [lds_rows][HSTRIDE] histogram
-    __shared__ TileRecs T;
     __shared__ uint32_t s_occ[256];
     __shared__ uint32_t s_red[3];
     const uint32_t s = blockIdx.y;
@@ -276,89 +290,69 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
     const uint32_t i0 = rec_lo + t0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t T = TL_THREADS / R;
+    const int tid = threadIdx.x, lane = tid & 63;
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
 
     for (uint32_t k = tid; k < lds_rows * HSTRIDE; k += TL_THREADS) s_hist[k] = 0;
     s_occ[tid] = 0;
     if (tid < 3) s_red[tid] = 0;
-    const uint8_t *tb = load_tile(A, i0, i0 + nt, s_dyn);
-    tile_records(A, i0, nt, T);
-    const uint32_t total = T.cum[TL_THREADS];
-    const uint32_t chunk = ((total + TL_WAVES * 64 - 1) / (TL_WAVES * 64)) * 64;  // symbols per wave, multiple of 64
-    const uint32_t c0 = wave * chunk, c1 = c0 + chunk < total ? c0 + chunk : total;
+    const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
+    const uint8_t *tb = s_dyn;
+    const Slice S = make_slice(A, i0, nt, T, b0);
 
     if (t0 == 0 && tid == 0) {  // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
-        uint32_t L = T.se[0] - T.te[0] - 1;
-        uint8_t c1b = tb[T.te[0] + 2];
-        if (L >= 2 && c1b >= '0' && c1b <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+        uint8_t c1 = tb[S.s0 + 1];
+        if (S.L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
     }
-    // pass 1: N-transfer test (phyNGSC.cpp:549-571): flag = any | bad << 1 | (#ambiguous) << 8
-    if (c0 < total) {
-        uint32_t rs = first_record_of(T, nt, c0);
-        for (uint32_t e0 = c0; e0 < c1; e0 += 64) {
-            uint32_t r, j;
-            bool act = locate(T, nt, e0 + lane, c1, rs, r, j);
-            if (act) {
-                uint8_t c = tb[T.te[r] + 1 + j];
-                if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) {
-                    uint32_t a = amb_code(c);
-                    if (a == 0) atomicOr(&T.flag[r], 2u);
-                    else {
-                        uint8_t q = tb[T.se[r] + 3 + j];
-                        atomicAdd(&T.flag[r], 256u);
-                        atomicOr(&T.flag[r], (q < 33 || q > 40) ? 2u : 1u);
-                    }
-                }
+    // pass 1: N-transfer test (phyNGSC.cpp:549-571).  The serial loop stops at the first failure, so the
+    // outcome is "some ambiguous base" && "no failure anywhere": order independent.
+    uint32_t fl = 0, namb = 0;  // bit0 any, bit1 bad
+    for (uint32_t j = S.j0; j < S.j1; ++j) {
+        uint8_t c = tb[S.s0 + j];
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) {
+            uint32_t a = amb_code(c);
+            if (a == 0) fl |= 2;
+            else {
+                uint8_t q = tb[S.q0 + j];
+                fl |= (q < 33 || q > 40) ? 2u : 1u;
+                ++namb;
             }
         }
     }
-    __syncthreads();
+    fl = rec_or(fl, T);
+    namb = rec_sum(namb, T);
+    const bool xfer = (fl & 1) && !(fl & 2);
+    const uint32_t kept = S.L - (xfer ? namb : 0);
+    const bool rec_lead = S.valid && S.t == 0;
+    if (rec_lead) A.slen[i0 + S.r] = kept | ((uint32_t)xfer << 31);
     {
-        uint32_t L = 0, kept = 0;
-        if ((uint32_t)tid < nt) {
-            uint32_t f = T.flag[tid];
-            bool xfer = (f & 1) && !(f & 2);
-            L = T.se[tid] - T.te[tid] - 1;
-            kept = L - (xfer ? (f >> 8) : 0);
-            A.slen[i0 + tid] = kept | ((uint32_t)xfer << 31);
-            T.flag[tid] = xfer;
-        } else {
-            T.flag[tid] = 0;
-        }
-        uint32_t mq = wmax(L), ms = wmax(kept), sb_ = wsum(L);
-        if (lane == 0) { atomicMax(&s_red[0], mq); atomicMax(&s_red[1], ms); atomicAdd(&s_red[2], sb_); }
+        uint32_t mq = wmax(rec_lead ? S.L : 0), ms = wmax(rec_lead ? kept : 0), sbs = wsum(rec_lead ? S.L : 0);
+        if (lane == 0) { atomicMax(&s_red[0], mq); atomicMax(&s_red[1], ms); atomicAdd(&s_red[2], sbs); }
     }
-    __syncthreads();
-    // pass 2: histograms
+    // pass 2: histograms.  Lanes start at different positions of their slice (rotation) so that
+    // neighbouring lanes update different histogram rows at the same time.
     uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
-    if (c0 < total) {
-        uint32_t rs = first_record_of(T, nt, c0);
-        for (uint32_t e0 = c0; e0 < c1; e0 += 64) {
-            uint32_t r, j;
-            bool act = locate(T, nt, e0 + lane, c1, rs, r, j);
-            uint8_t c = 0;
-            bool keep = false;
-            uint32_t a = 1;
-            if (act) {
-                c = tb[T.te[r] + 1 + j];
-                uint8_t q = tb[T.se[r] + 3 + j];
-                a = amb_fast_t(c);
-                bool drop = T.flag[r] && a > 1;
-                keep = !drop;
-                uint32_t qv = drop ? transfer_quality(a, q) : q;
-                uint32_t row = j + 1, col = qv - 33;
-                if (col < HCOLS && row < lds_rows) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
-                else atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
+    {
+        const uint32_t len = S.j1 - S.j0;
+        uint32_t j = len ? S.j0 + (uint32_t)lane % len : 0;
+        for (uint32_t it = 0; it < len; ++it) {
+            uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
+            uint32_t a = amb_fast_t(c);
+            bool drop = xfer && a > 1;
+            uint32_t qv = drop ? transfer_quality(a, q) : q;  // phyNGSC.cpp:579
+            uint32_t row = j + 1, col = qv - 33;
+            if (col < HCOLS && row < lds_rows) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
+            else atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
+            if (!drop) {
+                cA += c == 'A'; cC += c == 'C'; cG += c == 'G'; cT += c == 'T';
+                if (a != 1) atomicAdd(&s_occ[c], 1u);
             }
-            cA += __popcll(__ballot(keep && c == 'A'));
-            cC += __popcll(__ballot(keep && c == 'C'));
-            cG += __popcll(__ballot(keep && c == 'G'));
-            cT += __popcll(__ballot(keep && c == 'T'));
-            if (keep && a != 1) atomicAdd(&s_occ[c], 1u);
+            if (++j == S.j1) j = S.j0;
         }
     }
+    cA = wsum(cA); cC = wsum(cC); cG = wsum(cG); cT = wsum(cT);
     if (lane == 0) {
         atomicAdd(&s_occ['A'], cA); atomicAdd(&s_occ['C'], cC); atomicAdd(&s_occ['G'], cG); atomicAdd(&s_occ['T'], cT);
     }
@@ -377,7 +371,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
 }
 
 // ====================================================================================================
-// Measure: title flags/bits per record, quality/DNA bit totals per wave chunk
+// Measure
 // ====================================================================================================
 struct SqLut {
     const uint32_t *qtab;  // LDS or global; row stride qstride
@@ -424,10 +418,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // tile, then quality code table
-    __shared__ TileRecs T;
     __shared__ uint32_t s_dcode[256];
     __shared__ uint8_t s_qcode[256];
     __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
@@ -435,17 +429,16 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
     const uint32_t i0 = rec_lo + t0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t T = TL_THREADS / R;
+    const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
 
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TL_THREADS)
         reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, Lt);
-    const uint8_t *tb = load_tile(A, i0, i0 + nt, s_dyn);
-    tile_records(A, i0, nt, T);
-    if ((uint32_t)tid < nt) T.flag[tid] = A.slen[i0 + tid] >> 31;  // N-transfer flag of the record
-    __syncthreads();
+    const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
+    const uint8_t *tb = s_dyn;
 
     // ---- title: thread per record (tasks.cpp:393-509) ----
     {
@@ -456,9 +449,9 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
         TitleDiffs d = {0, 0, 0};
         uint32_t p_cur = 0, p_prev = 0;
         if (valid) {
-            p_cur = A.ls[i0 + tid];
-            p_prev = gi ? A.ls[i0 + tid - 1] : p_cur;
-            if (gi) d = title_record_diffs(tb, s_fd, nf, A.ls[i0 + gstart], p_prev, p_cur);
+            p_cur = A.ls[i0 + tid] - b0;
+            p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
+            if (gi) d = title_record_diffs(tb, s_fd, nf, A.ls[i0 + gstart] - b0, p_prev, p_cur);
         }
         TitleDiffs gd = {g32_or(d.txt), g32_or(d.val), g32_or(d.dlt)};
         const uint32_t gconst = title_group_const(s_fd, nf, gd, gsize);
@@ -477,34 +470,26 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
             A.gflags[grp] = gconst;
         }
     }
-    // ---- quality / DNA: bit totals of this wave's chunk of symbols ----
-    const uint32_t total = T.cum[TL_THREADS];
-    const uint32_t chunk = ((total + TL_WAVES * 64 - 1) / (TL_WAVES * 64)) * 64;
-    const uint32_t c0 = wave * chunk, c1 = c0 + chunk < total ? c0 + chunk : total;
+    // ---- quality / DNA: bits of this thread's slice ----
+    const Slice S = make_slice(A, i0, nt, T, b0);
     uint32_t qb = 0, db = 0;
-    if (c0 < total) {
-        uint32_t rs = first_record_of(T, nt, c0);
-        for (uint32_t e0 = c0; e0 < c1; e0 += 64) {
-            uint32_t r, j;
-            bool act = locate(T, nt, e0 + lane, c1, rs, r, j);
-            if (act) {
-                uint8_t c = tb[T.te[r] + 1 + j], q = tb[T.se[r] + 3 + j];
-                bool xfer = T.flag[r];
-                uint32_t a = xfer ? amb_fast_t(c) : 1u;
-                bool drop = xfer && a > 1;
-                uint32_t qv = drop ? transfer_quality(a, q) : q;
-                qb += Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]] & 31;
-                if (!drop) db += Lt.dcode[c] & 31;
-            }
+    if (S.valid) {
+        const bool xfer = A.slen[i0 + S.r] >> 31;
+        for (uint32_t j = S.j0; j < S.j1; ++j) {
+            uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
+            uint32_t a = xfer ? amb_fast_t(c) : 1u;
+            bool drop = xfer && a > 1;
+            uint32_t qv = drop ? transfer_quality(a, q) : q;
+            qb += Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]] & 31;
+            if (!drop) db += Lt.dcode[c] & 31;
         }
     }
-    qb = wsum(qb);
-    db = wsum(db);
-    if (lane == 0) {
-        size_t w = ((size_t)A.tile_lo[s] + blockIdx.x) * TL_WAVES + wave;
-        A.wq[w] = qb;
-        A.wd[w] = db;
-    }
+    const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
+    A.ubits[tix * TL_THREADS + tid] = qb | (db << 16);
+    uint32_t tq, td;
+    (void)wg_scan_excl256(qb, s_part, &tq);
+    (void)wg_scan_excl256(db, s_part, &td);
+    if (tid == 0) { A.wq[tix] = tq; A.wd[tix] = td; }
 }
 
 // ====================================================================================================
@@ -541,8 +526,8 @@ __global__ __launch_bounds__(1024) void k_scan_tile(Arena A, uint32_t R)
     const uint32_t s = blockIdx.x;
     SbState &sb = A.sb[s];
     const uint32_t ntiles = (sb.n_rec + R - 1) / R;
-    uint32_t tq = wg_scan_excl_t(A.wq + (size_t)A.tile_lo[s] * TL_WAVES, ntiles * TL_WAVES, s_wave);
-    uint32_t td = wg_scan_excl_t(A.wd + (size_t)A.tile_lo[s] * TL_WAVES, ntiles * TL_WAVES, s_wave);
+    uint32_t tq = wg_scan_excl_t(A.wq + A.tile_lo[s], ntiles, s_wave);
+    uint32_t td = wg_scan_excl_t(A.wd + A.tile_lo[s], ntiles, s_wave);
     uint32_t tg = wg_scan_excl_t(A.goff + A.grp_lo[s], (sb.n_rec + GROUP - 1) / GROUP, s_wave);
     if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
 }
@@ -550,53 +535,44 @@ __global__ __launch_bounds__(1024) void k_scan_tile(Arena A, uint32_t R)
 // ====================================================================================================
 // Pack
 // ====================================================================================================
-// OR-writer for one lane's bits into a word array (LDS staging or the global output), MSB-first.
-struct OrWriter {
-    uint32_t *words;   // word 0 = absolute output word `word0`
-    uint64_t bitpos;   // absolute bit position in the output buffer
-    uint64_t word0;
+// One lane's MSB-first bit writer into a word array (LDS staging, or the zeroed output in the overflow
+// path).  Bits are collected in a 64-bit accumulator and leave as whole 32-bit big-endian words, each
+// merged with atomicOr: a lane's first and last word are shared with its neighbours.
+struct LaneWriter {
+    uint32_t *words;
+    uint64_t widx;   // index of the word currently being filled (relative to words[0])
+    uint64_t acc;
+    uint32_t nacc;   // bits pending in acc, including the leading (bitpos & 31) zero bits
+    __device__ __forceinline__ void init(uint32_t *w, uint64_t word0, uint64_t bitpos)
+    {
+        words = w;
+        widx = (bitpos >> 5) - word0;
+        acc = 0;
+        nacc = (uint32_t)(bitpos & 31);
+    }
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb)
     {
         if (!nb) return;
         if (nb < 32) v &= (1u << nb) - 1u;
-        const uint32_t sh = (uint32_t)(bitpos & 31);
-        const uint64_t x = (uint64_t)v << (64 - nb - sh);  // nb <= 32, sh <= 31
-        const uint64_t w = (bitpos >> 5) - word0;
-        atomicOr(&words[w], __builtin_bswap32((uint32_t)(x >> 32)));
-        if ((uint32_t)x) atomicOr(&words[w + 1], __builtin_bswap32((uint32_t)x));
-        bitpos += nb;
+        acc = (acc << nb) | v;
+        nacc += nb;
+        if (nacc >= 32) {
+            uint32_t word = (uint32_t)(acc >> (nacc - 32));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            ++widx;
+            nacc -= 32;
+            acc &= (1ull << nacc) - 1ull;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc) {
+            uint32_t word = (uint32_t)(acc << (32 - nacc));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            nacc = 0;
+        }
     }
 };
-
-// Wave-cooperative emit of up to 64 codes into a word array (see k_pack_sq for the derivation).  All tails
-// use atomicOr: the target is zero-initialised LDS staging (or, in the overflow path, the zeroed output).
-__device__ __forceinline__ uint32_t wave_emit_or(uint32_t *words, uint64_t word0, uint64_t bitpos, uint32_t code, uint32_t len)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t incl = wscan_incl(len);
-    const uint32_t total = __shfl(incl, 63);
-    if (!total) return 0;
-    const uint64_t o = bitpos + (incl - len);
-    const uint32_t key = (uint32_t)((o >> 5) - word0), sh = (uint32_t)(o & 31);
-    uint32_t hi = 0, lo = 0;
-    if (len) {
-        uint64_t x = (uint64_t)code << (64 - len - sh);
-        hi = (uint32_t)(x >> 32);
-        lo = (uint32_t)x;
-    }
-    const uint32_t key_prev = __shfl_up(key, 1), lo_prev = __shfl_up(lo, 1);
-    if (lane > 0 && key_prev != key) hi |= lo_prev;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t ko = __shfl_up(key, d), vo = __shfl_up(hi, d);
-        if (lane >= d && ko == key) hi |= vo;
-    }
-    const uint32_t key_next = __shfl_down(key, 1);
-    const bool tail = lane == 63 || key_next != key;
-    if (tail && hi) atomicOr(&words[key], __builtin_bswap32(hi));
-    if (lane == 63 && lo) atomicOr(&words[key + 1], __builtin_bswap32(lo));
-    return total;
-}
 
 // Copies staged words [0, nwords) to the output starting at absolute word `word0`.  Words strictly inside
 // the stream's bit range [b0, b1) are complete and stored plainly; the boundary words are shared -> atomicOr.
@@ -617,10 +593,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     if (*A.err) return;
     // dynamic LDS: tile | quality code table | staging areas (title sw_t, quality sw_q, DNA sw_d words)
     extern __shared__ __align__(16) uint8_t s_dyn[];
-    __shared__ TileRecs T;
     __shared__ uint32_t s_dcode[256];
     __shared__ uint8_t s_qcode[256];
     __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
@@ -628,8 +604,9 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
     const uint32_t i0 = rec_lo + t0;
+    const uint32_t T = TL_THREADS / R;
     const bool last_tile = t0 + R >= n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
     uint32_t *s_stage = s_qtab + lds_entries;
     uint32_t *st_t = s_stage, *st_q = s_stage + sw_t, *st_d = s_stage + sw_t + sw_q;
@@ -639,10 +616,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
         reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, Lt);
-    const uint8_t *tb = load_tile(A, i0, i0 + nt, s_dyn);
-    tile_records(A, i0, nt, T);
-    if ((uint32_t)tid < nt) T.flag[tid] = A.slen[i0 + tid] >> 31;
-    __syncthreads();
+    const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
+    const uint8_t *tb = s_dyn;
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
 
     // absolute bit ranges of this tile's share of the three payload streams
@@ -651,11 +626,11 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     const uint64_t title_base = (sb.out_off + sb.info_len + sb.title_hdr) * 8;
     const uint64_t tb0 = title_base + 8ull * A.goff[grp_first];
     const uint64_t tb1 = title_base + 8ull * (last_tile ? sb.title_body : A.goff[grp_first + ngrp_t]);
-    const size_t wix = ((size_t)A.tile_lo[s] + blockIdx.x) * TL_WAVES;
+    const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
-    const uint64_t qb0 = qbase + A.wq[wix], qb1 = qbase + (last_tile ? sb.qbits : A.wq[wix + TL_WAVES]);
-    const uint64_t db0 = dbase + A.wd[wix], db1 = dbase + (last_tile ? sb.dbits : A.wd[wix + TL_WAVES]);
+    const uint64_t qb0 = qbase + A.wq[tix], qb1 = qbase + (last_tile ? sb.qbits : A.wq[tix + 1]);
+    const uint64_t db0 = dbase + A.wd[tix], db1 = dbase + (last_tile ? sb.dbits : A.wd[tix + 1]);
     const uint64_t tw0 = tb0 >> 5, qw0 = qb0 >> 5, dw0 = db0 >> 5;
     const uint32_t tnw = (uint32_t)(((tb1 + 31) >> 5) - tw0), qnw = (uint32_t)(((qb1 + 31) >> 5) - qw0),
                    dnw = (uint32_t)(((db1 + 31) >> 5) - dw0);
@@ -676,40 +651,41 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
         if (valid) {
             const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
             const uint32_t gconst = A.gflags[grp];
-            OrWriter w;
-            w.words = t_lds ? st_t : outw;
-            w.word0 = t_lds ? tw0 : 0;
-            w.bitpos = title_base + 8ull * A.goff[grp] + (incl - bits);
-            const uint32_t p_cur = A.ls[i0 + tid], p_prev = gi ? A.ls[i0 + tid - 1] : p_cur;
+            LaneWriter w;
+            w.init(t_lds ? st_t : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
+            const uint32_t p_cur = A.ls[i0 + tid] - b0, p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
             if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
             title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, w);
+            w.finish();
         }
     }
 
-    // ---- quality / DNA: lane per symbol ----
-    const uint32_t total = T.cum[TL_THREADS];
-    const uint32_t chunk = ((total + TL_WAVES * 64 - 1) / (TL_WAVES * 64)) * 64;
-    const uint32_t c0 = wave * chunk, c1 = c0 + chunk < total ? c0 + chunk : total;
-    if (c0 < total) {
-        uint64_t qpos = qbase + A.wq[wix + wave], dpos = dbase + A.wd[wix + wave];
-        uint32_t *qdst = q_lds ? st_q : outw, *ddst = d_lds ? st_d : outw;
-        const uint64_t qz = q_lds ? qw0 : 0, dz = d_lds ? dw0 : 0;
-        uint32_t rs = first_record_of(T, nt, c0);
-        for (uint32_t e0 = c0; e0 < c1; e0 += 64) {
-            uint32_t r, j;
-            bool act = locate(T, nt, e0 + lane, c1, rs, r, j);
-            uint32_t qe = 0, de = 0;
-            if (act) {
-                uint8_t c = tb[T.te[r] + 1 + j], q = tb[T.se[r] + 3 + j];
-                bool xfer = T.flag[r];
+    // ---- quality / DNA: one lane per record slice, offsets from a workgroup scan of the slice bit counts ----
+    {
+        const Slice S = make_slice(A, i0, nt, T, b0);
+        const uint32_t ub = A.ubits[tix * TL_THREADS + tid];
+        uint32_t tq, td;
+        const uint32_t qo = wg_scan_excl256(ub & 0xffffu, s_part, &tq);
+        const uint32_t dofs = wg_scan_excl256(ub >> 16, s_part, &td);
+        if (S.valid && S.j1 > S.j0) {
+            const bool xfer = A.slen[i0 + S.r] >> 31;
+            LaneWriter wq_, wd_;
+            wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
+            wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
+            for (uint32_t j = S.j0; j < S.j1; ++j) {
+                uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
                 uint32_t a = xfer ? amb_fast_t(c) : 1u;
                 bool drop = xfer && a > 1;
                 uint32_t qv = drop ? transfer_quality(a, q) : q;
-                qe = Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]];
-                if (!drop) de = Lt.dcode[c];
+                uint32_t qe = Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]];   // tasks.cpp:614-618
+                wq_.put(qe >> 5, qe & 31);
+                if (!drop) {
+                    uint32_t de = Lt.dcode[c];                                 // tasks.cpp:549-556
+                    wd_.put(de >> 5, de & 31);
+                }
             }
-            qpos += wave_emit_or(qdst, qz, qpos, qe >> 5, qe & 31);
-            dpos += wave_emit_or(ddst, dz, dpos, de >> 5, de & 31);
+            wq_.finish();
+            wd_.finish();
         }
     }
     __syncthreads();
@@ -731,7 +707,7 @@ static void allow_big_lds(K kernel)
 // Records per tile for a job whose longest record has max_rec_bytes; 0 = use the untiled kernels.
 uint32_t tile_records_for(uint32_t max_rec_bytes, uint32_t r_max)
 {
-    for (uint32_t R : {256u, 192u, 128u, 64u})
+    for (uint32_t R : {256u, 128u, 64u})
         if (R <= r_max && (uint64_t)R * max_rec_bytes + 32 <= TILE_LDS_BUDGET) return R;
     return 0;
 }

@@ -224,7 +224,8 @@ struct Arena {
     uint32_t *grp_lo;       // per sub-block: first title group index
     uint32_t *tbits;        // per record: title bits (tiled path)
     uint32_t *gflags;       // per title group: flag bits (tiled path)
-    uint32_t *wq, *wd;      // per (tile, wave): quality / DNA payload bits of the wave's symbol chunk, then offsets
+    uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
+    uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
     uint32_t *tile_lo;      // per sub-block: first tile index
     int32_t *err;           // job error word (min over error codes)
     // per sub-block arrays (index by sub-block)
