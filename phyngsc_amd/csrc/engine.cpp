@@ -388,6 +388,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_tilelo = cp.take(4 * (size_t)S);
     size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
     size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
+    size_t p_tw = cp.take(R ? 4 * (size_t)NCF_CAP * rec_cap : 0);
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
     Carver ct;
@@ -412,6 +413,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);
     A.ubits = (uint32_t *)(pb + p_ubits);
+    A.tw = (uint32_t *)(pb + p_tw);
+    A.tw_stride = (uint32_t)rec_cap;
     A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;
     A.sb = (SbState *)(pb + p_sb);

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
         const uint32_t g = rec_lo + r;
         const uint32_t t = A.te[g], e = A.se[g];
         const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
+        if (lane == 0 && (buf[e + 1] != '+' || buf[e + 2] != '\n')) atomicMin(A.err, (int32_t)ERR_FORMAT);  // bare '+' line
         if (r == 0 && lane == 0) {
             uint8_t c1 = buf[s0 + 1];  // colour-space detection, phyNGSC.cpp:478
             if (L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
     uint32_t p = A.ls[sb.rec_lo], e = 0;
     for (uint32_t k = 0; k <= f; ++k) { e = field_end(buf, p); if (k < f) p = e + 1; }
     FieldDesc d;
-    for (int k = 0; k < 5; ++k) d.pad[k] = 0;
+    for (int k = 0; k < 4; ++k) d.pad[k] = 0;
     int rc = finalize_field(A.fstat[(size_t)s * MAX_FIELDS + f], p, e - p, buf[e], sb.n_rec, f, sb.nf, d);
     if (rc == OK && d.kind == KIND_TEXT) {
         uint32_t slot = atomicAdd(A.slot_counter, 1u);
@@ -283,6 +284,10 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
         else { d.slot = slot; A.slot_owner[slot] = s * MAX_FIELDS + f; }
     }
     if (rc) atomicMin(A.err, (int32_t)rc);
+    // compact index among the non-constant fields (all lanes with f < nf are still here)
+    unsigned long long ncm = __ballot(d.kind != KIND_CONST);
+    d.kf = (uint32_t)__popcll(ncm & ((1ull << f) - 1ull));
+    if (f == 0) A.sb[s].ncf = (uint32_t)__popcll(ncm);
     A.fdesc[(size_t)s * MAX_FIELDS + f] = d;
 }
 

@@ -9,24 +9,22 @@
 //   k_title_stats_tile     AnalyzeTitleFields reductions                                (tasks.cpp:22-193)
 //   k_seq_qual_stats_tile  N-transfer test, DNA counts, per-position quality histogram   (phyNGSC.cpp:462-653,
 //                                                                                         tasks.cpp:260-286)
-//   k_measure_tile         title group flags + title bits per record; quality / DNA bits per slice and tile
+//   k_measure_tile         parses each title once more, caches its non-constant fields, derives the 32-record
+//                          group flags and the title bits per record; quality / DNA bits per slice and tile
 //   k_scan_tile            per-sub-block exclusive scans of group bytes and tile bit totals
-//   k_pack_tile            StoreTitle body, StoreQuality and StoreDNA payloads: every lane accumulates its own
-//                          bits and ORs whole words into LDS staging; one coalesced copy-out per stream
-//                                                                                        (tasks.cpp:427-507,
-//                                                                                         544-557, 609-619)
-// Integer / byte work bounded by HBM (tile load) and LDS issue rate; no MFMA.
+//   k_pack_tile            StoreTitle body (from the cached fields), StoreQuality and StoreDNA payloads: every
+//                          lane accumulates its own bits and ORs whole words into LDS staging; one coalesced
+//                          copy-out per stream                                (tasks.cpp:427-507, 544-557, 609-619)
+//
+// Loops are written with wave-uniform trip counts and predicated bodies: the first version of these kernels
+// used nested per-lane while-loops and spent 80 % of its time in scalar exec-mask bookkeeping (SQ_INSTS_SALU).
+// Integer / byte work bounded by HBM (tile load) and LDS / VALU issue; no MFMA.
 #include "ngsc_kernels.h"
 
 namespace ngsc {
 
 constexpr int TL_THREADS = 256;
 constexpr int TL_WAVES = TL_THREADS / 64;
-
-__device__ __forceinline__ uint32_t amb_fast_t(uint8_t c)
-{
-    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 1u : amb_code(c);
-}
 
 __device__ __forceinline__ uint32_t wsum(uint32_t v)
 {
@@ -95,12 +93,22 @@ __device__ __forceinline__ uint32_t load_tile(const Arena &A, uint32_t i0, uint3
 __device__ __forceinline__ void lds_max_t(uint32_t *p, uint32_t v) { if (v > *p) atomicMax(p, v); }
 __device__ __forceinline__ void lds_or_t(uint32_t *p, uint32_t v) { if ((*p & v) != v) atomicOr(p, v); }
 
+// branch-free membership test for the title separators " ._,=:/-#\n" (phyNGSC.cpp:208)
+__device__ __forceinline__ bool sep_fast(uint32_t c)
+{
+    const uint32_t m0 = 1u << 10;                                                                    // '\n'
+    const uint32_t m1 = (1u << 0) | (1u << 3) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 15) |  // ' ' # , - . /
+                        (1u << 26) | (1u << 29);                                                     // : =
+    const uint32_t m2 = 1u << 31;                                                                    // '_'
+    const uint32_t w = c >> 5;
+    const uint32_t m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : 0u));
+    return (m >> (c & 31)) & 1u;
+}
+
 // ====================================================================================================
-// Title statistics (the reductions of k_title_stats, bytes from LDS).  blockDim.x = R threads; a tile is
-// R-1 owned records plus the previous record as delta halo (thread 0).  All lanes walk the fields in
-// lockstep, so the previous record's value comes from the neighbouring lane (__shfl_up); the first lane of
-// each wave gets it from a small LDS edge buffer.  Record 0's title (the comparison base of every record)
-// is copied to LDS once.
+// Title statistics.  blockDim.x = R threads; a tile is R-1 owned records plus the previous record as delta
+// halo (thread 0).  One flat pass over the title bytes per lane: separator test, decimal accumulate and
+// comparison with record 0 of the sub-block (whose title and field table sit in LDS) in the same loop body.
 // ====================================================================================================
 constexpr uint32_t REC0_TITLE_CAP = 1024;
 
@@ -113,13 +121,14 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     const uint32_t owned_per_tile = blockDim.x - 1;
     if (blockIdx.x * owned_per_tile >= n) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
 
     __shared__ uint32_t s_stat[MAX_FIELDS * 24];
-    __shared__ uint32_t s_edge_v[MAX_FIELDS][TL_WAVES];   // value of each wave's last lane
-    __shared__ uint32_t s_own_v[MAX_FIELDS][TL_WAVES];    // value of each wave's first lane
-    __shared__ uint32_t s_edge_m[TL_WAVES], s_own_m[TL_WAVES];
-    __shared__ uint32_t s_nf0;
+    __shared__ uint32_t s_val[NUM_CAND_CAP][TL_THREADS];  // values of the numeric candidate fields
+    __shared__ uint32_t s_nummask[TL_THREADS];
+    __shared__ uint16_t s_f0_start[MAX_FIELDS], s_f0_len[MAX_FIELDS];
+    __shared__ uint8_t s_kmap[MAX_FIELDS], s_cand_f[NUM_CAND_CAP];
+    __shared__ uint32_t s_nf0, s_ncand;
     __shared__ uint8_t s_t0[REC0_TITLE_CAP];
 
     const int64_t ifirst = (int64_t)blockIdx.x * owned_per_tile - 1;
@@ -127,18 +136,37 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     const uint64_t rend = ((uint64_t)blockIdx.x + 1) * owned_per_tile;
     const uint32_t r1 = rend < n ? (uint32_t)rend : n;  // exclusive
     const uint32_t ls0 = A.ls[rec_lo], te0 = A.te[rec_lo];
-    const bool t0_lds = te0 - ls0 + 1 <= REC0_TITLE_CAP;
-    if (t0_lds)
-        for (uint32_t k = tid; k <= te0 - ls0; k += blockDim.x) s_t0[k] = A.buf[ls0 + k];
+    const uint32_t t0len = te0 - ls0 + 1;
+    if (t0len > REC0_TITLE_CAP) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
+    for (uint32_t k = tid; k < t0len; k += blockDim.x) s_t0[k] = A.buf[ls0 + k];
     for (int k = tid; k < (int)(MAX_FIELDS * 24); k += blockDim.x) s_stat[k] = 0;
     const uint32_t b0 = load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
     const uint8_t *tb = s_dyn;   // tile bytes, indexed by (position - b0)
-    const uint8_t *b0p = s_t0;   // record 0's title, indexed from 0
-    if (!t0_lds) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
 
     if (tid == 0) {
-        uint32_t nf0 = count_fields(b0p, 0, te0 - ls0);
+        // field table of record 0 (phyNGSC.cpp:345-379) + numeric candidates (only they can stay numeric)
+        uint32_t nf0 = 0, ncand = 0, start = 0;
+        for (uint32_t p = 0; p < t0len; ++p) {
+            if (!is_sep(s_t0[p])) continue;
+            if (nf0 < MAX_FIELDS) {
+                uint32_t v; bool o;
+                s_f0_start[nf0] = (uint16_t)start;
+                s_f0_len[nf0] = (uint16_t)(p - start);
+                uint8_t km = 0xff;
+                if (parse_num(s_t0, start, p, v, o)) {
+                    if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; s_cand_f[ncand++] = (uint8_t)nf0; }
+                    else {
+                        km = 0xfe;
+                        if (blockIdx.x == 0) A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1;
+                    }
+                }
+                s_kmap[nf0] = km;
+            }
+            ++nf0;
+            start = p + 1;
+        }
         s_nf0 = nf0;
+        s_ncand = ncand;
         if (blockIdx.x == 0) A.sb[s].nf = nf0;
         if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
     }
@@ -150,79 +178,80 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     const bool valid = i >= 0 && i < (int64_t)n;
     const bool owned = valid && tid >= 1;
     const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
-    uint32_t pc = valid ? A.ls[g] - b0 : 0, p0 = 0;   // tile-relative / title-relative cursors
-    const uint32_t tec = valid ? A.te[g] - b0 : 0;
-    uint32_t nummask = 0;
-    bool short_title = false;
-    for (uint32_t f = 0; f < nf0; ++f) {
-        uint32_t v = 0;
-        bool isnum = false;
-        const uint32_t e0 = field_end(b0p, p0);
-        if (valid && pc <= tec) {
-            const uint32_t ec = field_end(tb, pc);
-            const uint32_t len = ec - pc, len0 = e0 - p0;
-            bool ovf = false;
-            isnum = parse_num(tb, pc, ec, v, ovf);
-            if (owned) {
-                uint32_t *st = s_stat + f * 24;
-                lds_max_t(st + 0, len);
-                lds_max_t(st + 1, ~len);
-                uint32_t m = len < len0 ? len : len0;
-                bool diff = false;
-                for (uint32_t p = 0; p < m; ++p) {
-                    if (tb[pc + p] != b0p[p0 + p]) {
-                        diff = true;
-                        if (p < 256) lds_or_t(st + 10 + (p >> 5), 1u << (p & 31));
-                    }
-                }
-                if (len != len0) { lds_max_t(st + 3, 1); lds_max_t(st + 2, 1); }
-                else if (diff) lds_max_t(st + 2, 1);
-                if (!isnum) lds_max_t(st + 4, 1);
-                else {
-                    if (ovf) lds_max_t(st + 5, 1);
-                    lds_max_t(st + 6, bias((int32_t)v));
-                    lds_max_t(st + 7, ~bias((int32_t)v));
+    const uint32_t pc = valid ? A.ls[g] - b0 : 0;
+    const uint32_t tl = valid ? A.te[g] - A.ls[g] + 1 : 0;  // title bytes including the newline
+    const uint32_t maxl = wmax(tl);
+
+    uint32_t f = 0, k = 0, nummask = 0;
+    uint64_t v = 0;
+    bool isdig = true, lead0 = false, ovf = false, diff = false;
+    for (uint32_t it = 0; it < maxl; ++it) {
+        const bool act = it < tl;
+        const uint32_t c = tb[act ? pc + it : pc];
+        const bool sep = act && sep_fast(c);
+        if (act && !sep) {
+            const uint32_t d = c - '0';
+            if (d > 9) isdig = false;
+            else {
+                if (k == 0 && d == 0) lead0 = true;
+                v = v * 10 + d;
+                if (v > 0x7fffffffull) { ovf = true; v &= 0xffffffffull; }
+            }
+            if (f < nf0 && k < s_f0_len[f]) {
+                if (c != s_t0[s_f0_start[f] + k]) {
+                    diff = true;
+                    if (owned && k < 256) lds_or_t(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
                 }
             }
-            pc = ec + 1;
-        } else if (valid) {
-            short_title = true;
+            ++k;
         }
-        nummask |= (uint32_t)isnum << f;
-        // delta against the previous record (tasks.cpp:149-166): neighbour lane, or LDS edge across waves
-        const uint32_t pv = __shfl_up(v, 1);
-        const uint32_t pnum = __shfl_up((uint32_t)isnum, 1);
-        if (lane == 63) s_edge_v[f][wave] = v;
-        if (lane == 0) s_own_v[f][wave] = v;
-        if (lane > 0 && owned && i >= 1 && isnum && pnum) {
-            int32_t d = (int32_t)(v - pv);
-            lds_max_t(s_stat + f * 24 + 8, bias(d));
-            lds_max_t(s_stat + f * 24 + 9, ~bias(d));
+        if (sep) {
+            if (f < nf0) {
+                const uint32_t len = k, len0 = s_f0_len[f];
+                const bool isn = isdig && len > 0 && !(len > 1 && lead0);  // utils::is_num, utils.h:107-114
+                if (owned) {
+                    uint32_t *st = s_stat + f * 24;
+                    lds_max_t(st + 0, len);
+                    lds_max_t(st + 1, ~len);
+                    if (len != len0) { lds_max_t(st + 3, 1); lds_max_t(st + 2, 1); }
+                    else if (diff) lds_max_t(st + 2, 1);
+                    if (!isn) lds_max_t(st + 4, 1);
+                    else {
+                        if (ovf) lds_max_t(st + 5, 1);
+                        lds_max_t(st + 6, bias((int32_t)(uint32_t)v));
+                        lds_max_t(st + 7, ~bias((int32_t)(uint32_t)v));
+                    }
+                }
+                const uint32_t kk = s_kmap[f];
+                if (kk < NUM_CAND_CAP) s_val[kk][tid] = (uint32_t)v;
+                nummask |= (uint32_t)isn << f;
+            }
+            ++f; k = 0; v = 0; isdig = true; lead0 = false; ovf = false; diff = false;
         }
-        p0 = e0 + 1;
     }
-    if (valid && (short_title || pc != tec + 1)) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
-    if (lane == 63) s_edge_m[wave] = nummask;
-    if (lane == 0) s_own_m[wave] = nummask;
+    if (valid && f != nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    s_nummask[tid] = nummask;
     __syncthreads();
-    if (lane == 0 && wave > 0 && owned && i >= 1) {
-        uint32_t both = s_own_m[wave] & s_edge_m[wave - 1];
-        for (uint32_t f = 0; f < nf0; ++f) {
-            if ((both >> f) & 1) {
-                int32_t d = (int32_t)(s_own_v[f][wave] - s_edge_v[f][wave - 1]);
-                lds_max_t(s_stat + f * 24 + 8, bias(d));
-                lds_max_t(s_stat + f * 24 + 9, ~bias(d));
+    if (owned && i >= 1) {
+        const uint32_t both = nummask & s_nummask[tid - 1];
+        const uint32_t ncand = s_ncand;
+        for (uint32_t kk = 0; kk < ncand; ++kk) {
+            const uint32_t ff = s_cand_f[kk];
+            if ((both >> ff) & 1) {
+                int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
+                lds_max_t(s_stat + ff * 24 + 8, bias(d));
+                lds_max_t(s_stat + ff * 24 + 9, ~bias(d));
             }
         }
     }
     __syncthreads();
     uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
-    for (uint32_t k = tid; k < nf0 * 24; k += blockDim.x) {
-        uint32_t v = s_stat[k];
-        if (!v) continue;
-        uint32_t w = k % 24;
-        if (w >= 10 && w < 18) atomicOr(gst + k, v);
-        else if (w < 10) atomicMax(gst + k, v);
+    for (uint32_t kx = tid; kx < nf0 * 24; kx += blockDim.x) {
+        uint32_t x = s_stat[kx];
+        if (!x) continue;
+        uint32_t w = kx % 24;
+        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
+        else if (w < 10) atomicMax(gst + kx, x);
     }
 }
 
@@ -249,7 +278,7 @@ __device__ __forceinline__ Slice make_slice(const Arena &A, uint32_t i0, uint32_
     if (S.valid) {
         uint32_t te = A.te[i0 + S.r], se = A.se[i0 + S.r];
         S.L = se - te - 1;
-        S.s0 = te + 1 - b0;   // tile-relative
+        S.s0 = te + 1 - b0;
         S.q0 = se + 3 - b0;
         S.j0 = (uint32_t)(((uint64_t)S.t * S.L) / T);
         S.j1 = (uint32_t)(((uint64_t)(S.t + 1) * S.L) / T);
@@ -282,6 +311,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // [tile_bytes] tile, then [lds_rows][HSTRIDE] histogram
     __shared__ uint32_t s_occ[256];
+    __shared__ uint8_t s_amb[256];
     __shared__ uint32_t s_red[3];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
@@ -296,27 +326,39 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
 
     for (uint32_t k = tid; k < lds_rows * HSTRIDE; k += TL_THREADS) s_hist[k] = 0;
     s_occ[tid] = 0;
+    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
     if (tid < 3) s_red[tid] = 0;
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
     const Slice S = make_slice(A, i0, nt, T, b0);
 
+    // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it
+    if ((uint32_t)tid < nt) {
+        uint32_t se = A.se[i0 + tid] - b0;
+        if (tb[se + 1] != '+' || tb[se + 2] != '\n') atomicMin(A.err, (int32_t)ERR_FORMAT);
+    }
     if (t0 == 0 && tid == 0) {  // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
         uint8_t c1 = tb[S.s0 + 1];
         if (S.L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
     }
+    const uint32_t len = S.j1 - S.j0;
+    const uint32_t maxl = wmax(len);
     // pass 1: N-transfer test (phyNGSC.cpp:549-571).  The serial loop stops at the first failure, so the
     // outcome is "some ambiguous base" && "no failure anywhere": order independent.
     uint32_t fl = 0, namb = 0;  // bit0 any, bit1 bad
-    for (uint32_t j = S.j0; j < S.j1; ++j) {
-        uint8_t c = tb[S.s0 + j];
-        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) {
-            uint32_t a = amb_code(c);
-            if (a == 0) fl |= 2;
-            else {
-                uint8_t q = tb[S.q0 + j];
-                fl |= (q < 33 || q > 40) ? 2u : 1u;
-                ++namb;
+    for (uint32_t it = 0; it < maxl; ++it) {
+        const bool act = it < len;
+        const uint32_t j = act ? S.j0 + it : S.j0;
+        const uint32_t a = s_amb[tb[S.s0 + j]];
+        const bool isamb = act && a != 1;
+        if (__any(isamb)) {
+            if (isamb) {
+                if (a == 0) fl |= 2;
+                else {
+                    uint8_t q = tb[S.q0 + j];
+                    fl |= (q < 33 || q > 40) ? 2u : 1u;
+                    ++namb;
+                }
             }
         }
     }
@@ -335,21 +377,25 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     {
-        const uint32_t len = S.j1 - S.j0;
-        uint32_t j = len ? S.j0 + (uint32_t)lane % len : 0;
-        for (uint32_t it = 0; it < len; ++it) {
-            uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-            uint32_t a = amb_fast_t(c);
-            bool drop = xfer && a > 1;
-            uint32_t qv = drop ? transfer_quality(a, q) : q;  // phyNGSC.cpp:579
-            uint32_t row = j + 1, col = qv - 33;
-            if (col < HCOLS && row < lds_rows) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
-            else atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
-            if (!drop) {
-                cA += c == 'A'; cC += c == 'C'; cG += c == 'G'; cT += c == 'T';
-                if (a != 1) atomicAdd(&s_occ[c], 1u);
+        uint32_t j = len ? S.j0 + (uint32_t)lane % len : S.j0;
+        for (uint32_t it = 0; it < maxl; ++it) {
+            const bool act = it < len;
+            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
+            const uint32_t a = s_amb[c];
+            const bool drop = xfer && a > 1;
+            const uint32_t qv = drop ? (uint32_t)transfer_quality(a, (uint8_t)q) : q;  // phyNGSC.cpp:579
+            const uint32_t row = j + 1, col = qv - 33;
+            const bool in_lds = act && col < HCOLS && row < lds_rows;
+            if (in_lds) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
+            if (__any(act && !in_lds)) {
+                if (act && !in_lds) atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
             }
-            if (++j == S.j1) j = S.j0;
+            const bool keep = act && !drop;
+            cA += keep && c == 'A'; cC += keep && c == 'C'; cG += keep && c == 'G'; cT += keep && c == 'T';
+            if (__any(keep && a != 1)) {
+                if (keep && a != 1) atomicAdd(&s_occ[c], 1u);
+            }
+            if (act) { ++j; if (j == S.j1) j = S.j0; }
         }
     }
     cA = wsum(cA); cC = wsum(cC); cG = wsum(cG); cT = wsum(cT);
@@ -359,8 +405,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     __syncthreads();
     for (uint32_t k = tid; k < lds_rows * HCOLS; k += TL_THREADS) {
         uint32_t row = k / HCOLS, col = k % HCOLS;
-        uint32_t v = s_hist[row * HSTRIDE + col];
-        if (v) atomicAdd(&qh[(size_t)row * 256 + 33 + col], v);
+        uint32_t x = s_hist[row * HSTRIDE + col];
+        if (x) atomicAdd(&qh[(size_t)row * 256 + 33 + col], x);
     }
     if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
     if (tid == 0) {
@@ -371,17 +417,19 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
 }
 
 // ====================================================================================================
-// Measure
+// Measure / pack common pieces
 // ====================================================================================================
 struct SqLut {
     const uint32_t *qtab;  // LDS or global; row stride qstride
     uint32_t qstride;
     const uint32_t *dcode; // LDS [256]
     const uint8_t *qcode;  // LDS [256]
+    const uint8_t *amb;    // LDS [256]
 };
 
 __device__ __forceinline__ void load_luts(const Arena &A, uint32_t s, const SbState &sb, uint32_t *s_qtab,
-                                          uint32_t lds_entries, uint32_t *s_dcode, uint8_t *s_qcode, SqLut &Lt)
+                                          uint32_t lds_entries, uint32_t *s_dcode, uint8_t *s_qcode, uint8_t *s_amb,
+                                          SqLut &Lt)
 {
     const int tid = threadIdx.x;
     const uint32_t nq = sb.nqual, entries = (sb.max_q + 1) * nq;
@@ -396,8 +444,10 @@ __device__ __forceinline__ void load_luts(const Arena &A, uint32_t s, const SbSt
     }
     s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
     s_qcode[tid] = sb.qua_code[tid];
+    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
     Lt.dcode = s_dcode;
     Lt.qcode = s_qcode;
+    Lt.amb = s_amb;
 }
 
 // group-of-32 OR / add reductions (xor distances < 32 never leave the 32-lane half)
@@ -414,17 +464,66 @@ __device__ __forceinline__ uint32_t g32_sum(uint32_t v)
     return v;
 }
 
+// Cached non-constant title fields of one record: numeric -> value, text -> tile offset | length << 16.
+struct CachedTitle {
+    uint32_t cur[NCF_CAP];
+    uint32_t prev[NCF_CAP];
+};
+
+// One record's title bits from its cached fields (tasks.cpp:427-507; same order and rules as
+// title_record_emit() in ngsc_common.h, which the untiled kernels and the CPU harness use).
+template <class Sink>
+__device__ __forceinline__ void title_emit_cached(const uint8_t *tb, const Arena &A, uint32_t s, const FieldDesc *fd,
+                                                  const uint8_t *kf_field, uint32_t ncf, bool first,
+                                                  const CachedTitle &C, uint32_t gconst, Sink &w)
+{
+#pragma unroll
+    for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+        if (kf >= ncf) break;
+        const uint32_t f = kf_field[kf];
+        const FieldDesc &d = fd[f];
+        const uint32_t wc = C.cur[kf];
+        if (d.kind == KIND_NUM) {
+            if (first) {
+                w.put(wc - (uint32_t)d.min_v, d.bits_val);                       // tasks.cpp:457
+            } else if (!((gconst >> f) & 1)) {
+                const uint32_t to_store = d.delta_coding ? (wc - C.prev[kf] - (uint32_t)d.min_d) : (wc - (uint32_t)d.min_v);
+                if (d.has_huff) {
+                    const uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                    w.put(e >> 5, e & 31);
+                } else {
+                    w.put(to_store, d.bits_num);
+                }
+            }
+        } else {  // KIND_TEXT
+            if (first || !((gconst >> f) & 1)) {                                  // tasks.cpp:487
+                const uint32_t start = wc & 0xffffu, len = wc >> 16;
+                if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
+                const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
+                for (uint32_t j = 0; j < len; ++j) {
+                    if (!ham_bit(d, j)) {
+                        const uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + tb[start + j]];
+                        w.put(e >> 5, e & 31);
+                    }
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries)
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // tile, then quality code table
     __shared__ uint32_t s_dcode[256];
-    __shared__ uint8_t s_qcode[256];
+    __shared__ uint8_t s_qcode[256], s_amb[256];
     __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint32_t s_w[NCF_CAP][TL_THREADS];
+    __shared__ uint8_t s_kf_field[NCF_CAP];
     __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
     const uint32_t t0 = blockIdx.x * R;
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
@@ -436,16 +535,69 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TL_THREADS)
         reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
     SqLut Lt;
-    load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, Lt);
+    load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
+    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
 
-    // ---- title: thread per record (tasks.cpp:393-509) ----
-    {
-        const bool valid = (uint32_t)tid < nt;
-        const uint32_t gi = tid & 31;                  // index inside the 32-record group
-        const uint32_t gstart = tid - gi;              // tile-relative first record of the group
-        const uint32_t gsize = valid ? ((gstart + 32 <= nt) ? 32u : nt - gstart) : 0u;
+    // ---- title (tasks.cpp:393-509) ----
+    const bool valid = (uint32_t)tid < nt;
+    const uint32_t gi = tid & 31;                  // index inside the 32-record group
+    const uint32_t gstart = tid - gi;              // tile-relative first record of the group
+    const uint32_t gsize = valid ? ((gstart + 32 <= nt) ? 32u : nt - gstart) : 0u;
+    uint32_t bits = 0, gconst = 0;
+    if (ncf <= NCF_CAP) {
+        // one flat pass over the title: cache the non-constant fields of this record
+        const uint32_t pc = valid ? A.ls[i0 + tid] - b0 : 0;
+        const uint32_t tl = valid ? A.te[i0 + tid] - A.ls[i0 + tid] + 1 : 0;
+        const uint32_t maxl = wmax(tl);
+        uint32_t f = 0, k = 0, v = 0;
+        for (uint32_t it = 0; it < maxl; ++it) {
+            const bool act = it < tl;
+            const uint32_t c = tb[act ? pc + it : pc];
+            const bool sep = act && sep_fast(c);
+            if (act && !sep) { v = v * 10 + (c - '0'); ++k; }   // wraps like utils::to_num (utils.h:117-125)
+            if (sep) {
+                if (f < nf && s_fd[f].kind != KIND_CONST)
+                    s_w[s_fd[f].kf][tid] = s_fd[f].kind == KIND_NUM ? v : ((pc + it - k) | (k << 16));
+                ++f; k = 0; v = 0;
+            }
+        }
+        __syncthreads();
+        CachedTitle C;
+        TitleDiffs d = {0, 0, 0};
+#pragma unroll
+        for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+            C.cur[kf] = C.prev[kf] = 0;
+            if (kf >= ncf || !valid) continue;
+            const uint32_t ff = s_kf_field[kf];
+            const uint32_t wc = s_w[kf][tid];
+            C.cur[kf] = wc;
+            A.tw[(size_t)kf * A.tw_stride + i0 + tid] = wc;
+            if (gi) {
+                const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
+                C.prev[kf] = wp;
+                if (s_fd[ff].kind == KIND_NUM) {
+                    if (wc != wf) d.val |= 1u << ff;
+                    if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= 1u << ff;
+                } else {
+                    const uint32_t lc = wc >> 16, sc = wc & 0xffffu, sf = wf & 0xffffu;
+                    bool same = lc == (wf >> 16);
+                    for (uint32_t j = 0; same && j < lc; ++j) same = tb[sc + j] == tb[sf + j];
+                    if (!same) d.txt |= 1u << ff;
+                }
+            }
+        }
+        TitleDiffs gd = {g32_or(d.txt), g32_or(d.val), g32_or(d.dlt)};
+        gconst = title_group_const(s_fd, nf, gd, gsize);
+        if (valid) {
+            BitCounter bc;
+            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
+            title_emit_cached(tb, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, bc);
+            bits = (uint32_t)bc.bits;
+        }
+    } else {
+        // many non-constant fields: walk (first, previous, current) titles per record
         TitleDiffs d = {0, 0, 0};
         uint32_t p_cur = 0, p_prev = 0;
         if (valid) {
@@ -454,15 +606,16 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
             if (gi) d = title_record_diffs(tb, s_fd, nf, A.ls[i0 + gstart] - b0, p_prev, p_cur);
         }
         TitleDiffs gd = {g32_or(d.txt), g32_or(d.val), g32_or(d.dlt)};
-        const uint32_t gconst = title_group_const(s_fd, nf, gd, gsize);
-        uint32_t bits = 0;
+        gconst = title_group_const(s_fd, nf, gd, gsize);
         if (valid) {
             BitCounter bc;
             if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
             title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, bc);
             bits = (uint32_t)bc.bits;
-            A.tbits[i0 + tid] = bits;
         }
+    }
+    if (valid) A.tbits[i0 + tid] = bits;
+    {
         uint32_t gbits = g32_sum(bits);
         if (valid && gi == 0) {
             uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
@@ -473,15 +626,19 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
     // ---- quality / DNA: bits of this thread's slice ----
     const Slice S = make_slice(A, i0, nt, T, b0);
     uint32_t qb = 0, db = 0;
-    if (S.valid) {
-        const bool xfer = A.slen[i0 + S.r] >> 31;
-        for (uint32_t j = S.j0; j < S.j1; ++j) {
-            uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-            uint32_t a = xfer ? amb_fast_t(c) : 1u;
-            bool drop = xfer && a > 1;
-            uint32_t qv = drop ? transfer_quality(a, q) : q;
-            qb += Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]] & 31;
-            if (!drop) db += Lt.dcode[c] & 31;
+    {
+        const bool xfer = S.valid ? (A.slen[i0 + S.r] >> 31) : false;
+        const uint32_t len = S.j1 - S.j0;
+        const uint32_t maxl = wmax(len);
+        for (uint32_t it = 0; it < maxl; ++it) {
+            const bool act = it < len;
+            const uint32_t j = act ? S.j0 + it : S.j0;
+            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
+            const bool drop = xfer && Lt.amb[c] > 1;
+            const uint32_t qv = drop ? (uint32_t)transfer_quality(Lt.amb[c], (uint8_t)q) : q;
+            const uint32_t qe = Lt.qtab[(act ? j + 1 : 0) * Lt.qstride + Lt.qcode[qv]];
+            qb += act ? (qe & 31) : 0;
+            db += (act && !drop) ? (Lt.dcode[c] & 31) : 0;
         }
     }
     const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
@@ -594,12 +751,13 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     // dynamic LDS: tile | quality code table | staging areas (title sw_t, quality sw_q, DNA sw_d words)
     extern __shared__ __align__(16) uint8_t s_dyn[];
     __shared__ uint32_t s_dcode[256];
-    __shared__ uint8_t s_qcode[256];
+    __shared__ uint8_t s_qcode[256], s_amb[256];
     __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint8_t s_kf_field[NCF_CAP];
     __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
     const uint32_t t0 = blockIdx.x * R;
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
@@ -615,9 +773,11 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TL_THREADS)
         reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
     SqLut Lt;
-    load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, Lt);
+    load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
+    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
+    __syncthreads();
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
 
     // absolute bit ranges of this tile's share of the three payload streams
@@ -653,9 +813,21 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
             const uint32_t gconst = A.gflags[grp];
             LaneWriter w;
             w.init(t_lds ? st_t : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
-            const uint32_t p_cur = A.ls[i0 + tid] - b0, p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
             if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
-            title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, w);
+            if (ncf <= NCF_CAP) {
+                CachedTitle C;
+#pragma unroll
+                for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+                    C.cur[kf] = C.prev[kf] = 0;
+                    if (kf >= ncf) continue;
+                    C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + i0 + tid];
+                    if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + i0 + tid - 1];
+                }
+                title_emit_cached(tb, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
+            } else {
+                const uint32_t p_cur = A.ls[i0 + tid] - b0, p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
+                title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, w);
+            }
             w.finish();
         }
     }
@@ -667,26 +839,24 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
         uint32_t tq, td;
         const uint32_t qo = wg_scan_excl256(ub & 0xffffu, s_part, &tq);
         const uint32_t dofs = wg_scan_excl256(ub >> 16, s_part, &td);
-        if (S.valid && S.j1 > S.j0) {
-            const bool xfer = A.slen[i0 + S.r] >> 31;
-            LaneWriter wq_, wd_;
-            wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
-            wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
-            for (uint32_t j = S.j0; j < S.j1; ++j) {
-                uint8_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-                uint32_t a = xfer ? amb_fast_t(c) : 1u;
-                bool drop = xfer && a > 1;
-                uint32_t qv = drop ? transfer_quality(a, q) : q;
-                uint32_t qe = Lt.qtab[(j + 1) * Lt.qstride + Lt.qcode[qv]];   // tasks.cpp:614-618
-                wq_.put(qe >> 5, qe & 31);
-                if (!drop) {
-                    uint32_t de = Lt.dcode[c];                                 // tasks.cpp:549-556
-                    wd_.put(de >> 5, de & 31);
-                }
-            }
-            wq_.finish();
-            wd_.finish();
+        const bool xfer = S.valid ? (A.slen[i0 + S.r] >> 31) : false;
+        const uint32_t len = S.j1 - S.j0;
+        const uint32_t maxl = wmax(len);
+        LaneWriter wq_, wd_;
+        wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
+        wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
+        for (uint32_t it = 0; it < maxl; ++it) {
+            const bool act = it < len;
+            const uint32_t j = act ? S.j0 + it : S.j0;
+            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
+            const bool drop = xfer && Lt.amb[c] > 1;
+            const uint32_t qv = drop ? (uint32_t)transfer_quality(Lt.amb[c], (uint8_t)q) : q;
+            const uint32_t qe = Lt.qtab[(act ? j + 1 : 0) * Lt.qstride + Lt.qcode[qv]];   // tasks.cpp:614-618
+            const uint32_t de = Lt.dcode[c];                                              // tasks.cpp:549-556
+            wq_.put(qe >> 5, act ? (qe & 31) : 0);
+            wd_.put(de >> 5, (act && !drop) ? (de & 31) : 0);
         }
+        if (len) { wq_.finish(); wd_.finish(); }
     }
     __syncthreads();
     if (t_lds) copy_out_words(outw, st_t, tw0, tnw, tb0, tb1);
@@ -701,7 +871,7 @@ constexpr uint32_t TILE_LDS_BUDGET = 48u << 10;   // bytes of raw records per ti
 template <class K>
 static void allow_big_lds(K kernel)
 {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 << 10);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
 }
 
 // Records per tile for a job whose longest record has max_rec_bytes; 0 = use the untiled kernels.

@@ -32,6 +32,8 @@ constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
 constexpr uint32_t MAX_FIELDS = 32;         // separators per title
 constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant text field (Hamming mask bits)
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
+constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
+constexpr uint32_t NUM_CAND_CAP = 16;       // numeric candidate fields whose deltas the tiled statistics track
 
 constexpr uint32_t BLOB_SLOT_256 = 336;     // >= 9 + ceil((256*9 + 255)/8) = 329
 constexpr uint32_t BLOB_SLOT_512 = 720;     // >= 9 + ceil((512*10 + 511)/8) = 713
@@ -170,7 +172,8 @@ struct FieldStat {
     uint32_t max_v, inv_min_v;  // biased int32
     uint32_t max_d, inv_min_d;  // biased int32 (deltas between consecutive records)
     uint32_t not_ham[8];    // bit p set: some record differs from record 0 at position p (< 256)
-    uint32_t pad[6];
+    uint32_t no_delta;      // tiled path: deltas of this field were not tracked (too many numeric candidates)
+    uint32_t pad[5];
 };
 static_assert(sizeof(FieldStat) == 96, "FieldStat layout");
 
@@ -190,7 +193,8 @@ struct FieldDesc {
     int32_t base;           // min_v or min_d
     uint32_t slot;          // text statistics / code slot, 0xffffffff if none
     uint32_t ham[8];        // Hamming mask bits (1 = every record equals record 0 at that position)
-    uint32_t pad[5];
+    uint32_t kf;            // index among the sub-block's non-constant fields
+    uint32_t pad[4];
 };
 static_assert(sizeof(FieldDesc) == 128, "FieldDesc layout");
 
@@ -204,6 +208,7 @@ struct SbState {        // per sub-block scalars
     uint32_t info_len, title_len, qual_len, dna_len;
     uint32_t total;
     uint32_t n_bases;               // sum of sequence lengths (= quality bytes) of the sub-block
+    uint32_t ncf, pad1;             // number of non-constant title fields
     uint64_t out_off;               // byte offset of the sub-block in the output buffer
     uint8_t symbols[256];
     uint8_t qualities[256];
@@ -226,6 +231,8 @@ struct Arena {
     uint32_t *gflags;       // per title group: flag bits (tiled path)
     uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
     uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
+    uint32_t *tw;           // [NCF_CAP][tw_stride]: cached non-constant title fields per record (tiled path)
+    uint32_t tw_stride;
     uint32_t *tile_lo;      // per sub-block: first tile index
     int32_t *err;           // job error word (min over error codes)
     // per sub-block arrays (index by sub-block)
@@ -328,6 +335,7 @@ NGSC_HD int finalize_field(const FieldStat &st, uint32_t start0, uint32_t len0, 
     d.min_len = ~st.inv_min_len;
     d.is_len_const = !st.not_len_const;
     d.slot = 0xffffffffu;
+    d.kf = 0;
     d.has_huff = 0;
     d.n_sym = 0;
     d.base = 0;
@@ -340,6 +348,7 @@ NGSC_HD int finalize_field(const FieldStat &st, uint32_t start0, uint32_t len0, 
     if (!st.not_const) { d.kind = KIND_CONST; return OK; }
     if (!st.not_num) {
         if (st.ovf) return ERR_RANGE;
+        if (st.no_delta) return ERR_UNSUPPORTED;
         d.kind = KIND_NUM;
         d.min_v = unbias(~st.inv_min_v);
         d.max_v = unbias(st.max_v);
