@@ -20,6 +20,7 @@
 // used nested per-lane while-loops and spent 80 % of its time in scalar exec-mask bookkeeping (SQ_INSTS_SALU).
 // Integer / byte work bounded by HBM (tile load) and LDS / VALU issue; no MFMA.
 #include "ngsc_kernels.h"
+#include <cstdlib>
 
 namespace ngsc {
 
@@ -93,6 +94,13 @@ __device__ __forceinline__ uint32_t load_tile(const Arena &A, uint32_t i0, uint3
 __device__ __forceinline__ void lds_max_t(uint32_t *p, uint32_t v) { if (v > *p) atomicMax(p, v); }
 __device__ __forceinline__ void lds_or_t(uint32_t *p, uint32_t v) { if ((*p & v) != v) atomicOr(p, v); }
 
+// A, C, G, T without a table: bit (c - 'A') of a 32-bit mask
+__device__ __forceinline__ bool is_acgt(uint32_t c)
+{
+    const uint32_t x = c - 'A';
+    return x < 32u && ((0x00080045u >> x) & 1u);   // bits 0 (A), 2 (C), 6 (G), 19 (T)
+}
+
 // branch-free membership test for the title separators " ._,=:/-#\n" (phyNGSC.cpp:208)
 __device__ __forceinline__ bool sep_fast(uint32_t c)
 {
@@ -112,7 +120,7 @@ __device__ __forceinline__ bool sep_fast(uint32_t c)
 // ====================================================================================================
 constexpr uint32_t REC0_TITLE_CAP = 1024;
 
-__global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
+__global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A, uint32_t dbg)
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     if (t0len > REC0_TITLE_CAP) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
     for (uint32_t k = tid; k < t0len; k += blockDim.x) s_t0[k] = A.buf[ls0 + k];
     for (int k = tid; k < (int)(MAX_FIELDS * 24); k += blockDim.x) s_stat[k] = 0;
-    const uint32_t b0 = load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
+    const uint32_t b0 = (dbg & 2) ? (A.ls[rec_lo + r0] & ~15u) : load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
     const uint8_t *tb = s_dyn;   // tile bytes, indexed by (position - b0)
 
     if (tid == 0) {
@@ -182,54 +190,76 @@ __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A)
     const uint32_t tl = valid ? A.te[g] - A.ls[g] + 1 : 0;  // title bytes including the newline
     const uint32_t maxl = wmax(tl);
 
-    uint32_t f = 0, k = 0, nummask = 0;
-    uint64_t v = 0;
-    bool isdig = true, lead0 = false, ovf = false, diff = false;
-    for (uint32_t it = 0; it < maxl; ++it) {
-        const bool act = it < tl;
-        const uint32_t c = tb[act ? pc + it : pc];
-        const bool sep = act && sep_fast(c);
-        if (act && !sep) {
+    // Per-lane parser state kept in integer registers (flag bits, not bools: the compiler turns bool state
+    // into scalar lane masks and spends most of the kernel in s_and/s_or bookkeeping).  The only branches in
+    // the byte loop are wave-level: "some lane sits on a separator", "some lane found a byte that differs".
+    //   st bit0: non-digit seen, bit1: leading zero, bit2: value > INT32_MAX, bit3: differs from record 0
+    uint32_t f = 0, k = 0, nummask = 0, v = 0, stf = 0;
+    uint32_t f0len = nf0 ? s_f0_len[0] : 0, f0start = nf0 ? s_f0_start[0] : 0;
+    const uint32_t maxl8 = (dbg & 1) ? 0u : ((maxl + 7) & ~7u);
+    for (uint32_t base = 0; base < maxl8; base += 8) {
+        uint32_t cb[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) cb[u] = tb[(base + u < tl) ? pc + base + u : pc];  // 8 loads in flight
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t it = base + u;
+            const uint32_t c = cb[u];
+            const uint32_t act = it < tl ? 1u : 0u;
+            const uint32_t sepb = act & (sep_fast(c) ? 1u : 0u);
+            const uint32_t body = act & (sepb ^ 1u);
             const uint32_t d = c - '0';
-            if (d > 9) isdig = false;
-            else {
-                if (k == 0 && d == 0) lead0 = true;
-                v = v * 10 + d;
-                if (v > 0x7fffffffull) { ovf = true; v &= 0xffffffffull; }
+            const uint32_t dig = d <= 9 ? 1u : 0u;
+            const uint32_t ovn = (v > 214748364u || (v == 214748364u && d > 7)) ? 1u : 0u;
+            const uint32_t ld0 = (k == 0 && d == 0) ? 1u : 0u;
+            const uint32_t inr = body & (k < f0len ? 1u : 0u);          // f0len == 0 once f >= nf0
+            const uint32_t c0 = s_t0[f0start + (inr ? k : 0)];
+            const uint32_t nd = inr & (c != c0 ? 1u : 0u);
+            stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | ((body & dig & ovn) << 2) | (nd << 3);
+            v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num
+            if (__any(nd)) {
+                if (nd && owned && k < 256) lds_or_t(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
             }
-            if (f < nf0 && k < s_f0_len[f]) {
-                if (c != s_t0[s_f0_start[f] + k]) {
-                    diff = true;
-                    if (owned && k < 256) lds_or_t(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
-                }
-            }
-            ++k;
-        }
-        if (sep) {
-            if (f < nf0) {
-                const uint32_t len = k, len0 = s_f0_len[f];
-                const bool isn = isdig && len > 0 && !(len > 1 && lead0);  // utils::is_num, utils.h:107-114
-                if (owned) {
-                    uint32_t *st = s_stat + f * 24;
-                    lds_max_t(st + 0, len);
-                    lds_max_t(st + 1, ~len);
-                    if (len != len0) { lds_max_t(st + 3, 1); lds_max_t(st + 2, 1); }
-                    else if (diff) lds_max_t(st + 2, 1);
-                    if (!isn) lds_max_t(st + 4, 1);
-                    else {
-                        if (ovf) lds_max_t(st + 5, 1);
-                        lds_max_t(st + 6, bias((int32_t)(uint32_t)v));
-                        lds_max_t(st + 7, ~bias((int32_t)(uint32_t)v));
+            k += body;
+            if (__any(sepb)) {
+                if (sepb) {
+                    if (f < nf0) {
+                        const uint32_t len = k, len0 = f0len;
+                        const bool isn = !(stf & 1) && len > 0 && !(len > 1 && (stf & 2));  // utils::is_num
+                        // A field identical to record 0's cannot change any statistic beyond what record 0's own
+                        // thread contributes, so only differing fields (and record 0 itself) touch the counters.
+                        const bool same = len == len0 && !(stf & 8);
+                        if (owned && (!same || i == 0)) {
+                            uint32_t *st = s_stat + f * 24;
+                            const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5],
+                                           a6 = st[6], a7 = st[7];
+                            const uint32_t bv = bias((int32_t)v);
+                            const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3,
+                                       n4 = !isn && !a4, n5 = isn && (stf & 4) && !a5, n6 = isn && bv > a6,
+                                       n7 = isn && ~bv > a7;
+                            if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
+                                if (n0) atomicMax(st + 0, len);
+                                if (n1) atomicMax(st + 1, ~len);
+                                if (n2) atomicMax(st + 2, 1u);
+                                if (n3) atomicMax(st + 3, 1u);
+                                if (n4) atomicMax(st + 4, 1u);
+                                if (n5) atomicMax(st + 5, 1u);
+                                if (n6) atomicMax(st + 6, bv);
+                                if (n7) atomicMax(st + 7, ~bv);
+                            }
+                        }
+                        const uint32_t kk = s_kmap[f];
+                        if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
+                        nummask |= (uint32_t)isn << f;
                     }
+                    ++f; k = 0; v = 0; stf = 0;
+                    f0len = f < nf0 ? s_f0_len[f] : 0;
+                    f0start = f < nf0 ? s_f0_start[f] : 0;
                 }
-                const uint32_t kk = s_kmap[f];
-                if (kk < NUM_CAND_CAP) s_val[kk][tid] = (uint32_t)v;
-                nummask |= (uint32_t)isn << f;
             }
-            ++f; k = 0; v = 0; isdig = true; lead0 = false; ovf = false; diff = false;
         }
     }
-    if (valid && f != nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    if (valid && f != nf0 && !dbg) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
     s_nummask[tid] = nummask;
     __syncthreads();
     if (owned && i >= 1) {
@@ -346,18 +376,24 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     // pass 1: N-transfer test (phyNGSC.cpp:549-571).  The serial loop stops at the first failure, so the
     // outcome is "some ambiguous base" && "no failure anywhere": order independent.
     uint32_t fl = 0, namb = 0;  // bit0 any, bit1 bad
-    for (uint32_t it = 0; it < maxl; ++it) {
-        const bool act = it < len;
-        const uint32_t j = act ? S.j0 + it : S.j0;
-        const uint32_t a = s_amb[tb[S.s0 + j]];
-        const bool isamb = act && a != 1;
-        if (__any(isamb)) {
-            if (isamb) {
-                if (a == 0) fl |= 2;
-                else {
-                    uint8_t q = tb[S.q0 + j];
-                    fl |= (q < 33 || q > 40) ? 2u : 1u;
-                    ++namb;
+    for (uint32_t base = 0; base < maxl; base += 8) {
+        uint32_t cc[8];
+        bool anyamb = false;
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) cc[u] = tb[S.s0 + ((base + u < len) ? S.j0 + base + u : S.j0)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) anyamb = anyamb || (base + u < len && !is_acgt(cc[u]));
+        if (__any(anyamb)) {  // rare: some lane of the wave holds a non-ACGT base in this chunk
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                if (base + u < len && !is_acgt(cc[u])) {
+                    const uint32_t a = s_amb[cc[u]];
+                    if (a == 0) fl |= 2;
+                    else {
+                        uint8_t q = tb[S.q0 + S.j0 + base + u];
+                        fl |= (q < 33 || q > 40) ? 2u : 1u;
+                        ++namb;
+                    }
                 }
             }
         }
@@ -377,25 +413,42 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     {
-        uint32_t j = len ? S.j0 + (uint32_t)lane % len : S.j0;
-        for (uint32_t it = 0; it < maxl; ++it) {
-            const bool act = it < len;
-            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-            const uint32_t a = s_amb[c];
-            const bool drop = xfer && a > 1;
-            const uint32_t qv = drop ? (uint32_t)transfer_quality(a, (uint8_t)q) : q;  // phyNGSC.cpp:579
-            const uint32_t row = j + 1, col = qv - 33;
-            const bool in_lds = act && col < HCOLS && row < lds_rows;
-            if (in_lds) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
-            if (__any(act && !in_lds)) {
-                if (act && !in_lds) atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
+        const uint32_t rot = len ? (uint32_t)lane % len : 0;
+        const bool wave_xfer = __any(xfer);
+        for (uint32_t base = 0; base < maxl; base += 8) {
+            uint32_t cc[8], qq[8], jj[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {   // 16 LDS loads in flight
+                uint32_t x = rot + base + u;
+                if (x >= len) x -= len;
+                jj[u] = S.j0 + ((base + u < len) ? x : 0);
+                cc[u] = tb[S.s0 + jj[u]];
+                qq[u] = tb[S.q0 + jj[u]];
             }
-            const bool keep = act && !drop;
-            cA += keep && c == 'A'; cC += keep && c == 'C'; cG += keep && c == 'G'; cT += keep && c == 'T';
-            if (__any(keep && a != 1)) {
-                if (keep && a != 1) atomicAdd(&s_occ[c], 1u);
+            uint32_t cnt4 = 0;  // per-chunk A/C/G/T counters, 8 bits each
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool act = base + u < len;
+                const uint32_t c = cc[u];
+                const bool acgt = is_acgt(c);
+                bool drop = false;
+                uint32_t qv = qq[u];
+                if (wave_xfer || __any(act && !acgt)) {   // rare: transfer records or non-ACGT symbols around
+                    const uint32_t a = s_amb[c];
+                    drop = xfer && a > 1;
+                    if (drop) qv = transfer_quality(a, (uint8_t)qv);  // phyNGSC.cpp:579
+                    if (act && !drop && !acgt) atomicAdd(&s_occ[c], 1u);
+                }
+                const uint32_t row = jj[u] + 1, col = qv - 33;
+                const bool in_lds = act && col < HCOLS && row < lds_rows;
+                if (in_lds) atomicAdd(&s_hist[row * HSTRIDE + col], 1u);
+                if (__any(act && !in_lds)) {
+                    if (act && !in_lds) atomicAdd(&qh[(size_t)row * 256 + qv], 1u);
+                }
+                // A=0x41 C=0x43 G=0x47 T=0x54: (c >> 1) & 3 = 0, 1, 3, 2
+                cnt4 += (act && !drop && acgt) ? (1u << (((c >> 1) & 3u) * 8u)) : 0u;
             }
-            if (act) { ++j; if (j == S.j1) j = S.j0; }
+            cA += cnt4 & 0xffu; cC += (cnt4 >> 8) & 0xffu; cT += (cnt4 >> 16) & 0xffu; cG += cnt4 >> 24;
         }
     }
     cA = wsum(cA); cC = wsum(cC); cG = wsum(cG); cT = wsum(cT);
@@ -630,15 +683,34 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
         const bool xfer = S.valid ? (A.slen[i0 + S.r] >> 31) : false;
         const uint32_t len = S.j1 - S.j0;
         const uint32_t maxl = wmax(len);
-        for (uint32_t it = 0; it < maxl; ++it) {
-            const bool act = it < len;
-            const uint32_t j = act ? S.j0 + it : S.j0;
-            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-            const bool drop = xfer && Lt.amb[c] > 1;
-            const uint32_t qv = drop ? (uint32_t)transfer_quality(Lt.amb[c], (uint8_t)q) : q;
-            const uint32_t qe = Lt.qtab[(act ? j + 1 : 0) * Lt.qstride + Lt.qcode[qv]];
-            qb += act ? (qe & 31) : 0;
-            db += (act && !drop) ? (Lt.dcode[c] & 31) : 0;
+        const bool wave_xfer = __any(xfer);
+        for (uint32_t base = 0; base < maxl; base += 8) {
+            uint32_t cc[8], qv[8], qc[8], qe[8], de[8];
+            uint32_t dropm = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t j = (base + u < len) ? S.j0 + base + u : S.j0;
+                cc[u] = tb[S.s0 + j];
+                qv[u] = tb[S.q0 + j];
+            }
+            if (wave_xfer) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t a = Lt.amb[cc[u]];
+                    if (xfer && a > 1) { dropm |= 1u << u; qv[u] = transfer_quality(a, (uint8_t)qv[u]); }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) { qc[u] = Lt.qcode[qv[u]]; de[u] = Lt.dcode[cc[u]]; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)
+                qe[u] = Lt.qtab[((base + u < len) ? S.j0 + base + u + 1 : 0) * Lt.qstride + qc[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool act = base + u < len;
+                qb += act ? (qe[u] & 31) : 0;
+                db += (act && !((dropm >> u) & 1)) ? (de[u] & 31) : 0;
+            }
         }
     }
     const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
@@ -845,16 +917,34 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
         LaneWriter wq_, wd_;
         wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
         wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
-        for (uint32_t it = 0; it < maxl; ++it) {
-            const bool act = it < len;
-            const uint32_t j = act ? S.j0 + it : S.j0;
-            const uint32_t c = tb[S.s0 + j], q = tb[S.q0 + j];
-            const bool drop = xfer && Lt.amb[c] > 1;
-            const uint32_t qv = drop ? (uint32_t)transfer_quality(Lt.amb[c], (uint8_t)q) : q;
-            const uint32_t qe = Lt.qtab[(act ? j + 1 : 0) * Lt.qstride + Lt.qcode[qv]];   // tasks.cpp:614-618
-            const uint32_t de = Lt.dcode[c];                                              // tasks.cpp:549-556
-            wq_.put(qe >> 5, act ? (qe & 31) : 0);
-            wd_.put(de >> 5, (act && !drop) ? (de & 31) : 0);
+        const bool wave_xfer = __any(xfer);
+        for (uint32_t base = 0; base < maxl; base += 8) {
+            uint32_t cc[8], qv[8], qc[8], qe[8], de[8];
+            uint32_t dropm = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const uint32_t j = (base + u < len) ? S.j0 + base + u : S.j0;
+                cc[u] = tb[S.s0 + j];
+                qv[u] = tb[S.q0 + j];
+            }
+            if (wave_xfer) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8; ++u) {
+                    const uint32_t a = Lt.amb[cc[u]];
+                    if (xfer && a > 1) { dropm |= 1u << u; qv[u] = transfer_quality(a, (uint8_t)qv[u]); }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) { qc[u] = Lt.qcode[qv[u]]; de[u] = Lt.dcode[cc[u]]; }   // tasks.cpp:549-556
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u)                                                          // tasks.cpp:614-618
+                qe[u] = Lt.qtab[((base + u < len) ? S.j0 + base + u + 1 : 0) * Lt.qstride + qc[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; ++u) {
+                const bool act = base + u < len;
+                wq_.put(qe[u] >> 5, act ? (qe[u] & 31) : 0);
+                wd_.put(de[u] >> 5, (act && !((dropm >> u) & 1)) ? (de[u] & 31) : 0);
+            }
         }
         if (len) { wq_.finish(); wd_.finish(); }
     }
@@ -895,7 +985,8 @@ void launch_title_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, u
     dim3 grid((max_rec + R - 2) / (R - 1), A.n_sb);
     size_t lds = tile_bytes_for(R, max_rec_bytes);
     allow_big_lds(k_title_stats_tile);
-    hipLaunchKernelGGL(k_title_stats_tile, grid, dim3(R), lds, st, A);
+    static const uint32_t dbg = getenv("NGSC_DBG_TS") ? (uint32_t)atoi(getenv("NGSC_DBG_TS")) : 0;
+    hipLaunchKernelGGL(k_title_stats_tile, grid, dim3(R), lds, st, A, dbg);
 }
 
 void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
