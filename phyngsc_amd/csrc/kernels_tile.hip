@@ -118,7 +118,7 @@ __device__ __forceinline__ bool sep_fast(uint32_t c)
 // halo (thread 0).  One flat pass over the title bytes per lane: separator test, decimal accumulate and
 // comparison with record 0 of the sub-block (whose title and field table sit in LDS) in the same loop body.
 // ====================================================================================================
-constexpr uint32_t REC0_TITLE_CAP = 1024;
+constexpr uint32_t REC0_TITLE_CAP = 512;
 
 __global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A, uint32_t dbg)
 {
