@@ -388,7 +388,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_tilelo = cp.take(4 * (size_t)S);
     size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
     size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
-    size_t p_tw = cp.take(R ? 4 * (size_t)NCF_CAP * rec_cap : 0);
+    size_t p_tw = cp.take(4 * (size_t)NCF_CAP * rec_cap);
+    size_t p_rec0 = cp.take(sizeof(Rec0Tab) * (size_t)S);
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
     Carver ct;
@@ -415,6 +416,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.ubits = (uint32_t *)(pb + p_ubits);
     A.tw = (uint32_t *)(pb + p_tw);
     A.tw_stride = (uint32_t)rec_cap;
+    A.rec0 = (Rec0Tab *)(pb + p_rec0);
     A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;
     A.sb = (SbState *)(pb + p_sb);
@@ -467,24 +469,21 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemcpyAsync(A.tile_lo, h_grp + S, 4 * (size_t)S, hipMemcpyHostToDevice, st));
 
     // ---- stage C ----
-    if (R) {
-        { KScope k(c, st, "k_title_stats_tile"); launch_title_stats_tile(st, A, max_rec, R, max_rec_bytes); }
-        { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
-    } else {
-        { KScope k(c, st, "k_title_stats"); launch_title_stats(st, A, max_rec); }
-        { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
-    }
+    { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
+    { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+    if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
+    else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
     { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
     { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec); }
     { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
+    { KScope k(c, st, "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec); }
     if (R) {
-        { KScope k(c, st, "k_measure_tile"); launch_measure_tile(st, A, max_rec, R, max_rec_bytes); }
+        { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
         { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     } else {
         { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
-        { KScope k(c, st, "k_title_measure"); launch_title_measure(st, A, max_rec); }
         { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
@@ -521,12 +520,9 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)std::min<uint64_t>(out_cap, (total + 15) & ~15ull), st));
     { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
-    if (R) {
-        { KScope k(c, st, "k_pack_tile"); launch_pack_tile(st, A, max_rec, R, max_rec_bytes); }
-    } else {
-        { KScope k(c, st, "k_title_pack"); launch_title_pack(st, A, max_rec); }
-        { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
-    }
+    { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
+    if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
+    else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
     HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());

@@ -6,15 +6,13 @@
 // thread per record slice (sequence / quality; T = 256 / R threads share a record), so HBM sees each raw
 // byte once per kernel and all random access, histogramming, code lookup and bit merging stays on chip:
 //
-//   k_title_stats_tile     AnalyzeTitleFields reductions                                (tasks.cpp:22-193)
 //   k_seq_qual_stats_tile  N-transfer test, DNA counts, per-position quality histogram   (phyNGSC.cpp:462-653,
 //                                                                                         tasks.cpp:260-286)
-//   k_measure_tile         parses each title once more, caches its non-constant fields, derives the 32-record
-//                          group flags and the title bits per record; quality / DNA bits per slice and tile
+//   k_measure_sq_tile      quality / DNA code bits per record slice and per tile
 //   k_scan_tile            per-sub-block exclusive scans of group bytes and tile bit totals
-//   k_pack_tile            StoreTitle body (from the cached fields), StoreQuality and StoreDNA payloads: every
-//                          lane accumulates its own bits and ORs whole words into LDS staging; one coalesced
-//                          copy-out per stream                                (tasks.cpp:427-507, 544-557, 609-619)
+//   k_pack_sq_tile         StoreQuality and StoreDNA payloads: every lane accumulates its own bits and ORs whole
+//                          words into LDS staging; one coalesced copy-out per stream (tasks.cpp:544-557, 609-619)
+// (The title path lives in kernels_title.hip: it parses out of registers and needs no tile.)
 //
 // Loops are written with wave-uniform trip counts and predicated bodies: the first version of these kernels
 // used nested per-lane while-loops and spent 80 % of its time in scalar exec-mask bookkeeping (SQ_INSTS_SALU).
@@ -111,178 +109,6 @@ __device__ __forceinline__ bool sep_fast(uint32_t c)
     const uint32_t w = c >> 5;
     const uint32_t m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : 0u));
     return (m >> (c & 31)) & 1u;
-}
-
-// ====================================================================================================
-// Title statistics.  blockDim.x = R threads; a tile is R-1 owned records plus the previous record as delta
-// halo (thread 0).  One flat pass over the title bytes per lane: separator test, decimal accumulate and
-// comparison with record 0 of the sub-block (whose title and field table sit in LDS) in the same loop body.
-// ====================================================================================================
-constexpr uint32_t REC0_TITLE_CAP = 512;
-
-__global__ __launch_bounds__(TL_THREADS) void k_title_stats_tile(Arena A, uint32_t dbg)
-{
-    if (*A.err) return;
-    extern __shared__ __align__(16) uint8_t s_dyn[];
-    const uint32_t s = blockIdx.y;
-    const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
-    const uint32_t owned_per_tile = blockDim.x - 1;
-    if (blockIdx.x * owned_per_tile >= n) return;
-    const int tid = threadIdx.x;
-
-    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
-    __shared__ uint32_t s_val[NUM_CAND_CAP][TL_THREADS];  // values of the numeric candidate fields
-    __shared__ uint32_t s_nummask[TL_THREADS];
-    __shared__ uint16_t s_f0_start[MAX_FIELDS], s_f0_len[MAX_FIELDS];
-    __shared__ uint8_t s_kmap[MAX_FIELDS], s_cand_f[NUM_CAND_CAP];
-    __shared__ uint32_t s_nf0, s_ncand;
-    __shared__ uint8_t s_t0[REC0_TITLE_CAP];
-
-    const int64_t ifirst = (int64_t)blockIdx.x * owned_per_tile - 1;
-    const uint32_t r0 = ifirst < 0 ? 0u : (uint32_t)ifirst;
-    const uint64_t rend = ((uint64_t)blockIdx.x + 1) * owned_per_tile;
-    const uint32_t r1 = rend < n ? (uint32_t)rend : n;  // exclusive
-    const uint32_t ls0 = A.ls[rec_lo], te0 = A.te[rec_lo];
-    const uint32_t t0len = te0 - ls0 + 1;
-    if (t0len > REC0_TITLE_CAP) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
-    for (uint32_t k = tid; k < t0len; k += blockDim.x) s_t0[k] = A.buf[ls0 + k];
-    for (int k = tid; k < (int)(MAX_FIELDS * 24); k += blockDim.x) s_stat[k] = 0;
-    const uint32_t b0 = (dbg & 2) ? (A.ls[rec_lo + r0] & ~15u) : load_tile(A, rec_lo + r0, rec_lo + r1, s_dyn);
-    const uint8_t *tb = s_dyn;   // tile bytes, indexed by (position - b0)
-
-    if (tid == 0) {
-        // field table of record 0 (phyNGSC.cpp:345-379) + numeric candidates (only they can stay numeric)
-        uint32_t nf0 = 0, ncand = 0, start = 0;
-        for (uint32_t p = 0; p < t0len; ++p) {
-            if (!is_sep(s_t0[p])) continue;
-            if (nf0 < MAX_FIELDS) {
-                uint32_t v; bool o;
-                s_f0_start[nf0] = (uint16_t)start;
-                s_f0_len[nf0] = (uint16_t)(p - start);
-                uint8_t km = 0xff;
-                if (parse_num(s_t0, start, p, v, o)) {
-                    if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; s_cand_f[ncand++] = (uint8_t)nf0; }
-                    else {
-                        km = 0xfe;
-                        if (blockIdx.x == 0) A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1;
-                    }
-                }
-                s_kmap[nf0] = km;
-            }
-            ++nf0;
-            start = p + 1;
-        }
-        s_nf0 = nf0;
-        s_ncand = ncand;
-        if (blockIdx.x == 0) A.sb[s].nf = nf0;
-        if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
-    }
-    __syncthreads();
-    const uint32_t nf0 = s_nf0;
-    if (nf0 > MAX_FIELDS) return;
-
-    const int64_t i = (int64_t)blockIdx.x * owned_per_tile + tid - 1;  // record index inside the sub-block
-    const bool valid = i >= 0 && i < (int64_t)n;
-    const bool owned = valid && tid >= 1;
-    const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
-    const uint32_t pc = valid ? A.ls[g] - b0 : 0;
-    const uint32_t tl = valid ? A.te[g] - A.ls[g] + 1 : 0;  // title bytes including the newline
-    const uint32_t maxl = wmax(tl);
-
-    // Per-lane parser state kept in integer registers (flag bits, not bools: the compiler turns bool state
-    // into scalar lane masks and spends most of the kernel in s_and/s_or bookkeeping).  The only branches in
-    // the byte loop are wave-level: "some lane sits on a separator", "some lane found a byte that differs".
-    //   st bit0: non-digit seen, bit1: leading zero, bit2: value > INT32_MAX, bit3: differs from record 0
-    uint32_t f = 0, k = 0, nummask = 0, v = 0, stf = 0;
-    uint32_t f0len = nf0 ? s_f0_len[0] : 0, f0start = nf0 ? s_f0_start[0] : 0;
-    const uint32_t maxl8 = (dbg & 1) ? 0u : ((maxl + 7) & ~7u);
-    for (uint32_t base = 0; base < maxl8; base += 8) {
-        uint32_t cb[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) cb[u] = tb[(base + u < tl) ? pc + base + u : pc];  // 8 loads in flight
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-            const uint32_t it = base + u;
-            const uint32_t c = cb[u];
-            const uint32_t act = it < tl ? 1u : 0u;
-            const uint32_t sepb = act & (sep_fast(c) ? 1u : 0u);
-            const uint32_t body = act & (sepb ^ 1u);
-            const uint32_t d = c - '0';
-            const uint32_t dig = d <= 9 ? 1u : 0u;
-            const uint32_t ovn = (v > 214748364u || (v == 214748364u && d > 7)) ? 1u : 0u;
-            const uint32_t ld0 = (k == 0 && d == 0) ? 1u : 0u;
-            const uint32_t inr = body & (k < f0len ? 1u : 0u);          // f0len == 0 once f >= nf0
-            const uint32_t c0 = s_t0[f0start + (inr ? k : 0)];
-            const uint32_t nd = inr & (c != c0 ? 1u : 0u);
-            stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | ((body & dig & ovn) << 2) | (nd << 3);
-            v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num
-            if (__any(nd)) {
-                if (nd && owned && k < 256) lds_or_t(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
-            }
-            k += body;
-            if (__any(sepb)) {
-                if (sepb) {
-                    if (f < nf0) {
-                        const uint32_t len = k, len0 = f0len;
-                        const bool isn = !(stf & 1) && len > 0 && !(len > 1 && (stf & 2));  // utils::is_num
-                        // A field identical to record 0's cannot change any statistic beyond what record 0's own
-                        // thread contributes, so only differing fields (and record 0 itself) touch the counters.
-                        const bool same = len == len0 && !(stf & 8);
-                        if (owned && (!same || i == 0)) {
-                            uint32_t *st = s_stat + f * 24;
-                            const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5],
-                                           a6 = st[6], a7 = st[7];
-                            const uint32_t bv = bias((int32_t)v);
-                            const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3,
-                                       n4 = !isn && !a4, n5 = isn && (stf & 4) && !a5, n6 = isn && bv > a6,
-                                       n7 = isn && ~bv > a7;
-                            if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
-                                if (n0) atomicMax(st + 0, len);
-                                if (n1) atomicMax(st + 1, ~len);
-                                if (n2) atomicMax(st + 2, 1u);
-                                if (n3) atomicMax(st + 3, 1u);
-                                if (n4) atomicMax(st + 4, 1u);
-                                if (n5) atomicMax(st + 5, 1u);
-                                if (n6) atomicMax(st + 6, bv);
-                                if (n7) atomicMax(st + 7, ~bv);
-                            }
-                        }
-                        const uint32_t kk = s_kmap[f];
-                        if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
-                        nummask |= (uint32_t)isn << f;
-                    }
-                    ++f; k = 0; v = 0; stf = 0;
-                    f0len = f < nf0 ? s_f0_len[f] : 0;
-                    f0start = f < nf0 ? s_f0_start[f] : 0;
-                }
-            }
-        }
-    }
-    if (valid && f != nf0 && !dbg) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
-    s_nummask[tid] = nummask;
-    __syncthreads();
-    if (owned && i >= 1) {
-        const uint32_t both = nummask & s_nummask[tid - 1];
-        const uint32_t ncand = s_ncand;
-        for (uint32_t kk = 0; kk < ncand; ++kk) {
-            const uint32_t ff = s_cand_f[kk];
-            if ((both >> ff) & 1) {
-                int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
-                lds_max_t(s_stat + ff * 24 + 8, bias(d));
-                lds_max_t(s_stat + ff * 24 + 9, ~bias(d));
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
-    for (uint32_t kx = tid; kx < nf0 * 24; kx += blockDim.x) {
-        uint32_t x = s_stat[kx];
-        if (!x) continue;
-        uint32_t w = kx % 24;
-        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
-        else if (w < 10) atomicMax(gst + kx, x);
-    }
 }
 
 // ====================================================================================================
@@ -517,66 +343,16 @@ __device__ __forceinline__ uint32_t g32_sum(uint32_t v)
     return v;
 }
 
-// Cached non-constant title fields of one record: numeric -> value, text -> tile offset | length << 16.
-struct CachedTitle {
-    uint32_t cur[NCF_CAP];
-    uint32_t prev[NCF_CAP];
-};
-
-// One record's title bits from its cached fields (tasks.cpp:427-507; same order and rules as
-// title_record_emit() in ngsc_common.h, which the untiled kernels and the CPU harness use).
-template <class Sink>
-__device__ __forceinline__ void title_emit_cached(const uint8_t *tb, const Arena &A, uint32_t s, const FieldDesc *fd,
-                                                  const uint8_t *kf_field, uint32_t ncf, bool first,
-                                                  const CachedTitle &C, uint32_t gconst, Sink &w)
-{
-#pragma unroll
-    for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
-        if (kf >= ncf) break;
-        const uint32_t f = kf_field[kf];
-        const FieldDesc &d = fd[f];
-        const uint32_t wc = C.cur[kf];
-        if (d.kind == KIND_NUM) {
-            if (first) {
-                w.put(wc - (uint32_t)d.min_v, d.bits_val);                       // tasks.cpp:457
-            } else if (!((gconst >> f) & 1)) {
-                const uint32_t to_store = d.delta_coding ? (wc - C.prev[kf] - (uint32_t)d.min_d) : (wc - (uint32_t)d.min_v);
-                if (d.has_huff) {
-                    const uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
-                    w.put(e >> 5, e & 31);
-                } else {
-                    w.put(to_store, d.bits_num);
-                }
-            }
-        } else {  // KIND_TEXT
-            if (first || !((gconst >> f) & 1)) {                                  // tasks.cpp:487
-                const uint32_t start = wc & 0xffffu, len = wc >> 16;
-                if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
-                const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
-                for (uint32_t j = 0; j < len; ++j) {
-                    if (!ham_bit(d, j)) {
-                        const uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + tb[start + j]];
-                        w.put(e >> 5, e & 31);
-                    }
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries)
+__global__ __launch_bounds__(TL_THREADS) void k_measure_sq_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries)
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // tile, then quality code table
     __shared__ uint32_t s_dcode[256];
     __shared__ uint8_t s_qcode[256], s_amb[256];
-    __shared__ FieldDesc s_fd[MAX_FIELDS];
-    __shared__ uint32_t s_w[NCF_CAP][TL_THREADS];
-    __shared__ uint8_t s_kf_field[NCF_CAP];
     __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     const uint32_t t0 = blockIdx.x * R;
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
@@ -585,97 +361,11 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_tile(Arena A, uint32_t R
     const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
 
-    for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TL_THREADS)
-        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
-    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
 
-    // ---- title (tasks.cpp:393-509) ----
-    const bool valid = (uint32_t)tid < nt;
-    const uint32_t gi = tid & 31;                  // index inside the 32-record group
-    const uint32_t gstart = tid - gi;              // tile-relative first record of the group
-    const uint32_t gsize = valid ? ((gstart + 32 <= nt) ? 32u : nt - gstart) : 0u;
-    uint32_t bits = 0, gconst = 0;
-    if (ncf <= NCF_CAP) {
-        // one flat pass over the title: cache the non-constant fields of this record
-        const uint32_t pc = valid ? A.ls[i0 + tid] - b0 : 0;
-        const uint32_t tl = valid ? A.te[i0 + tid] - A.ls[i0 + tid] + 1 : 0;
-        const uint32_t maxl = wmax(tl);
-        uint32_t f = 0, k = 0, v = 0;
-        for (uint32_t it = 0; it < maxl; ++it) {
-            const bool act = it < tl;
-            const uint32_t c = tb[act ? pc + it : pc];
-            const bool sep = act && sep_fast(c);
-            if (act && !sep) { v = v * 10 + (c - '0'); ++k; }   // wraps like utils::to_num (utils.h:117-125)
-            if (sep) {
-                if (f < nf && s_fd[f].kind != KIND_CONST)
-                    s_w[s_fd[f].kf][tid] = s_fd[f].kind == KIND_NUM ? v : ((pc + it - k) | (k << 16));
-                ++f; k = 0; v = 0;
-            }
-        }
-        __syncthreads();
-        CachedTitle C;
-        TitleDiffs d = {0, 0, 0};
-#pragma unroll
-        for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
-            C.cur[kf] = C.prev[kf] = 0;
-            if (kf >= ncf || !valid) continue;
-            const uint32_t ff = s_kf_field[kf];
-            const uint32_t wc = s_w[kf][tid];
-            C.cur[kf] = wc;
-            A.tw[(size_t)kf * A.tw_stride + i0 + tid] = wc;
-            if (gi) {
-                const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
-                C.prev[kf] = wp;
-                if (s_fd[ff].kind == KIND_NUM) {
-                    if (wc != wf) d.val |= 1u << ff;
-                    if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= 1u << ff;
-                } else {
-                    const uint32_t lc = wc >> 16, sc = wc & 0xffffu, sf = wf & 0xffffu;
-                    bool same = lc == (wf >> 16);
-                    for (uint32_t j = 0; same && j < lc; ++j) same = tb[sc + j] == tb[sf + j];
-                    if (!same) d.txt |= 1u << ff;
-                }
-            }
-        }
-        TitleDiffs gd = {g32_or(d.txt), g32_or(d.val), g32_or(d.dlt)};
-        gconst = title_group_const(s_fd, nf, gd, gsize);
-        if (valid) {
-            BitCounter bc;
-            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
-            title_emit_cached(tb, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, bc);
-            bits = (uint32_t)bc.bits;
-        }
-    } else {
-        // many non-constant fields: walk (first, previous, current) titles per record
-        TitleDiffs d = {0, 0, 0};
-        uint32_t p_cur = 0, p_prev = 0;
-        if (valid) {
-            p_cur = A.ls[i0 + tid] - b0;
-            p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
-            if (gi) d = title_record_diffs(tb, s_fd, nf, A.ls[i0 + gstart] - b0, p_prev, p_cur);
-        }
-        TitleDiffs gd = {g32_or(d.txt), g32_or(d.val), g32_or(d.dlt)};
-        gconst = title_group_const(s_fd, nf, gd, gsize);
-        if (valid) {
-            BitCounter bc;
-            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
-            title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, bc);
-            bits = (uint32_t)bc.bits;
-        }
-    }
-    if (valid) A.tbits[i0 + tid] = bits;
-    {
-        uint32_t gbits = g32_sum(bits);
-        if (valid && gi == 0) {
-            uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
-            A.goff[grp] = (gbits + 7) >> 3;
-            A.gflags[grp] = gconst;
-        }
-    }
     // ---- quality / DNA: bits of this thread's slice ----
     const Slice S = make_slice(A, i0, nt, T, b0);
     uint32_t qb = 0, db = 0;
@@ -816,20 +506,18 @@ __device__ __forceinline__ void copy_out_words(uint32_t *outw, const uint32_t *s
     }
 }
 
-__global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries,
-                                                          uint32_t sw_t, uint32_t sw_q, uint32_t sw_d)
+__global__ __launch_bounds__(TL_THREADS) void k_pack_sq_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries,
+                                                             uint32_t sw_q, uint32_t sw_d)
 {
     if (*A.err) return;
-    // dynamic LDS: tile | quality code table | staging areas (title sw_t, quality sw_q, DNA sw_d words)
+    // dynamic LDS: tile | quality code table | staging areas (quality sw_q, DNA sw_d words)
     extern __shared__ __align__(16) uint8_t s_dyn[];
     __shared__ uint32_t s_dcode[256];
     __shared__ uint8_t s_qcode[256], s_amb[256];
-    __shared__ FieldDesc s_fd[MAX_FIELDS];
-    __shared__ uint8_t s_kf_field[NCF_CAP];
     __shared__ uint32_t s_part[TL_WAVES];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     const uint32_t t0 = blockIdx.x * R;
     if (t0 >= n) return;
     const uint32_t nt = t0 + R < n ? R : n - t0;
@@ -839,70 +527,25 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
     const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
     uint32_t *s_stage = s_qtab + lds_entries;
-    uint32_t *st_t = s_stage, *st_q = s_stage + sw_t, *st_d = s_stage + sw_t + sw_q;
+    uint32_t *st_q = s_stage, *st_d = s_stage + sw_q;
 
-    for (uint32_t k = tid; k < sw_t + sw_q + sw_d; k += TL_THREADS) s_stage[k] = 0;
-    for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TL_THREADS)
-        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+    for (uint32_t k = tid; k < sw_q + sw_d; k += TL_THREADS) s_stage[k] = 0;
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
-    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
-    __syncthreads();
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
 
-    // absolute bit ranges of this tile's share of the three payload streams
-    const uint32_t grp_first = A.grp_lo[s] + t0 / GROUP;
-    const uint32_t ngrp_t = (nt + GROUP - 1) / GROUP;
-    const uint64_t title_base = (sb.out_off + sb.info_len + sb.title_hdr) * 8;
-    const uint64_t tb0 = title_base + 8ull * A.goff[grp_first];
-    const uint64_t tb1 = title_base + 8ull * (last_tile ? sb.title_body : A.goff[grp_first + ngrp_t]);
+    // absolute bit ranges of this tile's share of the two payload streams
     const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
     const uint64_t qb0 = qbase + A.wq[tix], qb1 = qbase + (last_tile ? sb.qbits : A.wq[tix + 1]);
     const uint64_t db0 = dbase + A.wd[tix], db1 = dbase + (last_tile ? sb.dbits : A.wd[tix + 1]);
-    const uint64_t tw0 = tb0 >> 5, qw0 = qb0 >> 5, dw0 = db0 >> 5;
-    const uint32_t tnw = (uint32_t)(((tb1 + 31) >> 5) - tw0), qnw = (uint32_t)(((qb1 + 31) >> 5) - qw0),
-                   dnw = (uint32_t)(((db1 + 31) >> 5) - dw0);
-    // staging overflow (very long titles / codes): write straight into the zeroed output with atomics
-    const bool t_lds = tnw + 1 <= sw_t, q_lds = qnw + 1 <= sw_q, d_lds = dnw + 1 <= sw_d;
-
-    // ---- title: every lane ORs its own record's bits ----
-    {
-        const bool valid = (uint32_t)tid < nt;
-        const uint32_t gi = tid & 31, gstart = tid - gi;
-        const uint32_t bits = valid ? A.tbits[i0 + tid] : 0;
-        uint32_t incl = bits;  // inclusive prefix inside the 32-record group
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d);
-            if ((int)gi >= d) incl += o;
-        }
-        if (valid) {
-            const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
-            const uint32_t gconst = A.gflags[grp];
-            LaneWriter w;
-            w.init(t_lds ? st_t : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
-            if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
-            if (ncf <= NCF_CAP) {
-                CachedTitle C;
-#pragma unroll
-                for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
-                    C.cur[kf] = C.prev[kf] = 0;
-                    if (kf >= ncf) continue;
-                    C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + i0 + tid];
-                    if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + i0 + tid - 1];
-                }
-                title_emit_cached(tb, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
-            } else {
-                const uint32_t p_cur = A.ls[i0 + tid] - b0, p_prev = gi ? A.ls[i0 + tid - 1] - b0 : p_cur;
-                title_record_emit(tb, A, s, s_fd, nf, gi == 0, p_prev, p_cur, gconst, w);
-            }
-            w.finish();
-        }
-    }
+    const uint64_t qw0 = qb0 >> 5, dw0 = db0 >> 5;
+    const uint32_t qnw = (uint32_t)(((qb1 + 31) >> 5) - qw0), dnw = (uint32_t)(((db1 + 31) >> 5) - dw0);
+    // staging overflow (very long codes): write straight into the zeroed output with atomics
+    const bool q_lds = qnw + 1 <= sw_q, d_lds = dnw + 1 <= sw_d;
 
     // ---- quality / DNA: one lane per record slice, offsets from a workgroup scan of the slice bit counts ----
     {
@@ -949,7 +592,6 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_tile(Arena A, uint32_t R, u
         if (len) { wq_.finish(); wd_.finish(); }
     }
     __syncthreads();
-    if (t_lds) copy_out_words(outw, st_t, tw0, tnw, tb0, tb1);
     if (q_lds) copy_out_words(outw, st_q, qw0, qnw, qb0, qb1);
     if (d_lds) copy_out_words(outw, st_d, dw0, dnw, db0, db1);
 }
@@ -980,15 +622,6 @@ static uint32_t qtab_entries_for(uint32_t qrows)
     return (uint32_t)(e < 12288 ? e : 12288);  // <= 48 KB
 }
 
-void launch_title_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
-{
-    dim3 grid((max_rec + R - 2) / (R - 1), A.n_sb);
-    size_t lds = tile_bytes_for(R, max_rec_bytes);
-    allow_big_lds(k_title_stats_tile);
-    static const uint32_t dbg = getenv("NGSC_DBG_TS") ? (uint32_t)atoi(getenv("NGSC_DBG_TS")) : 0;
-    hipLaunchKernelGGL(k_title_stats_tile, grid, dim3(R), lds, st, A, dbg);
-}
-
 void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
 {
     uint32_t tbytes = tile_bytes_for(R, max_rec_bytes);
@@ -1001,12 +634,12 @@ void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec
     hipLaunchKernelGGL(k_seq_qual_stats_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, rows);
 }
 
-void launch_measure_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
+void launch_measure_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
 {
     uint32_t tbytes = tile_bytes_for(R, max_rec_bytes), le = qtab_entries_for(A.qrows);
     dim3 grid((max_rec + R - 1) / R, A.n_sb);
-    allow_big_lds(k_measure_tile);
-    hipLaunchKernelGGL(k_measure_tile, grid, dim3(TL_THREADS), tbytes + (size_t)le * 4, st, A, R, tbytes, le);
+    allow_big_lds(k_measure_sq_tile);
+    hipLaunchKernelGGL(k_measure_sq_tile, grid, dim3(TL_THREADS), tbytes + (size_t)le * 4, st, A, R, tbytes, le);
 }
 
 void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
@@ -1014,21 +647,20 @@ void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
     hipLaunchKernelGGL(k_scan_tile, dim3(A.n_sb), dim3(1024), 0, st, A, R);
 }
 
-void launch_pack_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
+void launch_pack_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
 {
     uint32_t tbytes = tile_bytes_for(R, max_rec_bytes), le = qtab_entries_for(A.qrows);
-    // staging sized for typical streams (5 bits per quality symbol, 3 per base, 6 B of title per record);
-    // a tile that needs more writes straight to the zeroed output with atomics
+    // staging sized for typical streams (5 bits per quality symbol, 3 per base); a tile that needs more
+    // writes straight to the zeroed output with atomics
     uint32_t maxq = A.qrows - 1;
     uint32_t sw_q = (uint32_t)(((uint64_t)R * maxq * 5) / 32) + 64;
     uint32_t sw_d = (uint32_t)(((uint64_t)R * maxq * 3) / 32) + 64;
-    uint32_t sw_t = (R * 6) / 4 + 64;
     if (sw_q > 4096) sw_q = 4096;
     if (sw_d > 3072) sw_d = 3072;
     dim3 grid((max_rec + R - 1) / R, A.n_sb);
-    size_t lds = tbytes + (size_t)le * 4 + ((size_t)sw_t + sw_q + sw_d) * 4;
-    allow_big_lds(k_pack_tile);
-    hipLaunchKernelGGL(k_pack_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, le, sw_t, sw_q, sw_d);
+    size_t lds = tbytes + (size_t)le * 4 + ((size_t)sw_q + sw_d) * 4;
+    allow_big_lds(k_pack_sq_tile);
+    hipLaunchKernelGGL(k_pack_sq_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, le, sw_q, sw_d);
 }
 
 }  // namespace ngsc

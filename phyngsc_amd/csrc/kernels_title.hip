@@ -1,0 +1,528 @@
+// kernels_title.hip - title path with the bytes in registers (no LDS tile): one thread per record reads its
+// own title with aligned 16-byte global loads (double buffered) and parses it byte by byte out of VGPRs.
+// LDS holds only a few KB of reduction state, so the kernels run at full occupancy (32 waves / CU); the LDS
+// tile versions of the same logic were latency bound at 8-12 waves / CU.
+//
+//   k_rec0_fields        field table of each sub-block's first record            (phyNGSC.cpp:342-379)
+//   k_title_stats_reg    AnalyzeTitleFields reductions                           (tasks.cpp:22-193)
+//   k_title_measure_reg  caches the non-constant fields of every record, derives the 32-record group flags
+//                        and the title bits per record                           (tasks.cpp:393-509)
+//   k_title_pack_reg     StoreTitle body from the cached fields; every lane ORs its bits into an LDS staging
+//                        area, one coalesced copy-out per 256 records            (tasks.cpp:427-507)
+// Algorithmic traffic: the title bytes once per kernel (stats, measure) + 4 B per cached field and record.
+#include "ngsc_kernels.h"
+
+namespace ngsc {
+
+constexpr int TT_THREADS = 256;
+constexpr int TT_WAVES = TT_THREADS / 64;
+
+__device__ __forceinline__ uint32_t t_wmax(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t t_g32_or(uint32_t v)
+{
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t t_g32_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ void t_lds_or(uint32_t *p, uint32_t v) { if ((*p & v) != v) atomicOr(p, v); }
+
+// branch-free membership test for the title separators " ._,=:/-#\n" (phyNGSC.cpp:208)
+__device__ __forceinline__ uint32_t t_sep(uint32_t c)
+{
+    const uint32_t m0 = 1u << 10;
+    const uint32_t m1 = (1u << 0) | (1u << 3) | (1u << 12) | (1u << 13) | (1u << 14) | (1u << 15) | (1u << 26) | (1u << 29);
+    const uint32_t m2 = 1u << 31;
+    const uint32_t w = c >> 5;
+    const uint32_t m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : 0u));
+    return (m >> (c & 31)) & 1u;
+}
+
+// Calls body(c, act, p) for 16 bytes per chunk of the title [ls, te] of this lane's record; every lane of the
+// wave makes the same number of calls (act == 0 outside its own title).  The next chunk is loaded while the
+// current one is parsed.
+__device__ __forceinline__ uint4 load16_guarded(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 16 <= buf_len) return *reinterpret_cast<const uint4 *>(buf + a);
+    uint32_t w[4] = {0, 0, 0, 0};   // last bytes of the job buffer: never read past its end
+    for (uint32_t x = 0; x < 16; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <class F>
+__device__ __forceinline__ void for_each_title_byte(const uint8_t *buf, uint32_t buf_len, uint32_t ls, uint32_t te, bool valid,
+                                                    F &&body)
+{
+    const uint32_t a0 = ls & ~15u;
+    const uint32_t nch = valid ? ((te - a0) >> 4) + 1 : 0;
+    const uint32_t maxch = t_wmax(nch);
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    if (nch) cur = load16_guarded(buf, a0, buf_len);
+    for (uint32_t ch = 0; ch < maxch; ++ch) {
+        if (ch + 1 < nch) nxt = load16_guarded(buf, a0 + 16 * (ch + 1), buf_len);
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (uint32_t b = 0; b < 16; ++b) {
+            const uint32_t p = a0 + 16 * ch + b;
+            const uint32_t act = (ch < nch && p >= ls && p <= te) ? 1u : 0u;
+            const uint32_t c = (w[b >> 2] >> (8 * (b & 3))) & 0xffu;
+            body(c, act, p);
+        }
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_sb) return;
+    const SbState &sb = A.sb[s];
+    Rec0Tab &T = A.rec0[s];
+    const uint32_t ls0 = A.ls[sb.rec_lo], te0 = A.te[sb.rec_lo];
+    const uint32_t tlen = te0 - ls0 + 1;
+    if (tlen > REC0_TITLE_CAP) { atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
+    uint32_t nf0 = 0, ncand = 0, start = 0;
+    for (uint32_t p = 0; p < tlen; ++p) {
+        const uint8_t c = A.buf[ls0 + p];
+        T.title[p] = c;
+        if (!is_sep(c)) continue;
+        if (nf0 < MAX_FIELDS) {
+            uint32_t v;
+            bool o;
+            T.start[nf0] = (uint16_t)start;
+            T.len[nf0] = (uint16_t)(p - start);
+            uint8_t km = 0xff;
+            if (parse_num(A.buf, ls0 + start, ls0 + p, v, o)) {   // only a numeric record 0 can leave the field numeric
+                if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; T.cand_f[ncand++] = (uint8_t)nf0; }
+                else { km = 0xfe; A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1; }
+            }
+            T.kmap[nf0] = km;
+        }
+        ++nf0;
+        start = p + 1;
+    }
+    T.nf0 = nf0;
+    T.ncand = ncand;
+    A.sb[s].nf = nf0;
+    if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 255 owned records + the previous record as delta halo (thread 0) per workgroup.
+__global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    constexpr uint32_t OWNED = TT_THREADS - 1;
+    if (blockIdx.x * OWNED >= n) return;
+    const int tid = threadIdx.x;
+
+    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
+    __shared__ uint32_t s_val[NUM_CAND_CAP][TT_THREADS];
+    __shared__ uint32_t s_nummask[TT_THREADS];
+    __shared__ Rec0Tab s_r0;
+
+    for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
+        reinterpret_cast<uint32_t *>(&s_r0)[k] = reinterpret_cast<const uint32_t *>(A.rec0 + s)[k];
+    for (uint32_t k = tid; k < MAX_FIELDS * 24; k += TT_THREADS) s_stat[k] = 0;
+    __syncthreads();
+    const uint32_t nf0 = s_r0.nf0;
+
+    const int64_t i = (int64_t)blockIdx.x * OWNED + tid - 1;  // record index inside the sub-block
+    const bool valid = i >= 0 && i < (int64_t)n;
+    const bool owned = valid && tid >= 1;
+    const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
+    const uint32_t ls = A.ls[g], te = A.te[g];
+
+    // parser state in integer registers; st bit0: non-digit seen, bit1: leading zero, bit2: value > INT32_MAX,
+    // bit3: differs from record 0
+    uint32_t f = 0, k = 0, nummask = 0, v = 0, stf = 0;
+    uint32_t f0len = nf0 ? s_r0.len[0] : 0, f0start = nf0 ? s_r0.start[0] : 0;
+    for_each_title_byte(A.buf, A.buf_len, ls, te, valid, [&](uint32_t c, uint32_t act, uint32_t) {
+        const uint32_t sepb = act & t_sep(c);
+        const uint32_t body = act & (sepb ^ 1u);
+        const uint32_t d = c - '0';
+        const uint32_t dig = d <= 9 ? 1u : 0u;
+        const uint32_t ovn = (v > 214748364u || (v == 214748364u && d > 7)) ? 1u : 0u;
+        const uint32_t ld0 = (k == 0 && d == 0) ? 1u : 0u;
+        const uint32_t inr = body & (k < f0len ? 1u : 0u);          // f0len == 0 once f >= nf0
+        const uint32_t c0 = s_r0.title[f0start + (inr ? k : 0)];
+        const uint32_t nd = inr & (c != c0 ? 1u : 0u);
+        stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | ((body & dig & ovn) << 2) | (nd << 3);
+        v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num (utils.h:117-125)
+        if (__any(nd)) {
+            if (nd && owned && k < 256) t_lds_or(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
+        }
+        k += body;
+        if (__any(sepb)) {
+            if (sepb) {
+                if (f < nf0) {
+                    const uint32_t len = k, len0 = f0len;
+                    const bool isn = !(stf & 1) && len > 0 && !(len > 1 && (stf & 2));  // utils::is_num, utils.h:107-114
+                    // A field identical to record 0's cannot change any statistic beyond what record 0's own
+                    // thread contributes, so only differing fields (and record 0 itself) touch the counters.
+                    const bool same = len == len0 && !(stf & 8);
+                    if (owned && (!same || i == 0)) {
+                        uint32_t *st = s_stat + f * 24;
+                        const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5], a6 = st[6],
+                                       a7 = st[7];
+                        const uint32_t bv = bias((int32_t)v);
+                        const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3,
+                                   n4 = !isn && !a4, n5 = isn && (stf & 4) && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
+                        if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
+                            if (n0) atomicMax(st + 0, len);
+                            if (n1) atomicMax(st + 1, ~len);
+                            if (n2) atomicMax(st + 2, 1u);
+                            if (n3) atomicMax(st + 3, 1u);
+                            if (n4) atomicMax(st + 4, 1u);
+                            if (n5) atomicMax(st + 5, 1u);
+                            if (n6) atomicMax(st + 6, bv);
+                            if (n7) atomicMax(st + 7, ~bv);
+                        }
+                    }
+                    const uint32_t kk = s_r0.kmap[f];
+                    if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
+                    nummask |= (uint32_t)isn << f;
+                }
+                ++f; k = 0; v = 0; stf = 0;
+                f0len = f < nf0 ? s_r0.len[f] : 0;
+                f0start = f < nf0 ? s_r0.start[f] : 0;
+            }
+        }
+    });
+    if (valid && f != nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    s_nummask[tid] = nummask;
+    __syncthreads();
+    if (owned && i >= 1) {
+        const uint32_t both = nummask & s_nummask[tid - 1];
+        const uint32_t ncand = s_r0.ncand;
+        for (uint32_t kk = 0; kk < ncand; ++kk) {
+            const uint32_t ff = s_r0.cand_f[kk];
+            if ((both >> ff) & 1) {
+                const int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
+                const uint32_t bd = bias(d);
+                if (bd > s_stat[ff * 24 + 8]) atomicMax(&s_stat[ff * 24 + 8], bd);
+                if (~bd > s_stat[ff * 24 + 9]) atomicMax(&s_stat[ff * 24 + 9], ~bd);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
+    for (uint32_t kx = tid; kx < nf0 * 24; kx += TT_THREADS) {
+        uint32_t x = s_stat[kx];
+        if (!x) continue;
+        uint32_t w = kx % 24;
+        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
+        else if (w < 10) atomicMax(gst + kx, x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Cached non-constant title fields of one record: numeric -> value, text -> (offset from the record start) |
+// length << 16.
+struct CachedTitle {
+    uint32_t cur[NCF_CAP];
+    uint32_t prev[NCF_CAP];
+};
+
+// One record's title bits from its cached fields (tasks.cpp:427-507; same order and rules as
+// title_record_emit() in ngsc_common.h, which the fallback path and the CPU harness use).
+// rec: first byte of the record (text field offsets are relative to it).
+template <class Sink>
+__device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Arena &A, uint32_t s, const FieldDesc *fd,
+                                                  const uint8_t *kf_field, uint32_t ncf, bool first,
+                                                  const CachedTitle &C, uint32_t gconst, Sink &w)
+{
+#pragma unroll
+    for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+        if (kf >= ncf) break;
+        const uint32_t f = kf_field[kf];
+        const FieldDesc &d = fd[f];
+        const uint32_t wc = C.cur[kf];
+        if (d.kind == KIND_NUM) {
+            if (first) {
+                w.put(wc - (uint32_t)d.min_v, d.bits_val);                       // tasks.cpp:457
+            } else if (!((gconst >> f) & 1)) {
+                const uint32_t to_store = d.delta_coding ? (wc - C.prev[kf] - (uint32_t)d.min_d) : (wc - (uint32_t)d.min_v);
+                if (d.has_huff) {
+                    const uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                    w.put(e >> 5, e & 31);
+                } else {
+                    w.put(to_store, d.bits_num);
+                }
+            }
+        } else {  // KIND_TEXT
+            if (first || !((gconst >> f) & 1)) {                                  // tasks.cpp:487
+                const uint32_t start = wc & 0xffffu, len = wc >> 16;
+                if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
+                const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
+                for (uint32_t j = 0; j < len; ++j) {
+                    if (!ham_bit(d, j)) {
+                        const uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + rec[start + j]];
+                        w.put(e >> 5, e & 31);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// 256 records (8 groups of 32) per workgroup.
+__global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
+    const uint32_t t0 = blockIdx.x * TT_THREADS;
+    if (t0 >= n) return;
+    const uint32_t nt = t0 + TT_THREADS < n ? TT_THREADS : n - t0;
+    const uint32_t i0 = rec_lo + t0;
+    const int tid = threadIdx.x;
+
+    __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint32_t s_w[NCF_CAP][TT_THREADS];
+    __shared__ uint8_t s_kf_field[NCF_CAP];
+
+    for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TT_THREADS)
+        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+    __syncthreads();
+    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
+
+    const bool valid = (uint32_t)tid < nt;
+    const uint32_t gi = tid & 31;                  // index inside the 32-record group
+    const uint32_t gstart = tid - gi;              // first record of the group (relative to t0)
+    const uint32_t gsize = valid ? ((gstart + 32 <= nt) ? 32u : nt - gstart) : 0u;
+    const uint32_t g = valid ? i0 + tid : i0;
+    const uint32_t ls = A.ls[g], te = A.te[g];
+    uint32_t bits = 0, gconst = 0;
+    if (ncf <= NCF_CAP) {
+        // one pass over the title: cache the non-constant fields of this record
+        uint32_t f = 0, k = 0, v = 0;
+        for_each_title_byte(A.buf, A.buf_len, ls, te, valid, [&](uint32_t c, uint32_t act, uint32_t p) {
+            const uint32_t sepb = act & t_sep(c);
+            const uint32_t body = act & (sepb ^ 1u);
+            v = body ? v * 10 + (c - '0') : v;   // wraps like utils::to_num; only used for all-numeric fields
+            k += body;
+            if (__any(sepb)) {
+                if (sepb) {
+                    if (f < nf && s_fd[f].kind != KIND_CONST)
+                        s_w[s_fd[f].kf][tid] = s_fd[f].kind == KIND_NUM ? v : ((p - k - ls) | (k << 16));
+                    ++f; k = 0; v = 0;
+                }
+            }
+        });
+        __syncthreads();
+        CachedTitle C;
+        TitleDiffs d = {0, 0, 0};
+#pragma unroll
+        for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+            C.cur[kf] = C.prev[kf] = 0;
+            if (kf >= ncf || !valid) continue;
+            const uint32_t ff = s_kf_field[kf];
+            const uint32_t wc = s_w[kf][tid];
+            C.cur[kf] = wc;
+            A.tw[(size_t)kf * A.tw_stride + g] = wc;
+            if (gi) {
+                const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
+                C.prev[kf] = wp;
+                if (s_fd[ff].kind == KIND_NUM) {
+                    if (wc != wf) d.val |= 1u << ff;
+                    if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= 1u << ff;
+                } else {
+                    const uint32_t lc = wc >> 16;
+                    const uint8_t *mine = A.buf + ls + (wc & 0xffffu), *frst = A.buf + A.ls[i0 + gstart] + (wf & 0xffffu);
+                    bool same = lc == (wf >> 16);
+                    for (uint32_t j = 0; same && j < lc; ++j) same = mine[j] == frst[j];
+                    if (!same) d.txt |= 1u << ff;
+                }
+            }
+        }
+        TitleDiffs gd = {t_g32_or(d.txt), t_g32_or(d.val), t_g32_or(d.dlt)};
+        gconst = title_group_const(s_fd, nf, gd, gsize);
+        if (valid) {
+            BitCounter bc;
+            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
+            title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, bc);
+            bits = (uint32_t)bc.bits;
+        }
+    } else {
+        // more non-constant fields than the cache holds: walk (first, previous, current) titles per record
+        TitleDiffs d = {0, 0, 0};
+        const uint32_t p_prev = (valid && gi) ? A.ls[g - 1] : ls;
+        if (valid && gi) d = title_record_diffs(A.buf, s_fd, nf, A.ls[i0 + gstart], p_prev, ls);
+        TitleDiffs gd = {t_g32_or(d.txt), t_g32_or(d.val), t_g32_or(d.dlt)};
+        gconst = title_group_const(s_fd, nf, gd, gsize);
+        if (valid) {
+            BitCounter bc;
+            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
+            title_record_emit(A.buf, A, s, s_fd, nf, gi == 0, p_prev, ls, gconst, bc);
+            bits = (uint32_t)bc.bits;
+        }
+    }
+    if (valid) A.tbits[g] = bits;
+    const uint32_t gbits = t_g32_sum(bits);
+    if (valid && gi == 0) {
+        const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
+        A.goff[grp] = (gbits + 7) >> 3;
+        A.gflags[grp] = gconst;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One lane's MSB-first bit writer into a word array (LDS staging, or the zeroed output in the overflow path).
+struct TLaneWriter {
+    uint32_t *words;
+    uint64_t widx;
+    uint64_t acc;
+    uint32_t nacc;
+    __device__ __forceinline__ void init(uint32_t *w, uint64_t word0, uint64_t bitpos)
+    {
+        words = w;
+        widx = (bitpos >> 5) - word0;
+        acc = 0;
+        nacc = (uint32_t)(bitpos & 31);
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb)
+    {
+        if (!nb) return;
+        if (nb < 32) v &= (1u << nb) - 1u;
+        acc = (acc << nb) | v;
+        nacc += nb;
+        if (nacc >= 32) {
+            uint32_t word = (uint32_t)(acc >> (nacc - 32));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            ++widx;
+            nacc -= 32;
+            acc &= (1ull << nacc) - 1ull;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc) {
+            uint32_t word = (uint32_t)(acc << (32 - nacc));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            nacc = 0;
+        }
+    }
+};
+
+constexpr uint32_t TP_STAGE_WORDS = 2048;  // 8 KB: 32 B of title bits per record on average
+
+__global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
+    const uint32_t t0 = blockIdx.x * TT_THREADS;
+    if (t0 >= n) return;
+    const uint32_t nt = t0 + TT_THREADS < n ? TT_THREADS : n - t0;
+    const uint32_t i0 = rec_lo + t0;
+    const bool last_tile = t0 + TT_THREADS >= n;
+    const int tid = threadIdx.x;
+
+    __shared__ FieldDesc s_fd[MAX_FIELDS];
+    __shared__ uint8_t s_kf_field[NCF_CAP];
+    __shared__ uint32_t s_stage[TP_STAGE_WORDS];
+
+    for (uint32_t k = tid; k < TP_STAGE_WORDS; k += TT_THREADS) s_stage[k] = 0;
+    for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TT_THREADS)
+        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+    __syncthreads();
+    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
+    __syncthreads();
+
+    uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
+    const uint32_t grp_first = A.grp_lo[s] + t0 / GROUP;
+    const uint32_t ngrp_t = (nt + GROUP - 1) / GROUP;
+    const uint64_t title_base = (sb.out_off + sb.info_len + sb.title_hdr) * 8;
+    const uint64_t tb0 = title_base + 8ull * A.goff[grp_first];
+    const uint64_t tb1 = title_base + 8ull * (last_tile ? sb.title_body : A.goff[grp_first + ngrp_t]);
+    const uint64_t tw0 = tb0 >> 5;
+    const uint32_t tnw = (uint32_t)(((tb1 + 31) >> 5) - tw0);
+    const bool t_lds = tnw + 1 <= TP_STAGE_WORDS;  // otherwise: straight into the zeroed output with atomics
+
+    const bool valid = (uint32_t)tid < nt;
+    const uint32_t gi = tid & 31, gstart = tid - gi;
+    const uint32_t g = valid ? i0 + tid : i0;
+    const uint32_t bits = valid ? A.tbits[g] : 0;
+    uint32_t incl = bits;  // inclusive prefix inside the 32-record group
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d);
+        if ((int)gi >= d) incl += o;
+    }
+    if (valid) {
+        const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
+        const uint32_t gconst = A.gflags[grp];
+        TLaneWriter w;
+        w.init(t_lds ? s_stage : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
+        if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
+        const uint32_t ls = A.ls[g];
+        if (ncf <= NCF_CAP) {
+            CachedTitle C;
+#pragma unroll
+            for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+                C.cur[kf] = C.prev[kf] = 0;
+                if (kf >= ncf) continue;
+                C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + g];
+                if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + g - 1];
+            }
+            title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
+        } else {
+            title_record_emit(A.buf, A, s, s_fd, nf, gi == 0, gi ? A.ls[g - 1] : ls, ls, gconst, w);
+        }
+        w.finish();
+    }
+    __syncthreads();
+    if (t_lds) {
+        for (uint32_t k = tid; k < tnw; k += TT_THREADS) {
+            const uint64_t w = tw0 + k;
+            const uint32_t x = s_stage[k];
+            if ((w << 5) >= tb0 && ((w + 1) << 5) <= tb1) outw[w] = x;   // complete word of this tile's range
+            else if (x) atomicOr(&outw[w], x);                           // shared with the neighbours
+        }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+void launch_rec0_fields(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_rec0_fields, dim3((A.n_sb + 63) / 64), dim3(64), 0, st, A);
+}
+
+void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TT_THREADS - 2) / (TT_THREADS - 1), A.n_sb);
+    hipLaunchKernelGGL(k_title_stats_reg, grid, dim3(TT_THREADS), 0, st, A);
+}
+
+void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TT_THREADS - 1) / TT_THREADS, A.n_sb);
+    hipLaunchKernelGGL(k_title_measure_reg, grid, dim3(TT_THREADS), 0, st, A);
+}
+
+void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TT_THREADS - 1) / TT_THREADS, A.n_sb);
+    hipLaunchKernelGGL(k_title_pack_reg, grid, dim3(TT_THREADS), 0, st, A);
+}
+
+}  // namespace ngsc

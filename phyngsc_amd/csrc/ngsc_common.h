@@ -33,6 +33,7 @@ constexpr uint32_t MAX_FIELDS = 32;         // separators per title
 constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant text field (Hamming mask bits)
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
 constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
+constexpr uint32_t REC0_TITLE_CAP = 512;      // longest first-record title the title kernels keep in LDS
 constexpr uint32_t NUM_CAND_CAP = 8;        // numeric candidate fields whose deltas the tiled statistics track
 
 constexpr uint32_t BLOB_SLOT_256 = 336;     // >= 9 + ceil((256*9 + 255)/8) = 329
@@ -216,6 +217,16 @@ struct SbState {        // per sub-block scalars
     uint8_t qua_code[256];
 };
 
+// Field table of a sub-block's first record (phyNGSC.cpp:342-379): every other title is compared with it.
+struct Rec0Tab {
+    uint32_t nf0, ncand;
+    uint16_t start[MAX_FIELDS], len[MAX_FIELDS];  // field start (offset in the title) and length
+    uint8_t kmap[MAX_FIELDS];                     // numeric candidate index, 0xff = not numeric, 0xfe = untracked
+    uint8_t cand_f[NUM_CAND_CAP];                 // candidate index -> field
+    uint8_t title[REC0_TITLE_CAP];
+};
+static_assert(sizeof(Rec0Tab) % 4 == 0, "Rec0Tab is copied word-wise");
+
 // Everything a kernel needs to find a sub-block's working memory.
 struct Arena {
     // job-wide
@@ -239,6 +250,7 @@ struct Arena {
     SbState *sb;
     FieldStat *fstat;       // [S][MAX_FIELDS]
     FieldDesc *fdesc;       // [S][MAX_FIELDS]
+    Rec0Tab *rec0;          // [S]
     uint32_t *dna_occ;      // [S][256]
     uint32_t *qhist;        // [S][qrows][256]  row 0 = totals, row k+1 = position k
     uint32_t *nhist;        // [S][MAX_FIELDS][512]

@@ -40,12 +40,17 @@ void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_title_pack(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 
-// ---- kernels_tile.hip (LDS-tiled fast path) ----
+// ---- kernels_title.hip (register-resident title path) ----
+void launch_rec0_fields(hipStream_t st, const Arena &A);
+void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+
+// ---- kernels_tile.hip (LDS-tiled sequence / quality path) ----
 uint32_t tile_records_for(uint32_t max_rec_bytes, uint32_t r_max);
-void launch_title_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
 void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
-void launch_measure_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
+void launch_measure_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
 void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R);
-void launch_pack_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
+void launch_pack_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
 
 }  // namespace ngsc
