@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t rec_sum(uint32_t v, uint32_t T)
 constexpr uint32_t HCOLS = 64, HSTRIDE = 65;
 
 __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uint32_t R, uint32_t tile_bytes,
-                                                                    uint32_t lds_rows)
+                                                                    uint32_t lds_rows, uint32_t tpw)
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // [tile_bytes] tile, then [lds_rows][HSTRIDE] histogram
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
-    const uint32_t t0 = blockIdx.x * R;
-    if (t0 >= n) return;
-    const uint32_t nt = t0 + R < n ? R : n - t0;
-    const uint32_t i0 = rec_lo + t0;
+    const uint32_t ntiles = (n + R - 1) / R;
+    const uint32_t tile_first = blockIdx.x * tpw;   // this workgroup walks tiles [tile_first, tile_last)
+    if (tile_first >= ntiles) return;
+    const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
     const uint32_t T = TL_THREADS / R;
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
@@ -184,6 +184,13 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     s_occ[tid] = 0;
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
     if (tid < 3) s_red[tid] = 0;
+    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
+    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
+    for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
+    const uint32_t t0 = tile * R;
+    const uint32_t nt = t0 + R < n ? R : n - t0;
+    const uint32_t i0 = rec_lo + t0;
+    __syncthreads();   // everyone is done with the previous tile
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
     const Slice S = make_slice(A, i0, nt, T, b0);
@@ -236,8 +243,6 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
     }
     // pass 2: histograms.  Lanes start at different positions of their slice (rotation) so that
     // neighbouring lanes update different histogram rows at the same time.
-    uint32_t cA = 0, cC = 0, cG = 0, cT = 0;
-    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     {
         const uint32_t rot = len ? (uint32_t)lane % len : 0;
         const bool wave_xfer = __any(xfer);
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
             cA += cnt4 & 0xffu; cC += (cnt4 >> 8) & 0xffu; cT += (cnt4 >> 16) & 0xffu; cG += cnt4 >> 24;
         }
     }
+    }  // tiles
     cA = wsum(cA); cC = wsum(cC); cG = wsum(cG); cT = wsum(cT);
     if (lane == 0) {
         atomicAdd(&s_occ['A'], cA); atomicAdd(&s_occ['C'], cC); atomicAdd(&s_occ['G'], cG); atomicAdd(&s_occ['T'], cT);
@@ -343,7 +349,8 @@ __device__ __forceinline__ uint32_t g32_sum(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(TL_THREADS) void k_measure_sq_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries)
+__global__ __launch_bounds__(TL_THREADS) void k_measure_sq_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries,
+                                                                uint32_t tpw)
 {
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_dyn[];  // tile, then quality code table
@@ -353,16 +360,21 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_sq_tile(Arena A, uint32_
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
-    const uint32_t t0 = blockIdx.x * R;
-    if (t0 >= n) return;
-    const uint32_t nt = t0 + R < n ? R : n - t0;
-    const uint32_t i0 = rec_lo + t0;
+    const uint32_t ntiles = (n + R - 1) / R;
+    const uint32_t tile_first = blockIdx.x * tpw;   // this workgroup walks tiles [tile_first, tile_last)
+    if (tile_first >= ntiles) return;
+    const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
     const uint32_t T = TL_THREADS / R;
     const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
 
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
+    for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
+    const uint32_t t0 = tile * R;
+    const uint32_t nt = t0 + R < n ? R : n - t0;
+    const uint32_t i0 = rec_lo + t0;
+    __syncthreads();   // everyone is done with the previous tile
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
 
@@ -403,12 +415,13 @@ __global__ __launch_bounds__(TL_THREADS) void k_measure_sq_tile(Arena A, uint32_
             }
         }
     }
-    const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
+    const size_t tix = (size_t)A.tile_lo[s] + tile;
     A.ubits[tix * TL_THREADS + tid] = qb | (db << 16);
     uint32_t tq, td;
     (void)wg_scan_excl256(qb, s_part, &tq);
     (void)wg_scan_excl256(db, s_part, &td);
     if (tid == 0) { A.wq[tix] = tq; A.wd[tix] = td; }
+    }  // tiles
 }
 
 // ====================================================================================================
@@ -507,7 +520,7 @@ __device__ __forceinline__ void copy_out_words(uint32_t *outw, const uint32_t *s
 }
 
 __global__ __launch_bounds__(TL_THREADS) void k_pack_sq_tile(Arena A, uint32_t R, uint32_t tile_bytes, uint32_t lds_entries,
-                                                             uint32_t sw_q, uint32_t sw_d)
+                                                             uint32_t sw_q, uint32_t sw_d, uint32_t tpw)
 {
     if (*A.err) return;
     // dynamic LDS: tile | quality code table | staging areas (quality sw_q, DNA sw_d words)
@@ -518,26 +531,31 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_sq_tile(Arena A, uint32_t R
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
-    const uint32_t t0 = blockIdx.x * R;
-    if (t0 >= n) return;
-    const uint32_t nt = t0 + R < n ? R : n - t0;
-    const uint32_t i0 = rec_lo + t0;
+    const uint32_t ntiles = (n + R - 1) / R;
+    const uint32_t tile_first = blockIdx.x * tpw;   // this workgroup walks tiles [tile_first, tile_last)
+    if (tile_first >= ntiles) return;
+    const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
     const uint32_t T = TL_THREADS / R;
-    const bool last_tile = t0 + R >= n;
     const int tid = threadIdx.x;
     uint32_t *s_qtab = reinterpret_cast<uint32_t *>(s_dyn + tile_bytes);
     uint32_t *s_stage = s_qtab + lds_entries;
     uint32_t *st_q = s_stage, *st_d = s_stage + sw_q;
 
-    for (uint32_t k = tid; k < sw_q + sw_d; k += TL_THREADS) s_stage[k] = 0;
     SqLut Lt;
     load_luts(A, s, sb, s_qtab, lds_entries, s_dcode, s_qcode, s_amb, Lt);
+    for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
+    const uint32_t t0 = tile * R;
+    const uint32_t nt = t0 + R < n ? R : n - t0;
+    const uint32_t i0 = rec_lo + t0;
+    __syncthreads();   // everyone is done with the previous tile
+    const bool last_tile = t0 + R >= n;
+    for (uint32_t k = tid; k < sw_q + sw_d; k += TL_THREADS) s_stage[k] = 0;
     const uint32_t b0 = load_tile(A, i0, i0 + nt, s_dyn);
     const uint8_t *tb = s_dyn;
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
 
     // absolute bit ranges of this tile's share of the two payload streams
-    const size_t tix = (size_t)A.tile_lo[s] + blockIdx.x;
+    const size_t tix = (size_t)A.tile_lo[s] + tile;
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
     const uint64_t qb0 = qbase + A.wq[tix], qb1 = qbase + (last_tile ? sb.qbits : A.wq[tix + 1]);
@@ -594,6 +612,7 @@ __global__ __launch_bounds__(TL_THREADS) void k_pack_sq_tile(Arena A, uint32_t R
     __syncthreads();
     if (q_lds) copy_out_words(outw, st_q, qw0, qnw, qb0, qb1);
     if (d_lds) copy_out_words(outw, st_d, dw0, dnw, db0, db1);
+    }  // tiles
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
@@ -614,6 +633,13 @@ uint32_t tile_records_for(uint32_t max_rec_bytes, uint32_t r_max)
     return 0;
 }
 
+// Tiles walked by one workgroup (amortises the code table loads and the histogram flush).
+static uint32_t tiles_per_wg()
+{
+    static const uint32_t v = getenv("NGSC_TILES_PER_WG") ? (uint32_t)atoi(getenv("NGSC_TILES_PER_WG")) : 4;
+    return v ? v : 1;
+}
+
 static uint32_t tile_bytes_for(uint32_t R, uint32_t max_rec_bytes) { return ((R * max_rec_bytes + 32 + 15) & ~15u); }
 
 static uint32_t qtab_entries_for(uint32_t qrows)
@@ -628,18 +654,20 @@ void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec
     uint32_t rows = A.qrows;
     uint32_t max_rows = (96u << 10) > tbytes ? ((96u << 10) - tbytes) / (HSTRIDE * 4) : 0;
     if (rows > max_rows) rows = max_rows;
-    dim3 grid((max_rec + R - 1) / R, A.n_sb);
+    const uint32_t tpw = tiles_per_wg();
+    dim3 grid(((max_rec + R - 1) / R + tpw - 1) / tpw, A.n_sb);
     size_t lds = tbytes + (size_t)rows * HSTRIDE * 4;
     allow_big_lds(k_seq_qual_stats_tile);
-    hipLaunchKernelGGL(k_seq_qual_stats_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, rows);
+    hipLaunchKernelGGL(k_seq_qual_stats_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, rows, tpw);
 }
 
 void launch_measure_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes)
 {
     uint32_t tbytes = tile_bytes_for(R, max_rec_bytes), le = qtab_entries_for(A.qrows);
-    dim3 grid((max_rec + R - 1) / R, A.n_sb);
+    const uint32_t tpw = tiles_per_wg();
+    dim3 grid(((max_rec + R - 1) / R + tpw - 1) / tpw, A.n_sb);
     allow_big_lds(k_measure_sq_tile);
-    hipLaunchKernelGGL(k_measure_sq_tile, grid, dim3(TL_THREADS), tbytes + (size_t)le * 4, st, A, R, tbytes, le);
+    hipLaunchKernelGGL(k_measure_sq_tile, grid, dim3(TL_THREADS), tbytes + (size_t)le * 4, st, A, R, tbytes, le, tpw);
 }
 
 void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
@@ -657,10 +685,11 @@ void launch_pack_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     uint32_t sw_d = (uint32_t)(((uint64_t)R * maxq * 3) / 32) + 64;
     if (sw_q > 4096) sw_q = 4096;
     if (sw_d > 3072) sw_d = 3072;
-    dim3 grid((max_rec + R - 1) / R, A.n_sb);
+    const uint32_t tpw = tiles_per_wg();
+    dim3 grid(((max_rec + R - 1) / R + tpw - 1) / tpw, A.n_sb);
     size_t lds = tbytes + (size_t)le * 4 + ((size_t)sw_q + sw_d) * 4;
     allow_big_lds(k_pack_sq_tile);
-    hipLaunchKernelGGL(k_pack_sq_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, le, sw_q, sw_d);
+    hipLaunchKernelGGL(k_pack_sq_tile, grid, dim3(TL_THREADS), lds, st, A, R, tbytes, le, sw_q, sw_d, tpw);
 }
 
 }  // namespace ngsc

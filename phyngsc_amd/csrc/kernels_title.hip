@@ -15,7 +15,6 @@
 namespace ngsc {
 
 constexpr int TT_THREADS = 256;
-constexpr int TT_WAVES = TT_THREADS / 64;
 
 __device__ __forceinline__ uint32_t t_wmax(uint32_t v)
 {
