@@ -11,7 +11,9 @@ namespace ngsc {
 
 constexpr int TILE_THREADS = 256;
 constexpr int BYTES_PER_THREAD = 32;
-constexpr uint32_t TILE_BYTES = TILE_THREADS * BYTES_PER_THREAD;  // 8 KiB per workgroup
+constexpr uint32_t PIECE_BYTES = TILE_THREADS * BYTES_PER_THREAD;  // 8 KiB per coalesced piece
+constexpr uint32_t PIECES = 4;                                     // pieces per workgroup
+constexpr uint32_t TILE_BYTES = PIECE_BYTES * PIECES;              // 32 KiB per workgroup: 4x fewer counts to scan
 
 // exact per-byte "== 0" flags (bit 7 of each byte) of a 32-bit word
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t y)
@@ -72,9 +74,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
 {
     __shared__ uint32_t s_part[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
-    const uint32_t base = blockIdx.x * TILE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-    uint32_t flags[8];
-    uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t pc = 0; pc < PIECES; ++pc) {
+        const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
+        uint32_t flags[8];
+        c += (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+    }
     c = wave_reduce_add(c);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *tile_cnt, uint32_
     const uint32_t lo = threadIdx.x * per;
     const uint32_t hi = lo + per < n ? lo + per : n;
     uint32_t sum = 0;
+#pragma unroll 8
     for (uint32_t i = lo; i < hi; ++i) sum += tile_cnt[i];
     uint32_t incl = wave_scan_incl(sum);
     if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
@@ -116,31 +123,41 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
 {
     __shared__ uint32_t s_wave[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
-    const uint32_t base = blockIdx.x * TILE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-    uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
-    uint32_t incl = wave_scan_incl(c);
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wbase += s_wave[w];
-    uint32_t line = tile_off[blockIdx.x] + wbase + incl - c;
     if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = start;
-    if (!c) return;
+    uint32_t line_base = tile_off[blockIdx.x];
+    for (uint32_t pc = 0; pc < PIECES; ++pc) {
+        const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
+        uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+        uint32_t incl = wave_scan_incl(c);
+        __syncthreads();  // s_wave of the previous piece has been consumed
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint32_t f = flags[i];
-        while (f) {
-            uint32_t k = (uint32_t)(__ffs(f) - 1) >> 3;
-            f &= f - 1;
-            uint32_t pos = base + i * 4 + k;
-            uint32_t r = line >> 2, kind = line & 3;
-            if (r < rec_cap) {
-                if (kind == 0) te[r] = pos;
-                else if (kind == 1) se[r] = pos;
-                else if (kind == 3) ls[r + 1] = pos + 1;
+        for (uint32_t w = 0; w < TILE_THREADS / 64; ++w) {
+            if (w < (threadIdx.x >> 6)) wbase += s_wave[w];
+            total += s_wave[w];
+        }
+        uint32_t line = line_base + wbase + incl - c;
+        line_base += total;
+        if (c) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t f = flags[i];
+                while (f) {
+                    uint32_t k = (uint32_t)(__ffs(f) - 1) >> 3;
+                    f &= f - 1;
+                    uint32_t pos = base + i * 4 + k;
+                    uint32_t r = line >> 2, kind = line & 3;
+                    if (r < rec_cap) {
+                        if (kind == 0) te[r] = pos;
+                        else if (kind == 1) se[r] = pos;
+                        else if (kind == 3) ls[r + 1] = pos + 1;
+                    }
+                    ++line;
+                }
             }
-            ++line;
         }
     }
 }
@@ -269,7 +286,8 @@ void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_l
                  const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                  uint32_t max_cuts, RankPlan *plans, int32_t *err)
 {
-    hipLaunchKernelGGL(k_cuts, dim3((n_ranks + 63) / 64), dim3(64), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, ls,
+    // one workgroup per rank so that the ranks' dependent search chains run on different CUs
+    hipLaunchKernelGGL(k_cuts, dim3(n_ranks), dim3(1), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, ls,
                        total_lines, first_abs, cuts, max_cuts, plans, err);
 }
 
