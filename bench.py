@@ -42,14 +42,19 @@ def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
     title_in = raw - 2 * bases - 4 * n_rec   # title lines incl. their newline
     title_out = sum(sb.title_len for sb in res.subblocks)
     sq_out = sum(sb.qual_len + sb.dna_len for sb in res.subblocks)
+    ncf_words = 4 * n_rec * 2   # cached non-constant title fields (about two per record on this workload)
     return {
         "k_nl_count": raw,
         "k_nl_write": raw + 12 * n_rec,
         "k_validate": 12 * n_rec,
-        "k_title_stats": title_in,
+        "k_title_stats_reg": title_in,
+        "k_title_measure_reg": title_in + ncf_words + 4 * n_rec,
+        "k_title_pack_reg": ncf_words + 4 * n_rec + title_out,
         "k_title_hist": title_in,
-        "k_title_measure": title_in,
-        "k_title_pack": title_in + title_out,
+        "k_seq_qual_stats_tile": 2 * bases,
+        "k_measure_sq_tile": 2 * bases + 4 * n_rec,
+        "k_pack_sq_tile": 2 * bases + 4 * n_rec + sq_out,
+        # untiled fallbacks (records longer than the LDS tile budget)
         "k_seq_qual_stats": 2 * bases,
         "k_measure_sq": 2 * bases + 8 * n_rec,
         "k_pack_sq": 2 * bases + sq_out,

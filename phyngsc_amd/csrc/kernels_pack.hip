@@ -105,22 +105,6 @@ __global__ __launch_bounds__(PK_THREADS) void k_measure_sq(Arena A, uint32_t lds
     }
 }
 
-// One thread per group of 32 records: byte size of the group's title bits (tasks.cpp:393-509).
-__global__ __launch_bounds__(64) void k_title_measure(Arena A)
-{
-    if (*A.err) return;
-    const uint32_t s = blockIdx.y;
-    const SbState &sb = A.sb[s];
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ngrp = (sb.n_rec + GROUP - 1) / GROUP;
-    if (k >= ngrp) return;
-    uint32_t g0 = sb.rec_lo + k * GROUP;
-    uint32_t g1 = k * GROUP + GROUP < sb.n_rec ? g0 + GROUP : sb.rec_lo + sb.n_rec;
-    BitCounter bc;
-    title_group(A, s, g0, g1, bc);
-    A.goff[A.grp_lo[s] + k] = (uint32_t)bc.nbytes();
-}
-
 // ---------------------------------------------------------------------------------------------------
 // In-place exclusive scan of a[0..n) by one workgroup of 1024 threads; returns the total (all threads).
 __device__ uint32_t wg_scan_excl(uint32_t *a, uint32_t n, uint32_t *s_wave /*[17]*/)
@@ -265,21 +249,6 @@ __global__ __launch_bounds__(256) void k_pack_lentable(Arena A)
     if (lo == (w << 5) && hi == ((w + 1) << 5)) *outw = be; else if (be) atomicOr(outw, be);
 }
 
-// One thread per group of 32 records writes the group's title bits (byte aligned, exclusive range).
-__global__ __launch_bounds__(64) void k_title_pack(Arena A)
-{
-    if (*A.err) return;
-    const uint32_t s = blockIdx.y;
-    const SbState &sb = A.sb[s];
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ngrp = (sb.n_rec + GROUP - 1) / GROUP;
-    if (k >= ngrp) return;
-    uint32_t g0 = sb.rec_lo + k * GROUP;
-    uint32_t g1 = k * GROUP + GROUP < sb.n_rec ? g0 + GROUP : sb.rec_lo + sb.n_rec;
-    ByteWriter w(A.out + sb.out_off + sb.info_len + sb.title_hdr + A.goff[A.grp_lo[s] + k]);
-    title_group(A, s, g0, g1, w);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Wave-cooperative emit of up to 64 variable-length codes starting at absolute bit `bitpos`.
 // Every lane passes (code, len) with len <= 26 (0 for "nothing").  Returns the number of bits emitted.
@@ -384,12 +353,6 @@ void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(k_measure_sq, grid, dim3(PK_THREADS), le * sizeof(uint32_t), st, A, le);
 }
 
-void launch_title_measure(hipStream_t st, const Arena &A, uint32_t max_rec)
-{
-    uint32_t max_grp = (max_rec + GROUP - 1) / GROUP;
-    hipLaunchKernelGGL(k_title_measure, dim3((max_grp + 63) / 64, A.n_sb), dim3(64), 0, st, A);
-}
-
 void launch_scan_sb(hipStream_t st, const Arena &A)
 {
     hipLaunchKernelGGL(k_scan_sb, dim3(A.n_sb), dim3(1024), 0, st, A);
@@ -410,12 +373,6 @@ void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     uint32_t lt_words = max_rec + 2;  // at most 32 bits per record, plus misalignment
     hipLaunchKernelGGL(k_pack_lentable, dim3((lt_words + 255) / 256, A.n_sb), dim3(256), 0, st, A);
-}
-
-void launch_title_pack(hipStream_t st, const Arena &A, uint32_t max_rec)
-{
-    uint32_t max_grp = (max_rec + GROUP - 1) / GROUP;
-    hipLaunchKernelGGL(k_title_pack, dim3((max_grp + 63) / 64, A.n_sb), dim3(64), 0, st, A);
 }
 
 void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec)

@@ -1,8 +1,7 @@
 // kernels_stats.hip - per-sub-block statistics of the FASTQ compressor (batched over sub-blocks:
-// blockIdx.y = sub-block).
+// blockIdx.y = sub-block).  The title reductions live in kernels_title.hip; k_seq_qual_stats below is the
+// untiled fallback of k_seq_qual_stats_tile for records longer than the LDS tile budget.
 //
-//   k_title_stats      AnalyzeTitleFields reductions (tasks.cpp:22-193): per-field min/max length,
-//                      constant / numeric flags, value and delta ranges, Hamming mask
 //   k_seq_qual_stats   DNA/quality prepass (phyNGSC.cpp:462-653) + AnalyzeQuality (tasks.cpp:260-286):
 //                      N-transfer decision, DNA symbol counts, per-position quality histograms staged
 //                      in LDS (row stride 65 words so the 64 lanes of one record hit distinct banks)
@@ -20,104 +19,6 @@ constexpr int TS_OWNED = TS_THREADS - 1;  // thread 0 of a workgroup re-parses t
 
 __device__ __forceinline__ void lds_max(uint32_t *p, uint32_t v) { if (v > *p) atomicMax(p, v); }
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { if ((*p & v) != v) atomicOr(p, v); }
-
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TS_THREADS) void k_title_stats(Arena A)
-{
-    if (*A.err) return;
-    const uint32_t s = blockIdx.y;
-    const SbState &sb = A.sb[s];
-    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
-    if (blockIdx.x * TS_OWNED >= n) return;
-    const int tid = threadIdx.x;
-    const uint8_t *buf = A.buf;
-
-    __shared__ uint32_t s_val[MAX_FIELDS][TS_THREADS];
-    __shared__ uint32_t s_nummask[TS_THREADS];
-    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
-    __shared__ uint32_t s_nf0;
-
-    for (int k = tid; k < (int)(MAX_FIELDS * 24); k += TS_THREADS) s_stat[k] = 0;
-    if (tid == 0) {
-        uint32_t nf0 = count_fields(buf, A.ls[rec_lo], A.te[rec_lo]);
-        s_nf0 = nf0;
-        if (blockIdx.x == 0) A.sb[s].nf = nf0;
-        if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
-    }
-    __syncthreads();
-    const uint32_t nf0 = s_nf0;
-    if (nf0 > MAX_FIELDS) return;
-
-    const int64_t i = (int64_t)blockIdx.x * TS_OWNED + tid - 1;  // record index inside the sub-block
-    const bool valid = i >= 0 && i < (int64_t)n;
-    const bool owned = valid && tid >= 1;
-    uint32_t nummask = 0;
-    if (valid) {
-        const uint32_t g = rec_lo + (uint32_t)i;
-        uint32_t pc = A.ls[g], p0 = A.ls[rec_lo];
-        const uint32_t tec = A.te[g];
-        uint32_t nfields = 0;
-        while (pc <= tec) {
-            uint32_t ec = field_end(buf, pc);
-            if (nfields < nf0) {
-                const uint32_t f = nfields;
-                uint32_t e0 = field_end(buf, p0);
-                uint32_t len = ec - pc, len0 = e0 - p0;
-                uint32_t v = 0;
-                bool ovf = false;
-                bool isnum = parse_num(buf, pc, ec, v, ovf);
-                s_val[f][tid] = v;
-                nummask |= (uint32_t)isnum << f;
-                if (owned) {
-                    uint32_t *st = s_stat + f * 24;
-                    lds_max(st + 0, len);
-                    lds_max(st + 1, ~len);
-                    uint32_t m = len < len0 ? len : len0;
-                    bool diff = false;
-                    for (uint32_t p = 0; p < m; ++p) {
-                        if (buf[pc + p] != buf[p0 + p]) {
-                            diff = true;
-                            if (p < 256) lds_or(st + 10 + (p >> 5), 1u << (p & 31));
-                        }
-                    }
-                    if (len != len0) { lds_max(st + 3, 1); lds_max(st + 2, 1); }
-                    else if (diff) lds_max(st + 2, 1);
-                    if (!isnum) lds_max(st + 4, 1);
-                    else {
-                        if (ovf) lds_max(st + 5, 1);
-                        lds_max(st + 6, bias((int32_t)v));
-                        lds_max(st + 7, ~bias((int32_t)v));
-                    }
-                }
-                p0 = e0 + 1;
-            }
-            ++nfields;
-            pc = ec + 1;
-        }
-        if (nfields != nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
-    }
-    s_nummask[tid] = nummask;
-    __syncthreads();
-    if (owned && i >= 1) {
-        uint32_t both = nummask & s_nummask[tid - 1];
-        for (uint32_t f = 0; f < nf0; ++f) {
-            if ((both >> f) & 1) {
-                int32_t d = (int32_t)(s_val[f][tid] - s_val[f][tid - 1]);  // tasks.cpp:149-166
-                lds_max(s_stat + f * 24 + 8, bias(d));
-                lds_max(s_stat + f * 24 + 9, ~bias(d));
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
-    for (uint32_t k = tid; k < nf0 * 24; k += TS_THREADS) {
-        uint32_t v = s_stat[k];
-        if (!v) continue;
-        uint32_t w = k % 24;
-        if (w >= 10 && w < 18) atomicOr(gst + k, v);
-        else if (w < 10) atomicMax(gst + k, v);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 constexpr int SQ_THREADS = 256;
@@ -412,12 +313,6 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A)
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-void launch_title_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
-{
-    dim3 grid((max_rec + TS_OWNED - 1) / TS_OWNED, A.n_sb);
-    hipLaunchKernelGGL(k_title_stats, grid, dim3(TS_THREADS), 0, st, A);
-}
-
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     uint32_t rows = A.qrows < HIST_MAX_ROWS ? A.qrows : HIST_MAX_ROWS;

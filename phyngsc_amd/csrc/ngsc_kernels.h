@@ -20,7 +20,6 @@ void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_l
                  uint32_t max_cuts, RankPlan *plans, int32_t *err);
 
 // ---- kernels_stats.hip ----
-void launch_title_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_finalize(hipStream_t st, const Arena &A);
 void launch_field_finalize(hipStream_t st, const Arena &A);
@@ -32,12 +31,10 @@ void launch_huffman_text(hipStream_t st, const Arena &A);
 
 // ---- kernels_pack.hip ----
 void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
-void launch_title_measure(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_scan_sb(hipStream_t st, const Arena &A);
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out);
 void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off);
 void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec);
-void launch_title_pack(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 
 // ---- kernels_title.hip (register-resident title path) ----

@@ -105,6 +105,38 @@ def test_against_oracle(eng, name, cfg, size, P):
     assert out == want
 
 
+PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "title_numeric.p3", "title_long.p2",
+              "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
+
+
+@pytest.mark.parametrize("tile_records", ["1", "64", "128", "256"])
+def test_kernel_paths_agree(eng, monkeypatch, tile_records):
+    """The sequence/quality kernels exist in an LDS-tiled form (64/128/256 records per tile, 4/2/1 threads
+    per record) and an untiled wave-per-record form (NGSC_TILE_RECORDS=1: no tile size allowed): every form
+    must reproduce the reference."""
+    monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
+    for name in PATH_CASES:
+        stem, P = name.rsplit(".p", 1)
+        with open(os.path.join(GOLDEN, "small", stem + ".fastq"), "rb") as f:
+            data = f.read()
+        with open(os.path.join(GOLDEN, "small", name + ".ngsc"), "rb") as f:
+            ref = f.read()
+        _, out = _gpu(eng, data, int(P))
+        ok, msg = nf.equivalent(ref, out)
+        assert ok, f"{name} (tile_records={tile_records}): {msg}"
+
+
+def test_long_records_take_the_untiled_path(eng):
+    """300-400 bp reads: records of ~850 B do not fit the LDS tile budget (and exceed the reference's
+    500-byte overlap, where it reads past its buffer - Q7 - so the oracle, which sees the real bytes, is
+    the comparison)."""
+    cfg = fastq_gen.GenConfig(seed=31, style=1, len_min=300, len_max=400, qual_model=2, n_rate_ppm=2000, n_lowq_pct=70)
+    data = fastq_gen.generate(cfg, target_bytes=40_000_000)
+    _, out = _gpu(eng, data, 4)
+    want, _ = orc.compress_file(data, 4, threads=4)
+    assert out == want
+
+
 def test_rank_split_invariance_and_repeatability(eng):
     """Compressing ranks [0,4) and [4,8) in separate calls (as two processes would) gives the same
     sub-block bytes as one whole-file call; a second identical call gives identical bytes."""
