@@ -99,6 +99,7 @@ const char *ngsc_strerror(int code);
 int ngsc_ctx_create(int device_id, ngsc_ctx **out);
 void ngsc_ctx_destroy(ngsc_ctx *ctx);
 const char *ngsc_last_hip_error(ngsc_ctx *ctx);
+int ngsc_ctx_device(ngsc_ctx *ctx); /* the HIP device the context was created on */
 
 /* Per-kernel device timing (hipEvent pairs around every launch). Off by default. */
 int ngsc_set_profiling(ngsc_ctx *ctx, int enable);
@@ -137,9 +138,21 @@ uint32_t ngsc_make_footer(uint8_t *out, uint32_t P, uint64_t fastq_size, uint32_
 /*
  * `<in.fastq> <out.ngsc>` (phyNGSC.cpp:61-108) with P virtual ranks on this context's GPU: reads the
  * file, uploads it, compresses, assembles blocks in the deterministic order "round k = k-th block of
- * every rank" and writes blocks + footer.  seconds_out (nullable, 3 doubles): read+H2D, device, D2H+write.
+ * every rank" and writes blocks + footer.  seconds_out (nullable, 3 doubles): read, H2D+device+D2H, plan+write.
  */
 int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out);
+
+/*
+ * The same job spread over n_ctx contexts (normally one per GPU of the node) from ONE process: the
+ * P virtual ranks are dealt to the contexts in contiguous runs of P / n_ctx (P % n_ctx == 0), each
+ * context's ranks run on its own host thread and device, and the blocks are assembled as above --
+ * so the file is byte-identical for every n_ctx.  This replaces the reference's `mpiexec -np P`
+ * fan-out (phyNGSC.cpp:45-57, 113-116) when one host drives several GPUs; there is no device-to-
+ * device traffic, only the per-rank block lists meet on the host (phyNGSC.cpp:875-1057).
+ * Every context's byte range (file_size / n_ctx + slack) must stay below 4 GiB.
+ */
+int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
+                             double *seconds_out);
 
 #ifdef __cplusplus
 }

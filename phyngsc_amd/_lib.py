@@ -17,6 +17,7 @@ EXPORTS = [
     "ngsc_set_profiling", "ngsc_reset_kernel_times", "ngsc_get_kernel_times", "ngsc_compress_device",
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
+    "ngsc_compress_file_multi", "ngsc_ctx_device",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -103,5 +104,10 @@ def lib():
                                    ctypes.POINTER(u32)]
     L.ngsc_compress_file.restype = ctypes.c_int
     L.ngsc_compress_file.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, u32, ctypes.POINTER(ctypes.c_double)]
+    L.ngsc_compress_file_multi.restype = ctypes.c_int
+    L.ngsc_compress_file_multi.argtypes = [ctypes.POINTER(vp), u32, ctypes.c_char_p, ctypes.c_char_p, u32,
+                                           ctypes.POINTER(ctypes.c_double)]
+    L.ngsc_ctx_device.restype = ctypes.c_int
+    L.ngsc_ctx_device.argtypes = [vp]
     _lib = L
     return L

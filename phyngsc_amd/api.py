@@ -111,12 +111,24 @@ class Engine:
         return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
 
     def compress_file(self, in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
-        """``<in.fastq> <out.ngsc>`` on this GPU; returns (read+H2D, device, D2H+write) seconds."""
+        """``<in.fastq> <out.ngsc>`` on this GPU; returns (read, H2D+device+D2H, plan+write) seconds."""
         sec = (ctypes.c_double * 3)()
         rc = self._L.ngsc_compress_file(self._h, in_path.encode(), out_path.encode(), P, sec)
         if rc:
             raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
         return sec[0], sec[1], sec[2]
+
+
+def compress_file_multi(engines: Sequence["Engine"], in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
+    """One process, several contexts (one per GPU): ranks are dealt in runs of P/len(engines); the file is
+    byte-identical to the single-context one (ngsc.h: ngsc_compress_file_multi)."""
+    L = _lib.lib()
+    hs = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    sec = (ctypes.c_double * 3)()
+    rc = L.ngsc_compress_file_multi(hs, len(engines), in_path.encode(), out_path.encode(), P, sec)
+    if rc:
+        raise NgscError(rc, "; ".join(L.ngsc_last_hip_error(e._h).decode() for e in engines))
+    return sec[0], sec[1], sec[2]
 
 
 def _copy_struct(s):

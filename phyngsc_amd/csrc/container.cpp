@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
@@ -152,18 +153,62 @@ static bool write_all(int fd, const void *p, size_t n)
     return true;
 }
 
-int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out)
+// One worker = one context (= one GPU): uploads the byte range of its virtual ranks, compresses them and
+// brings the sub-block streams back.  Workers share nothing but the read-only input.
+struct Worker {
+    ngsc_ctx *ctx = nullptr;
+    uint32_t rank_lo = 0, rank_hi = 0;
+    int rc = NGSC_OK;
+    std::vector<uint8_t> host;              // this worker's sub-block bytes
+    std::vector<ngsc_rank_t> ranks;
+    std::vector<uint32_t> sb_sizes;         // per sub-block, in result order
+    std::vector<uint32_t> sb_first;         // per local rank: first index into sb_sizes
+};
+
+static void run_worker(Worker *w, const uint8_t *h_in, uint64_t FS, uint32_t P)
 {
-    if (!ctx || !in_path || !out_path || P < 2) return NGSC_ERR_ARG;
+    if (hipSetDevice(ngsc_ctx_device(w->ctx)) != hipSuccess) { w->rc = NGSC_ERR_HIP; return; }
+    // byte range of the ranks (phyNGSC.cpp:113-116) + slack for the record that straddles the end
+    const RankGeom g0 = rank_geometry(FS, P, w->rank_lo), g1 = rank_geometry(FS, P, w->rank_hi - 1);
+    const uint64_t lo = (uint64_t)g0.wr_start & ~15ull;
+    const uint64_t hi = std::min<uint64_t>(FS, (uint64_t)g1.wr_end + 1 + 65536);
+    const uint64_t len = hi - lo;
+    if (len >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; return; }  // one job < 4 GiB: use more GPUs / ranks
+    void *d_in = nullptr, *d_out = nullptr;
+    const uint64_t out_cap = len + (len >> 2) + (64u << 20);
+    if (hipMalloc(&d_in, len + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess) w->rc = NGSC_ERR_HIP;
+    if (!w->rc && hipMemcpy(d_in, h_in + lo, len, hipMemcpyHostToDevice) != hipSuccess) w->rc = NGSC_ERR_HIP;
+    if (!w->rc) w->rc = ngsc_compress_device(w->ctx, d_in, len, lo, FS, P, w->rank_lo, w->rank_hi, d_out, out_cap, nullptr);
+    if (!w->rc) {
+        const uint64_t total = ngsc_result_bytes(w->ctx);
+        w->host.resize(total);
+        if (total && hipMemcpy(w->host.data(), d_out, total, hipMemcpyDeviceToHost) != hipSuccess) w->rc = NGSC_ERR_HIP;
+        const ngsc_subblock_t *sbs = ngsc_result_subblocks(w->ctx);
+        const ngsc_rank_t *rks = ngsc_result_ranks(w->ctx);
+        const uint32_t nr = ngsc_result_num_ranks(w->ctx), ns = ngsc_result_num_subblocks(w->ctx);
+        w->ranks.assign(rks, rks + nr);
+        w->sb_sizes.resize(ns);
+        for (uint32_t k = 0; k < ns; ++k) w->sb_sizes[k] = sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len;
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+}
+
+int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
+                             double *seconds_out)
+{
+    if (!ctxs || !n_ctx || !in_path || !out_path || P < 2 || P % n_ctx) return NGSC_ERR_ARG;
+    for (uint32_t i = 0; i < n_ctx; ++i)
+        if (!ctxs[i]) return NGSC_ERR_ARG;
     double t0 = now_s();
     int fd = ::open(in_path, O_RDONLY);
     if (fd < 0) return NGSC_ERR_IO;
     struct stat sbuf;
     if (fstat(fd, &sbuf) != 0 || sbuf.st_size <= 0) { ::close(fd); return NGSC_ERR_IO; }
     const uint64_t FS = (uint64_t)sbuf.st_size;
-    if (FS >= 0xFFFFFF00ull) { ::close(fd); return NGSC_ERR_UNSUPPORTED; }  // one job per call: < 4 GiB
     void *h_in = nullptr;
-    if (hipHostMalloc(&h_in, FS + 64, hipHostMallocDefault) != hipSuccess) { ::close(fd); return NGSC_ERR_HIP; }
+    if (hipSetDevice(ngsc_ctx_device(ctxs[0])) != hipSuccess ||
+        hipHostMalloc(&h_in, FS + 64, hipHostMallocPortable) != hipSuccess) { ::close(fd); return NGSC_ERR_HIP; }
     uint64_t got = 0;
     while (got < FS) {
         ssize_t r = ::read(fd, (uint8_t *)h_in + got, (size_t)std::min<uint64_t>(FS - got, 1u << 30));
@@ -172,47 +217,44 @@ int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path,
     }
     ::close(fd);
     if (got != FS) { (void)hipHostFree(h_in); return NGSC_ERR_IO; }
-    void *d_in = nullptr, *d_out = nullptr;
-    uint64_t out_cap = FS + (FS >> 2) + (64u << 20);
-    int rc = NGSC_OK;
-    if (hipMalloc(&d_in, FS + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess) rc = NGSC_ERR_HIP;
-    if (!rc && hipMemcpy(d_in, h_in, FS, hipMemcpyHostToDevice) != hipSuccess) rc = NGSC_ERR_HIP;
-    (void)hipHostFree(h_in);
     double t1 = now_s();
-    if (!rc) rc = ngsc_compress_device(ctx, d_in, FS, 0, FS, P, 0, P, d_out, out_cap, nullptr);
-    double t2 = now_s();
-    std::vector<uint8_t> host;
-    if (!rc) {
-        uint64_t total = ngsc_result_bytes(ctx);
-        host.resize(total);
-        if (total && hipMemcpy(host.data(), d_out, total, hipMemcpyDeviceToHost) != hipSuccess) rc = NGSC_ERR_HIP;
-    }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-    if (rc) return rc;
 
-    const ngsc_subblock_t *sbs = ngsc_result_subblocks(ctx);
-    const ngsc_rank_t *rks = ngsc_result_ranks(ctx);
+    // virtual ranks are dealt to the contexts in contiguous runs (P is a multiple of the context count)
+    std::vector<Worker> workers(n_ctx);
+    const uint32_t per = P / n_ctx;
+    for (uint32_t i = 0; i < n_ctx; ++i) { workers[i].ctx = ctxs[i]; workers[i].rank_lo = i * per; workers[i].rank_hi = (i + 1) * per; }
+    if (n_ctx == 1) run_worker(&workers[0], (const uint8_t *)h_in, FS, P);
+    else {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], (const uint8_t *)h_in, FS, P);
+        for (auto &t : th) t.join();
+    }
+    (void)hipHostFree(h_in);
+    double t2 = now_s();
+    for (auto &w : workers)
+        if (w.rc) return w.rc;
+
+    // container: blocks of every rank, deterministic order, footer (phyNGSC.cpp:842-1057)
     std::vector<std::vector<ngsc_block_t>> rb(P);
     std::vector<int32_t> ov(P);
     std::vector<uint32_t> lbs(P);
+    std::vector<const uint8_t *> stream(P);
     uint32_t n_sub_total = 0, max_blocks = 0, n_blocks_total = 0;
-    for (uint32_t r = 0; r < P; ++r) {
-        std::vector<uint32_t> sizes(rks[r].n_subblocks);
-        for (uint32_t k = 0; k < rks[r].n_subblocks; ++k) {
-            const ngsc_subblock_t &s = sbs[rks[r].first_subblock + k];
-            sizes[k] = s.info_len + s.title_len + s.qual_len + s.dna_len;
+    for (auto &w : workers) {
+        for (const ngsc_rank_t &rk : w.ranks) {
+            const uint32_t r = rk.rank;
+            uint32_t capb = (uint32_t)(rk.stream_bytes / (NGSC_BLOCK_SIZE - 4096)) + 4, nb = 0;
+            rb[r].resize(capb);
+            int rc = ngsc_plan_blocks(P, r, w.sb_sizes.data() + rk.first_subblock, rk.n_subblocks, rb[r].data(), capb, &nb);
+            if (rc) return rc;
+            rb[r].resize(nb);
+            ov[r] = rk.overlap_used;
+            lbs[r] = nb ? rb[r][nb - 1].size : 0;
+            stream[r] = w.host.data() + rk.stream_off;
+            n_sub_total += rk.n_subblocks;
+            n_blocks_total += nb;
+            max_blocks = std::max(max_blocks, nb);
         }
-        uint32_t capb = (uint32_t)(rks[r].stream_bytes / (NGSC_BLOCK_SIZE - 4096)) + 4, nb = 0;
-        rb[r].resize(capb);
-        rc = ngsc_plan_blocks(P, r, sizes.data(), (uint32_t)sizes.size(), rb[r].data(), capb, &nb);
-        if (rc) return rc;
-        rb[r].resize(nb);
-        ov[r] = rks[r].overlap_used;
-        lbs[r] = nb ? rb[r][nb - 1].size : 0;
-        n_sub_total += rks[r].n_subblocks;
-        n_blocks_total += nb;
-        max_blocks = std::max(max_blocks, nb);
     }
     int ofd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (ofd < 0) return NGSC_ERR_IO;
@@ -222,8 +264,7 @@ int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path,
         for (uint32_t r = 0; r < P && okw; ++r)
             if (k < rb[r].size()) {
                 const ngsc_block_t &b = rb[r][k];
-                okw = write_all(ofd, b.header, b.header_len) &&
-                      write_all(ofd, host.data() + rks[r].stream_off + b.stream_off, b.payload);
+                okw = write_all(ofd, b.header, b.header_len) && write_all(ofd, stream[r] + b.stream_off, b.payload);
                 cbo.push_back(r);
             }
     std::vector<uint8_t> footer(256 + 4 * (size_t)n_blocks_total + 8 * (size_t)P);
@@ -233,6 +274,11 @@ int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path,
     double t3 = now_s();
     if (seconds_out) { seconds_out[0] = t1 - t0; seconds_out[1] = t2 - t1; seconds_out[2] = t3 - t2; }
     return okw ? NGSC_OK : NGSC_ERR_IO;
+}
+
+int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out)
+{
+    return ngsc_compress_file_multi(&ctx, 1, in_path, out_path, P, seconds_out);
 }
 
 }  // extern "C"

@@ -204,6 +204,8 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
 
 const char *ngsc_last_hip_error(ngsc_ctx *c) { return c ? c->hip_err.c_str() : ""; }
 
+int ngsc_ctx_device(ngsc_ctx *c) { return c ? c->device : -1; }
+
 int ngsc_set_profiling(ngsc_ctx *c, int enable)
 {
     if (!c) return NGSC_ERR_ARG;

@@ -1,23 +1,34 @@
-// ngsc - command line front end: `ngsc <in.fastq> <out.ngsc> [threads] [--ranks P] [--device D]`.
+// ngsc - command line front end: `ngsc <in.fastq> <out.ngsc> [threads] [--ranks P] [--device D | --devices a,b,..]`.
 //
 // Keeps the reference's positional interface (phyNGSC.cpp:61-108: <input> <output> <threads>, exit codes
 // 1 usage, 2 open failure, 3 allocation failure).  `mpiexec -np P` becomes `--ranks P` (virtual ranks,
 // default 8): the output is what the reference writes with P processes, up to block order.  The
-// <threads> argument is accepted and ignored (the output never depended on it).
+// <threads> argument is accepted and ignored (the output never depended on it).  `--devices 0,1,2,3` spreads
+// the ranks over several GPUs from this one process (P must be a multiple of the device count); the file
+// does not depend on how many devices worked on it.
 #include "../../include/ngsc.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 int main(int argc, char **argv)
 {
     const char *in = nullptr, *out = nullptr;
     unsigned P = 8;
-    int device = 0, npos = 0;
+    int npos = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) P = (unsigned)atoi(argv[++i]);
-        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if ((!strcmp(argv[i], "--device") || !strcmp(argv[i], "--devices")) && i + 1 < argc) {
+            devices.clear();
+            for (const char *p = argv[++i]; *p;) {
+                devices.push_back(atoi(p));
+                while (*p && *p != ',') ++p;
+                if (*p == ',') ++p;
+            }
+        }
         else if (npos == 0) { in = argv[i]; ++npos; }
         else if (npos == 1) { out = argv[i]; ++npos; }
         else if (npos == 2) { if (atoi(argv[i]) < 1) { fprintf(stderr, "\n[E] ERROR: Number of threads is less than 1.\n"); return 1; } ++npos; }
@@ -25,31 +36,46 @@ int main(int argc, char **argv)
     }
     if (npos < 2 || npos > 3) {
         fprintf(stderr, "\n[E] ERROR: Incorrect number of arguments. Usage:\n");
-        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--device D]\n");
+        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--devices D[,D..]]\n");
         return 1;
     }
     if (P < 2) {
         fprintf(stderr, "\n[E] ERROR: Number of ranks (--ranks) is less than 2.\n");
         return 1;
     }
-    ngsc_ctx *ctx = nullptr;
-    int rc = ngsc_ctx_create(device, &ctx);
-    if (rc) {
-        fprintf(stderr, "\n[E] ERROR: no usable HIP device %d (%s). This program has no CPU fallback.\n", device, ngsc_strerror(rc));
-        return 3;
+    if (devices.empty()) devices.push_back(0);
+    if (P % devices.size()) {
+        fprintf(stderr, "\n[E] ERROR: Number of ranks (%u) is not a multiple of the number of devices (%zu).\n", P, devices.size());
+        return 1;
     }
-    printf("\n[I] INFO: Processing <<%s>> with %u virtual ranks on GPU %d.\n", in, P, device);
+    std::vector<ngsc_ctx *> ctxs;
+    auto destroy_all = [&]() { for (ngsc_ctx *c : ctxs) ngsc_ctx_destroy(c); };
+    for (int d : devices) {
+        ngsc_ctx *ctx = nullptr;
+        int rc = ngsc_ctx_create(d, &ctx);
+        if (rc) {
+            fprintf(stderr, "\n[E] ERROR: no usable HIP device %d (%s). This program has no CPU fallback.\n", d, ngsc_strerror(rc));
+            destroy_all();
+            return 3;
+        }
+        ctxs.push_back(ctx);
+    }
+    printf("\n[I] INFO: Processing <<%s>> with %u virtual ranks on %zu GPU context(s).\n", in, P, ctxs.size());
     double sec[3] = {0, 0, 0};
-    rc = ngsc_compress_file(ctx, in, out, P, sec);
+    int rc = ngsc_compress_file_multi(ctxs.data(), (uint32_t)ctxs.size(), in, out, P, sec);
     if (rc) {
-        fprintf(stderr, "\n[E] ERROR: %s%s%s\n", ngsc_strerror(rc), rc == NGSC_ERR_HIP ? ": " : "",
-                rc == NGSC_ERR_HIP ? ngsc_last_hip_error(ctx) : "");
-        ngsc_ctx_destroy(ctx);
+        fprintf(stderr, "\n[E] ERROR: %s\n", ngsc_strerror(rc));
+        if (rc == NGSC_ERR_HIP)
+            for (ngsc_ctx *c : ctxs)
+                if (*ngsc_last_hip_error(c)) fprintf(stderr, "          device %d: %s\n", ngsc_ctx_device(c), ngsc_last_hip_error(c));
+        destroy_all();
         return rc == NGSC_ERR_IO ? 2 : 3;
     }
-    printf("\nRANKS\tREAD+H2D\tDEVICE\t\tD2H+WRITE\tN_SUBBLOCKS\tOUT_BYTES\n");
-    printf("%u\t%f\t%f\t%f\t%u\t\t%llu\n", P, sec[0], sec[1], sec[2], ngsc_result_num_subblocks(ctx),
-           (unsigned long long)ngsc_result_bytes(ctx));
-    ngsc_ctx_destroy(ctx);
+    unsigned nsb = 0;
+    unsigned long long bytes = 0;
+    for (ngsc_ctx *c : ctxs) { nsb += ngsc_result_num_subblocks(c); bytes += ngsc_result_bytes(c); }
+    printf("\nRANKS\tREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tN_SUBBLOCKS\tOUT_BYTES\n");
+    printf("%u\t%f\t%f\t%f\t%u\t\t%llu\n", P, sec[0], sec[1], sec[2], nsb, bytes);
+    destroy_all();
     return 0;
 }

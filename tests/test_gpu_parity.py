@@ -248,3 +248,28 @@ def test_cli_file_to_file(tmp_path):
     # usage error -> exit code 1 like the reference
     assert subprocess.run([exe], capture_output=True).returncode == 1
     assert subprocess.run([exe, "/nonexistent.fastq", str(outp)], capture_output=True).returncode == 2
+
+
+def test_multi_context_file_driver(tmp_path):
+    """ngsc_compress_file_multi: two contexts (here both on device 0, on two host threads) write the same
+    file as one context -- the single-process multi-GPU driver (phyNGSC.cpp:113-116 rank split)."""
+    data = fastq_gen.generate(fastq_gen.CFG5, target_bytes=30_000_000)
+    inp = tmp_path / "in.fastq"
+    data.tofile(inp)
+    want, _ = orc.compress_file(data, 8, threads=8)
+    e0, e1 = api.Engine(0), api.Engine(0)
+    for engines, name in (([e0], "one"), ([e0, e1], "two"), ([e0, e1, api.Engine(0), api.Engine(0)], "four")):
+        outp = tmp_path / f"{name}.ngsc"
+        api.compress_file_multi(engines, str(inp), str(outp), 8)
+        assert outp.read_bytes() == want, name
+    with pytest.raises(api.NgscError) as ei:      # 8 ranks cannot be dealt to 3 contexts
+        api.compress_file_multi([e0, e1, api.Engine(0)], str(inp), str(tmp_path / "x.ngsc"), 8)
+    assert ei.value.code == -7
+    exe = os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc")
+    outp = tmp_path / "cli.ngsc"
+    r = subprocess.run([exe, str(inp), str(outp), "--ranks", "8", "--devices", "0,0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert outp.read_bytes() == want
+    assert subprocess.run([exe, str(inp), str(outp), "--ranks", "8", "--devices", "0,0,0"],
+                          capture_output=True).returncode == 1
