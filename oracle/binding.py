@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libngsc_oracle.so")
-_SRC = [os.path.join(_HERE, "ngsc_oracle.c"), os.path.join(_HERE, "ngsc_oracle.h")]
+_SRC = [os.path.join(_HERE, "ngsc_oracle.c"), os.path.join(_HERE, "ngsc_decode.c"), os.path.join(_HERE, "ngsc_oracle.h")]
 
 MAX_RECORDS = 100000
 WINDOW = 1 << 23
@@ -47,7 +47,7 @@ _libc.free.argtypes = [ctypes.c_void_p]
 def build(force: bool = False) -> str:
     stale = not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in _SRC)
     if force or stale:
-        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", _SO, _SRC[0], "-lm"])
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", _SO, _SRC[0], _SRC[1], "-lm"])
     return _SO
 
 
@@ -77,6 +77,10 @@ def lib():
         L.ngsc_o_make_footer.restype = ctypes.c_uint32
         L.ngsc_o_make_footer.argtypes = [u8p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                          u8p, u8p, u8p]
+        L.ngsc_o_decode_subblock.restype = ctypes.c_int
+        L.ngsc_o_decode_subblock.argtypes = [u8p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                             ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -167,3 +171,34 @@ def make_footer(P, fastq_size, n_subblocks, overlaps, cbo, lb_sizes) -> bytes:
     n = lib().ngsc_o_make_footer(out.ctypes.data, P, fastq_size, cb.size, n_subblocks, ov.ctypes.data,
                                  cb.ctypes.data, lb.ctypes.data)
     return bytes(out[:n])
+
+
+def decode_subblock(sb):
+    """Inverse of subblock(): returns (FASTQ bytes, bytes consumed, n_records)."""
+    a = _as_u8(sb)
+    out = ctypes.c_void_p()
+    n = ctypes.c_uint64()
+    used = ctypes.c_uint64()
+    nrec = ctypes.c_uint32()
+    rc = lib().ngsc_o_decode_subblock(a.ctypes.data, a.size, ctypes.byref(out), ctypes.byref(n), ctypes.byref(used),
+                                      ctypes.byref(nrec))
+    if rc:
+        raise OracleError(rc)
+    res = ctypes.string_at(out.value, n.value)
+    _libc.free(out)
+    return res, used.value, nrec.value
+
+
+def decompress(ngsc) -> bytes:
+    """.ngsc container -> FASTQ text: the sub-blocks of every rank, ranks ascending (each rank's records are a
+    contiguous run of the file, phyNGSC.cpp:113-166).  Every sub-block must decode to exactly its SBOL length."""
+    from phyngsc_amd import ngsc_format
+    streams = ngsc_format.rank_streams(bytes(ngsc))
+    parts = []
+    for w in sorted(streams):
+        for sb in streams[w]:
+            text, used, _ = decode_subblock(sb)
+            if used != len(sb):
+                raise OracleError(-1)
+            parts.append(text)
+    return b"".join(parts)

@@ -103,6 +103,15 @@ typedef struct {
 int ngsc_o_compress_file(const uint8_t *fastq, uint64_t size, uint32_t P, int threads, uint8_t **out,
                          uint64_t *out_len, ngsc_o_filestats *stats);
 
+/*
+ * Decoder (ngsc_decode.c), the round-trip leg of the tests: one sub-block's info|title|quality|DNA
+ * bytes -> the FASTQ text of its records.  *fastq is malloc()ed; consumed = bytes of sb read (equals
+ * the sub-block's SBOL length).  The reference has no decompressor; its unused Fetch* fragments
+ * (tasks.cpp:625-1101) are cited in the source.
+ */
+int ngsc_o_decode_subblock(const uint8_t *sb, uint64_t len, uint8_t **fastq, uint64_t *fastq_len, uint64_t *consumed,
+                           uint32_t *n_records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,21 @@ def test_full_size_properties_1gb(eng):
     assert off == res.total_bytes
     assert sum(sb.n_records for sb in res.subblocks) == int((data == 10).sum()) // 4
     assert sum(sb.n_bases for sb in res.subblocks) == 36 * (int((data == 10).sum()) // 4)
+    # encode -> decode round trip at full size: every sub-block decodes (oracle/ngsc_decode.c) to exactly the
+    # bytes of the file it covers, in order, and to exactly its own length
+    from concurrent.futures import ThreadPoolExecutor
+    spans = [(sb.out_off, sb.size) for sb in res.subblocks]
+
+    def dec(span):
+        text, used, _ = orc.decode_subblock(host[span[0]:span[0] + span[1]])
+        assert used == span[1]
+        return text
+    pos = 0
+    with ThreadPoolExecutor(8) as ex:
+        for text in ex.map(dec, spans):
+            assert text == data[pos:pos + len(text)].tobytes(), f"round trip differs near byte {pos}"
+            pos += len(text)
+    assert pos == data.size
 
 
 # ---- error behaviour of the boundary -----------------------------------------------------------------
@@ -273,3 +288,21 @@ def test_multi_context_file_driver(tmp_path):
     assert outp.read_bytes() == want
     assert subprocess.run([exe, str(inp), str(outp), "--ranks", "8", "--devices", "0,0,0"],
                           capture_output=True).returncode == 1
+
+
+@pytest.mark.parametrize("ngsc_path", SMALL[::3], ids=[os.path.basename(p) for p in SMALL[::3]])
+def test_round_trip_goldens(eng, ngsc_path):
+    """GPU output -> CPU decoder -> the original FASTQ (decoder pinned on the reference's own outputs in
+    tests/test_oracle_roundtrip.py)."""
+    m = re.match(r"(.*)\.p(\d+)\.ngsc$", ngsc_path)
+    with open(m.group(1) + ".fastq", "rb") as f:
+        data = f.read()
+    _, out = _gpu(eng, data, int(m.group(2)))
+    assert orc.decompress(out) == data
+
+
+@pytest.mark.parametrize("cfg,size,P", [(fastq_gen.CFG3, 60_000_000, 8), (fastq_gen.CFG5, 40_000_000, 6)])
+def test_round_trip_generated(eng, cfg, size, P):
+    data = fastq_gen.generate(cfg, target_bytes=size)
+    _, out = _gpu(eng, data, P)
+    assert orc.decompress(out) == data.tobytes()
