@@ -268,7 +268,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
     Carver cs;
     size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
-    size_t o_maxrec = cs.take(4);
+    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4);
     size_t o_outtot = cs.take(8);
     size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
     size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
@@ -279,7 +279,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     int32_t *d_err = (int32_t *)(sm + o_err);
     uint32_t *d_total = (uint32_t *)(sm + o_total), *d_start = (uint32_t *)(sm + o_start);
     uint32_t *d_maxq = (uint32_t *)(sm + o_maxq), *d_slotc = (uint32_t *)(sm + o_slotc);
-    uint32_t *d_maxrec = (uint32_t *)(sm + o_maxrec);
+    uint32_t *d_maxrec = (uint32_t *)(sm + o_maxrec), *d_maxtitle = (uint32_t *)(sm + o_maxtitle);
     uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
     RankPlan *d_plans = (RankPlan *)(sm + o_plans);
     Cut *d_cuts = (Cut *)(sm + o_cuts);
@@ -313,6 +313,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t o_te = cr.take(4 * rec_cap), o_se = cr.take(4 * rec_cap), o_ls = cr.take(4 * (rec_cap + 1));
     size_t o_slen = cr.take(4 * rec_cap), o_qoff = cr.take(4 * rec_cap), o_doff = cr.take(4 * rec_cap);
     size_t o_goff = cr.take(4 * grp_cap), o_gflags = cr.take(4 * grp_cap), o_tbits = cr.take(4 * rec_cap);
+    size_t o_tsep = cr.take(8 * rec_cap);
     rc = ensure(c, c->recs, cr.off);
     if (rc) return rc;
     uint8_t *rb = (uint8_t *)c->recs.p;
@@ -323,7 +324,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     {
         KScope k(c, st, "k_validate");
-        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_maxrec, d_err);
+        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_maxrec, d_maxtitle, d_err);
     }
     {
         KScope k(c, st, "k_cuts");
@@ -337,6 +338,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
     const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
     const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
+    const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
     const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
     const Cut *h_cuts = (const Cut *)(hp + o_cuts);
     std::vector<Cut> cuts;
@@ -412,6 +414,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.goff = (uint32_t *)(rb + o_goff);
     A.grp_lo = (uint32_t *)(pb + p_grplo);
     A.tbits = (uint32_t *)(rb + o_tbits);
+    A.tsep = (uint64_t *)(rb + o_tsep);
     A.gflags = (uint32_t *)(rb + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);
@@ -472,7 +475,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
 
     // ---- stage C ----
     { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
-    { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+    // titles of at most 64 bytes take the word-parallel kernels (NGSC_TITLE_PATH=reg forces the byte-serial ones)
+    const char *tp_env = getenv("NGSC_TITLE_PATH");
+    const bool t_swar = max_title <= 64 && !(tp_env && !strcmp(tp_env, "reg"));
+    if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
+    else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
     if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
@@ -480,7 +487,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec); }
     { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-    { KScope k(c, st, "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec); }
+    { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if (R) {
         { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
         { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }

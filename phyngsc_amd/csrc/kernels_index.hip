@@ -166,15 +166,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
 //   quality length must equal sequence length (README.md:97-103); line 2 == "+" is checked later.
 // The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
 __global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint32_t *te, const uint32_t *se,
-                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, int32_t *err)
+                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec,
+                                                  uint32_t *max_title, int32_t *err)
 {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t L = 0, RB = 0;
+    uint32_t L = 0, RB = 0, TL = 0;
     bool bad = false;
     if (r < n_rec) {
         uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
         L = s - t - 1;
         RB = l1 - l0;
+        TL = t - l0 + 1;
         // the bare '+' line is checked by the statistics kernels, which have the bytes in LDS anyway
         bad = !(t >= l0 && s > t) || l1 != 2 * s - t + 3;
     }
@@ -188,6 +190,10 @@ __global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mb, d); mb = o > mb ? o : mb; }
     if ((threadIdx.x & 63) == 0 && mb > *max_rec) atomicMax(max_rec, mb);
+    uint32_t mt = TL;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
+    if ((threadIdx.x & 63) == 0 && mt > *max_title) atomicMax(max_title, mt);
 }
 
 // First-record synchronisation of every virtual rank > 0 (phyNGSC.cpp:131-156): first '@' at or after
@@ -276,10 +282,11 @@ void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uin
 }
 
 void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
-                     uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, int32_t *err)
+                     uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, uint32_t *max_title, int32_t *err)
 {
     if (!n_rec) return;
-    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, max_rec, err);
+    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, max_rec,
+                       max_title, err);
 }
 
 void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,

@@ -82,6 +82,81 @@ __device__ __forceinline__ void for_each_title_byte(const uint8_t *buf, uint32_t
     }
 }
 
+// =========================================================================================================
+// Word-parallel title path for jobs whose titles are all <= 64 bytes (TS_MAX_TITLE).
+//
+// The byte-serial parsers above cost ~100 VALU instructions per title byte and wave (PMC: 6.4 k VALU per
+// wave, VALU-bound).  Here a lane holds its whole title in 16 dwords, classifies four bytes per step with
+// v_perm_b32 nibble tables into a 64-bit separator mask and a 64-bit digit mask, and then walks the FIELDS
+// (wave-uniform loop over record 0's field count) instead of the bytes: field length = count of trailing
+// zeros of the shifted separator mask, field bytes = funnel-shifted dwords of the lane's own LDS column,
+// equality / Hamming mask = XOR against record 0's field words, numeric value = SWAR 8-digit parse.
+// Same statistics, same s_stat layout and same results as k_title_stats_reg.
+constexpr uint32_t TS_ROWS = 17;   // 16 title dwords + one zero row for reads past the title
+
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
+
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 16 <= buf_len) { const U4u v = *reinterpret_cast<const U4u *>(buf + a); return make_uint4(v.x, v.y, v.z, v.w); }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t x = 0; x < 16; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 8 <= buf_len) { const U2u v = *reinterpret_cast<const U2u *>(buf + a); return make_uint2(v.x, v.y); }
+    uint32_t w[2] = {0, 0};
+    for (uint32_t x = 0; x < 8; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint2(w[0], w[1]);
+}
+
+// Four bytes at once: per byte, bits 0-3 = separator class (non-zero <=> one of " ._,=:/-#\n"), bit 4 = digit.
+// class(byte) = LUT_lo[low nibble] & LUT_hi[high nibble]; each LUT is a v_perm_b32 byte table (8 entries per
+// instruction, the 16-entry low table is two of them selected by nibble bit 3); bytes >= 0x80 are cleared.
+__device__ __forceinline__ uint32_t t_classify4(uint32_t w)
+{
+    const uint32_t lo3 = w & 0x07070707u;
+    const uint32_t pa = __builtin_amdgcn_perm(0x10101010u, 0x12101012u, lo3);   // low nibble 0..7
+    const uint32_t pb = __builtin_amdgcn_perm(0x0A020602u, 0x00051010u, lo3);   // low nibble 8..15
+    const uint32_t m3 = ((w >> 3) & 0x01010101u) * 0xFFu;
+    const uint32_t lo = (pa & ~m3) | (pb & m3);
+    const uint32_t hi = __builtin_amdgcn_perm(0x00000800u, 0x14020001u, (w >> 4) & 0x07070707u);
+    const uint32_t m7 = ((w >> 7) & 0x01010101u) * 0xFFu;
+    return lo & hi & ~m7;
+}
+// 0x01 flags in bytes 0..3 -> bits 0..3
+__device__ __forceinline__ uint32_t t_movemask(uint32_t flags01) { return (flags01 * 0x01020408u) >> 24; }
+// per byte: 0x01 where the byte of x is non-zero
+__device__ __forceinline__ uint32_t t_nonzero01(uint32_t x)
+{
+    return ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7) & 0x01010101u;
+}
+__device__ __forceinline__ uint64_t t_lowbytes(uint32_t n)   // 0xFF in the n lowest bytes, n clamped to 0..8
+{
+    return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
+}
+__device__ __forceinline__ uint64_t t_lowbits(uint32_t n)    // n lowest bits, n in 0..64
+{
+    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+}
+// value of four decimal digits (nibbles 0..9 in the bytes, most significant digit in byte 0)
+__device__ __forceinline__ uint32_t t_val4(uint32_t x)
+{
+    const uint32_t p = (x * 10u + (x >> 8)) & 0x00FF00FFu;
+    return (p & 0xFFu) * 100u + (p >> 16);
+}
+// SWAR parse of an all-digit field of len <= 8 whose bytes sit in the low bytes of {w1,w0}
+__device__ __forceinline__ uint32_t t_parse8(uint32_t w0, uint32_t w1, uint32_t len)
+{
+    const uint64_t d = ((uint64_t)(w1 & 0x0F0F0F0Fu) << 32) | (w0 & 0x0F0F0F0Fu);
+    const uint64_t t = d << ((8u * (8u - len)) & 63u);    // right-align: leading bytes become zero digits
+    return t_val4((uint32_t)t) * 10000u + t_val4((uint32_t)(t >> 32));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
 {
@@ -112,6 +187,16 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
         }
         ++nf0;
         start = p + 1;
+    }
+    // field-aligned copy of the title for the word-parallel path: every field starts on a dword and is zero
+    // padded to a multiple of eight bytes
+    uint32_t wcur = 0;
+    uint8_t *al = reinterpret_cast<uint8_t *>(T.al);
+    for (uint32_t k = 0; k < sizeof(T.al); ++k) al[k] = 0;
+    for (uint32_t f = 0; f < nf0 && f < MAX_FIELDS; ++f) {
+        T.woff[f] = (uint16_t)wcur;
+        for (uint32_t k = 0; k < T.len[f]; ++k) al[4 * wcur + k] = T.title[T.start[f] + k];
+        wcur += 2 * ((T.len[f] + 7u) / 8u);
     }
     T.nf0 = nf0;
     T.ncand = ncand;
@@ -281,7 +366,10 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
     }
 }
 
-// 256 records (8 groups of 32) per workgroup.
+// 256 records (8 groups of 32) per workgroup.  SWAR: titles <= 64 bytes whose separator masks k_title_stats_swar
+// left in A.tsep - the fields are found with count-trailing-zeros steps and only the non-constant numeric ones
+// are read (eight bytes, unaligned) and parsed; otherwise the title is parsed byte by byte.
+template <bool SWAR>
 __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
 {
     if (*A.err) return;
@@ -312,20 +400,46 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     uint32_t bits = 0, gconst = 0;
     if (ncf <= NCF_CAP) {
         // one pass over the title: cache the non-constant fields of this record
-        uint32_t f = 0, k = 0, v = 0;
-        for_each_title_byte(A.buf, A.buf_len, ls, te, valid, [&](uint32_t c, uint32_t act, uint32_t p) {
-            const uint32_t sepb = act & t_sep(c);
-            const uint32_t body = act & (sepb ^ 1u);
-            v = body ? v * 10 + (c - '0') : v;   // wraps like utils::to_num; only used for all-numeric fields
-            k += body;
-            if (__any(sepb)) {
-                if (sepb) {
-                    if (f < nf && s_fd[f].kind != KIND_CONST)
-                        s_w[s_fd[f].kf][tid] = s_fd[f].kind == KIND_NUM ? v : ((p - k - ls) | (k << 16));
-                    ++f; k = 0; v = 0;
+        if constexpr (SWAR) {
+            const uint64_t sepmask = valid ? A.tsep[g] : 0;
+            uint32_t pos = 0;
+            for (uint32_t f = 0; f < nf; ++f) {
+                const uint64_t rem = pos < 64 ? sepmask >> pos : 0;
+                const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
+                const uint32_t kind = s_fd[f].kind;
+                if (kind == KIND_NUM) {
+                    uint32_t v = 0;
+                    if (valid) {
+                        const uint2 q = load8_unaligned(A.buf, ls + pos, A.buf_len);
+                        const uint64_t km = t_lowbytes(len);
+                        v = t_parse8(q.x & (uint32_t)km, q.y & (uint32_t)(km >> 32), len);
+                        if (len > 8) {   // wraps like utils::to_num (utils.h:117-125)
+                            v = 0;
+                            for (uint32_t j = 0; j < len; ++j) v = v * 10 + (A.buf[ls + pos + j] - '0');
+                        }
+                    }
+                    s_w[s_fd[f].kf][tid] = v;
+                } else if (kind == KIND_TEXT) {
+                    s_w[s_fd[f].kf][tid] = pos | (len << 16);
                 }
+                pos += len + 1;
             }
-        });
+        } else {
+            uint32_t f = 0, k = 0, v = 0;
+            for_each_title_byte(A.buf, A.buf_len, ls, te, valid, [&](uint32_t c, uint32_t act, uint32_t p) {
+                const uint32_t sepb = act & t_sep(c);
+                const uint32_t body = act & (sepb ^ 1u);
+                v = body ? v * 10 + (c - '0') : v;   // wraps like utils::to_num; only used for all-numeric fields
+                k += body;
+                if (__any(sepb)) {
+                    if (sepb) {
+                        if (f < nf && s_fd[f].kind != KIND_CONST)
+                            s_w[s_fd[f].kf][tid] = s_fd[f].kind == KIND_NUM ? v : ((p - k - ls) | (k << 16));
+                        ++f; k = 0; v = 0;
+                    }
+                }
+            });
+        }
         __syncthreads();
         CachedTitle C;
         TitleDiffs d = {0, 0, 0};
@@ -500,6 +614,185 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     }
 }
 
+// Title of one record as 16 dwords (bytes past the title are other lines' bytes: every use masks by length),
+// written to the lane's LDS column, plus its separator / digit masks.
+__device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
+                                             uint64_t &sepmask, uint64_t &digmask)
+{
+    uint32_t seplo = 0, sephi = 0, diglo = 0, dighi = 0;
+#pragma unroll
+    for (uint32_t m = 0; m < 4; ++m) {
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (__any(16 * m < tlen)) {
+            if (16 * m < tlen) q = load16_unaligned(A.buf, ls + 16 * m, A.buf_len);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t cls = t_classify4(w[j]);
+                const uint32_t sp = t_movemask((((cls & 0x0F0F0F0Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u);
+                const uint32_t dg = t_movemask((cls >> 4) & 0x01010101u);
+                const uint32_t sh = 4 * ((4 * m + j) & 7);
+                if (m < 2) { seplo |= sp << sh; diglo |= dg << sh; }
+                else { sephi |= sp << sh; dighi |= dg << sh; }
+            }
+        }
+        s_w[4 * m + 0][tid] = q.x;
+        s_w[4 * m + 1][tid] = q.y;
+        s_w[4 * m + 2][tid] = q.z;
+        s_w[4 * m + 3][tid] = q.w;
+    }
+    s_w[16][tid] = 0;
+    const uint64_t keep = t_lowbits(tlen);
+    sepmask = (((uint64_t)sephi << 32) | seplo) & keep;
+    digmask = (((uint64_t)dighi << 32) | diglo) & keep;
+}
+
+// eight bytes of the lane's title starting at byte position pos (rows past the title read the zero row)
+__device__ __forceinline__ void t_field8(uint32_t (*s_w)[TT_THREADS], int tid, uint32_t pos, uint32_t &w0, uint32_t &w1)
+{
+    const uint32_t r = pos >> 2, sh = (pos & 3) * 8;
+    const uint32_t x0 = s_w[r < 16 ? r : 16][tid], x1 = s_w[r + 1 < 16 ? r + 1 : 16][tid], x2 = s_w[r + 2 < 16 ? r + 2 : 16][tid];
+    w0 = __builtin_amdgcn_alignbit(x1, x0, sh);
+    w1 = __builtin_amdgcn_alignbit(x2, x1, sh);
+}
+
+__global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
+{
+    if (*A.err) return;
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    constexpr uint32_t OWNED = TT_THREADS - 1;
+    if (blockIdx.x * OWNED >= n) return;
+    const int tid = threadIdx.x;
+
+    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
+    __shared__ uint32_t s_val[NUM_CAND_CAP][TT_THREADS];
+    __shared__ uint32_t s_nummask[TT_THREADS];
+    __shared__ uint32_t s_w[TS_ROWS][TT_THREADS];
+    __shared__ Rec0Tab s_r0;
+
+    for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
+        reinterpret_cast<uint32_t *>(&s_r0)[k] = reinterpret_cast<const uint32_t *>(A.rec0 + s)[k];
+    for (uint32_t k = tid; k < MAX_FIELDS * 24; k += TT_THREADS) s_stat[k] = 0;
+    __syncthreads();
+    const uint32_t nf0 = s_r0.nf0 < MAX_FIELDS ? s_r0.nf0 : MAX_FIELDS;
+
+    const int64_t i = (int64_t)blockIdx.x * OWNED + tid - 1;  // record index inside the sub-block
+    const bool valid = i >= 0 && i < (int64_t)n;
+    const bool owned = valid && tid >= 1;
+    const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
+    const uint32_t ls = A.ls[g], te = A.te[g];
+    const uint32_t tlen = valid ? te - ls + 1 : 0;            // title bytes including the closing newline
+
+    uint64_t sepmask, digmask;
+    t_load_title(A, ls, tlen, s_w, tid, sepmask, digmask);
+    if (owned) A.tsep[g] = sepmask;
+    if (valid && (uint32_t)__popcll(sepmask) != s_r0.nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+
+    uint32_t pos = 0, nummask = 0;
+    for (uint32_t f = 0; f < nf0; ++f) {
+        const uint32_t len0 = s_r0.len[f], kk = s_r0.kmap[f], wo = s_r0.woff[f];
+        const uint64_t rem = pos < 64 ? sepmask >> pos : 0;
+        const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
+        const uint32_t minlen = len < len0 ? len : len0;
+
+        // compare with record 0's field, eight bytes per step
+        uint32_t w0 = 0, w1 = 0, diff = 0, c8 = 0;
+        do {
+            uint32_t x0, x1;
+            t_field8(s_w, tid, pos + 8 * c8, x0, x1);
+            const uint32_t left = len > 8 * c8 ? len - 8 * c8 : 0;
+            const uint64_t km = t_lowbytes(left);
+            x0 &= (uint32_t)km;
+            x1 &= (uint32_t)(km >> 32);
+            if (c8 == 0) { w0 = x0; w1 = x1; }
+            const bool in0 = 8 * c8 < len0;
+            const uint32_t a0 = in0 ? s_r0.al[wo + 2 * c8] : 0, a1 = in0 ? s_r0.al[wo + 2 * c8 + 1] : 0;
+            const uint32_t d0 = x0 ^ a0, d1 = x1 ^ a1;
+            diff |= d0 | d1;
+            if (__any(d0 | d1)) {
+                const uint64_t hm = t_lowbytes(minlen > 8 * c8 ? minlen - 8 * c8 : 0);   // Hamming mask: tasks.cpp:187-193
+                const uint32_t hb = t_movemask(t_nonzero01(d0 & (uint32_t)hm)) | (t_movemask(t_nonzero01(d1 & (uint32_t)(hm >> 32))) << 4);
+                if (hb && owned && c8 < 32) t_lds_or(&s_stat[f * 24 + 10 + (c8 >> 2)], hb << (8 * (c8 & 3)));
+            }
+            ++c8;
+        } while (__any(len > 8 * c8) || 8 * c8 < len0);
+        const bool same = len == len0 && diff == 0;
+
+        // numeric test and value (utils::is_num / to_num, utils.h:107-125); only a numeric record 0 can leave the
+        // field numeric, and record 0's own lane marks it non-numeric otherwise
+        bool isn = false, ovf = false;
+        uint32_t v = 0;
+        if (kk != 0xff) {
+            const uint64_t dm = pos < 64 ? digmask >> pos : 0, lm = t_lowbits(len);
+            isn = (dm & lm) == lm && len > 0 && !(len > 1 && (w0 & 0xffu) == '0');
+            v = t_parse8(w0, w1, len);
+            if (__any(isn && len > 8)) {
+                if (isn && len > 8) {   // nine digits and more: digit by digit with the overflow test
+                    v = 0;
+                    for (uint32_t j = 0; j < len; ++j) {
+                        const uint32_t p = pos + j;
+                        const uint32_t d = ((s_w[p >> 2][tid] >> (8 * (p & 3))) & 0xffu) - '0';
+                        if (v > 214748364u || (v == 214748364u && d > 7)) ovf = true;
+                        v = v * 10 + d;
+                    }
+                }
+            }
+            if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
+            nummask |= (uint32_t)isn << f;
+        }
+
+        // A field identical to record 0's cannot change any statistic beyond what record 0's own lane
+        // contributes, so only differing fields (and record 0 itself) touch the counters.
+        const bool upd = owned && (!same || i == 0);
+        if (__any(upd)) {
+            if (upd) {
+                uint32_t *st = s_stat + f * 24;
+                const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5], a6 = st[6], a7 = st[7];
+                const uint32_t bv = bias((int32_t)v);
+                const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3, n4 = !isn && !a4,
+                           n5 = isn && ovf && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
+                if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
+                    if (n0) atomicMax(st + 0, len);
+                    if (n1) atomicMax(st + 1, ~len);
+                    if (n2) atomicMax(st + 2, 1u);
+                    if (n3) atomicMax(st + 3, 1u);
+                    if (n4) atomicMax(st + 4, 1u);
+                    if (n5) atomicMax(st + 5, 1u);
+                    if (n6) atomicMax(st + 6, bv);
+                    if (n7) atomicMax(st + 7, ~bv);
+                }
+            }
+        }
+        pos += len + 1;
+    }
+    s_nummask[tid] = nummask;
+    __syncthreads();
+    if (owned && i >= 1) {
+        const uint32_t both = nummask & s_nummask[tid - 1];
+        const uint32_t ncand = s_r0.ncand;
+        for (uint32_t kk = 0; kk < ncand; ++kk) {
+            const uint32_t ff = s_r0.cand_f[kk];
+            if ((both >> ff) & 1) {
+                const int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
+                const uint32_t bd = bias(d);
+                if (bd > s_stat[ff * 24 + 8]) atomicMax(&s_stat[ff * 24 + 8], bd);
+                if (~bd > s_stat[ff * 24 + 9]) atomicMax(&s_stat[ff * 24 + 9], ~bd);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
+    for (uint32_t kx = tid; kx < nf0 * 24; kx += TT_THREADS) {
+        uint32_t x = s_stat[kx];
+        if (!x) continue;
+        uint32_t w = kx % 24;
+        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
+        else if (w < 10) atomicMax(gst + kx, x);
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 void launch_rec0_fields(hipStream_t st, const Arena &A)
 {
@@ -512,10 +805,17 @@ void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(k_title_stats_reg, grid, dim3(TT_THREADS), 0, st, A);
 }
 
-void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    dim3 grid((max_rec + TT_THREADS - 2) / (TT_THREADS - 1), A.n_sb);
+    hipLaunchKernelGGL(k_title_stats_swar, grid, dim3(TT_THREADS), 0, st, A);
+}
+
+void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar)
 {
     dim3 grid((max_rec + TT_THREADS - 1) / TT_THREADS, A.n_sb);
-    hipLaunchKernelGGL(k_title_measure_reg, grid, dim3(TT_THREADS), 0, st, A);
+    if (swar) hipLaunchKernelGGL(k_title_measure_reg<true>, grid, dim3(TT_THREADS), 0, st, A);
+    else hipLaunchKernelGGL(k_title_measure_reg<false>, grid, dim3(TT_THREADS), 0, st, A);
 }
 
 void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)

@@ -224,6 +224,8 @@ struct Rec0Tab {
     uint8_t kmap[MAX_FIELDS];                     // numeric candidate index, 0xff = not numeric, 0xfe = untracked
     uint8_t cand_f[NUM_CAND_CAP];                 // candidate index -> field
     uint8_t title[REC0_TITLE_CAP];
+    uint16_t woff[MAX_FIELDS];                    // dword offset of the field inside al
+    uint32_t al[(REC0_TITLE_CAP + 8 * MAX_FIELDS) / 4];  // field-aligned copy, each field zero padded to 8 bytes
 };
 static_assert(sizeof(Rec0Tab) % 4 == 0, "Rec0Tab is copied word-wise");
 
@@ -242,6 +244,7 @@ struct Arena {
     uint32_t *gflags;       // per title group: flag bits (tiled path)
     uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
     uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
+    uint64_t *tsep;         // per record: separator mask of the title (word-parallel path, titles <= 64 B)
     uint32_t *tw;           // [NCF_CAP][tw_stride]: cached non-constant title fields per record (tiled path)
     uint32_t tw_stride;
     uint32_t *tile_lo;      // per sub-block: first tile index

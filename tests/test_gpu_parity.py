@@ -126,6 +126,52 @@ def test_kernel_paths_agree(eng, monkeypatch, tile_records):
         assert ok, f"{name} (tile_records={tile_records}): {msg}"
 
 
+@pytest.mark.parametrize("title_path", ["reg", "swar"])
+def test_title_paths_agree(eng, monkeypatch, title_path):
+    """Titles of at most 64 bytes take the word-parallel title kernels (separator/digit masks from v_perm nibble
+    tables, field-wise SWAR), longer ones the byte-serial kernels; NGSC_TITLE_PATH=reg forces the latter.  Both
+    must reproduce the reference on every committed golden and on generated inputs."""
+    monkeypatch.setenv("NGSC_TITLE_PATH", title_path)
+    for ngsc_path in SMALL:
+        m = re.match(r"(.*)\.p(\d+)\.ngsc$", ngsc_path)
+        with open(m.group(1) + ".fastq", "rb") as f:
+            data = f.read()
+        with open(ngsc_path, "rb") as f:
+            ref = f.read()
+        _, out = _gpu(eng, data, int(m.group(2)))
+        ok, msg = nf.equivalent(ref, out)
+        assert ok, f"{os.path.basename(ngsc_path)} (title path {title_path}): {msg}"
+    for cfg, size, P in ((fastq_gen.CFG2, 30_000_000, 4), (fastq_gen.CFG5, 30_000_000, 3), (fastq_gen.CFG1, 8 << 20, 2)):
+        data = fastq_gen.generate(cfg, target_bytes=size)
+        _, out = _gpu(eng, data, P)
+        want, _ = orc.compress_file(data, P, threads=4)
+        assert out == want, f"cfg seed {cfg.seed} (title path {title_path})"
+
+
+def _byte_class_fastq() -> bytes:
+    """Every byte value inside a title, with the separator count kept at three per title (a changing count is an
+    error): separators split `1c2z`, everything else sits in the middle of `1c2` (numeric only for digits)."""
+    seps = b" ._,=:/-#"
+    recs = []
+    for rep in range(3):
+        for c in range(256):
+            if c == 10:
+                continue
+            ch = bytes([c])
+            title = b"@x." + (b"1" + ch + b"2z" if ch in seps else b"1" + ch + b"2.z")
+            recs.append(title + b"\nACGTACGT\n+\nIIIIIIII\n")
+    return b"".join(recs)
+
+
+def test_title_separator_and_digit_classes(eng):
+    """The nibble-table classifier must agree with the separator list " ._,=:/-#\\n" (phyNGSC.cpp:208) and with
+    utils::is_num for all byte values (CR, NUL, high-bit bytes, ...)."""
+    data = _byte_class_fastq()
+    _, out = _gpu(eng, data, 2)
+    want, _ = orc.compress_file(data, 2)
+    assert out == want      # (no round trip here: the format keeps ONE separator byte per field position)
+
+
 def test_long_records_take_the_untiled_path(eng):
     """300-400 bp reads: records of ~850 B do not fit the LDS tile budget (and exceed the reference's
     500-byte overlap, where it reads past its buffer - Q7 - so the oracle, which sees the real bytes, is
