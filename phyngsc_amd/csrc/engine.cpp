@@ -480,7 +480,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const bool t_swar = max_title <= 64 && !(tp_env && !strcmp(tp_env, "reg"));
     if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
     else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
-    if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
+    // records of up to 2 KB: one lane per record straight from global memory (NGSC_SQ_PATH=tile keeps the LDS tiles)
+    const char *sq_env = getenv("NGSC_SQ_PATH");
+    const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
+    if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
+    else if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
     { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }

@@ -11,6 +11,7 @@
 //                        area, one coalesced copy-out per 256 records            (tasks.cpp:427-507)
 // Algorithmic traffic: the title bytes once per kernel (stats, measure) + 4 B per cached field and record.
 #include "ngsc_kernels.h"
+#include "ngsc_swar.h"
 
 namespace ngsc {
 
@@ -94,26 +95,6 @@ __device__ __forceinline__ void for_each_title_byte(const uint8_t *buf, uint32_t
 // Same statistics, same s_stat layout and same results as k_title_stats_reg.
 constexpr uint32_t TS_ROWS = 17;   // 16 title dwords + one zero row for reads past the title
 
-struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
-
-__device__ __forceinline__ uint4 load16_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
-{
-    if (a + 16 <= buf_len) { const U4u v = *reinterpret_cast<const U4u *>(buf + a); return make_uint4(v.x, v.y, v.z, v.w); }
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t x = 0; x < 16; ++x)
-        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-__device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
-{
-    if (a + 8 <= buf_len) { const U2u v = *reinterpret_cast<const U2u *>(buf + a); return make_uint2(v.x, v.y); }
-    uint32_t w[2] = {0, 0};
-    for (uint32_t x = 0; x < 8; ++x)
-        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
-    return make_uint2(w[0], w[1]);
-}
-
 // Four bytes at once: per byte, bits 0-3 = separator class (non-zero <=> one of " ._,=:/-#\n"), bit 4 = digit.
 // class(byte) = LUT_lo[low nibble] & LUT_hi[high nibble]; each LUT is a v_perm_b32 byte table (8 entries per
 // instruction, the 16-entry low table is two of them selected by nibble bit 3); bytes >= 0x80 are cleared.
@@ -127,21 +108,6 @@ __device__ __forceinline__ uint32_t t_classify4(uint32_t w)
     const uint32_t hi = __builtin_amdgcn_perm(0x00000800u, 0x14020001u, (w >> 4) & 0x07070707u);
     const uint32_t m7 = ((w >> 7) & 0x01010101u) * 0xFFu;
     return lo & hi & ~m7;
-}
-// 0x01 flags in bytes 0..3 -> bits 0..3
-__device__ __forceinline__ uint32_t t_movemask(uint32_t flags01) { return (flags01 * 0x01020408u) >> 24; }
-// per byte: 0x01 where the byte of x is non-zero
-__device__ __forceinline__ uint32_t t_nonzero01(uint32_t x)
-{
-    return ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7) & 0x01010101u;
-}
-__device__ __forceinline__ uint64_t t_lowbytes(uint32_t n)   // 0xFF in the n lowest bytes, n clamped to 0..8
-{
-    return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
-}
-__device__ __forceinline__ uint64_t t_lowbits(uint32_t n)    // n lowest bits, n in 0..64
-{
-    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
 // value of four decimal digits (nibbles 0..9 in the bytes, most significant digit in byte 0)
 __device__ __forceinline__ uint32_t t_val4(uint32_t x)

@@ -19,6 +19,9 @@ void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_l
                  const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                  uint32_t max_cuts, RankPlan *plans, int32_t *err);
 
+// ---- kernels_sq.hip ----
+void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+
 // ---- kernels_stats.hip ----
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_finalize(hipStream_t st, const Arena &A);

@@ -1,0 +1,53 @@
+// ngsc_swar.h - device helpers shared by the register-streaming kernels: unaligned global loads and
+// four-bytes-per-instruction (SWAR) mask tricks.
+#pragma once
+#include "ngsc_common.h"
+#include <hip/hip_runtime.h>
+
+namespace ngsc {
+
+// gfx950 global memory takes unaligned dword loads; the packed types tell the compiler so (one
+// global_load_dwordx4 / dwordx2 instead of byte loads).  Never reads past buf_len.
+struct __attribute__((packed, aligned(1))) U4u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U2u { uint32_t x, y; };
+
+__device__ __forceinline__ uint4 load16_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 16 <= buf_len) { const U4u v = *reinterpret_cast<const U4u *>(buf + a); return make_uint4(v.x, v.y, v.z, v.w); }
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t x = 0; x < 16; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 8 <= buf_len) { const U2u v = *reinterpret_cast<const U2u *>(buf + a); return make_uint2(v.x, v.y); }
+    uint32_t w[2] = {0, 0};
+    for (uint32_t x = 0; x < 8; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint2(w[0], w[1]);
+}
+
+// 0x01 flags in bytes 0..3 -> bits 0..3
+__device__ __forceinline__ uint32_t t_movemask(uint32_t flags01) { return (flags01 * 0x01020408u) >> 24; }
+// per byte: 0x01 where the byte of x is non-zero
+__device__ __forceinline__ uint32_t t_nonzero01(uint32_t x)
+{
+    return ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7) & 0x01010101u;
+}
+__device__ __forceinline__ uint64_t t_lowbytes(uint32_t n)   // 0xFF in the n lowest bytes, n clamped to 0..8
+{
+    return n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull);
+}
+__device__ __forceinline__ uint64_t t_lowbits(uint32_t n)    // n lowest bits, n in 0..64
+{
+    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+}
+
+// 0xFF in the n lowest bytes of a dword, n clamped to 0..4
+__device__ __forceinline__ uint32_t t_lowbytes32(int32_t n)
+{
+    return n >= 4 ? ~0u : (n <= 0 ? 0u : ((1u << (8 * n)) - 1u));
+}
+
+}  // namespace ngsc
