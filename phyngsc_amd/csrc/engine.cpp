@@ -385,7 +385,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // tiled fast path: R records per tile (0 = records too long for the LDS budget -> untiled kernels)
     uint32_t r_max = 256;
     if (const char *ev = getenv("NGSC_TILE_RECORDS")) r_max = (uint32_t)atoi(ev);
-    const uint32_t R = tile_records_for(max_rec_bytes, r_max);
+    // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile"
+    // (NGSC_SQ_PATH=tile keeps the LDS-tiled kernels)
+    const char *sq_env = getenv("NGSC_SQ_PATH");
+    const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
+    const uint32_t R = sq_reg ? 256u : tile_records_for(max_rec_bytes, r_max);
     uint32_t n_tiles = 0;
     std::vector<uint32_t> tile_lo(S);
     for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
@@ -480,9 +484,6 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const bool t_swar = max_title <= 64 && !(tp_env && !strcmp(tp_env, "reg"));
     if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
     else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
-    // records of up to 2 KB: one lane per record straight from global memory (NGSC_SQ_PATH=tile keeps the LDS tiles)
-    const char *sq_env = getenv("NGSC_SQ_PATH");
-    const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
     if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
     else if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
@@ -492,7 +493,10 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
     { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
-    if (R) {
+    if (sq_reg) {
+        { KScope k(c, st, "k_sq_measure_reg"); launch_sq_measure_reg(st, A, max_rec); }
+        { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
+    } else if (R) {
         { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
         { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     } else {
@@ -534,7 +538,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
     { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
-    if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
+    if (sq_reg) { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec); }
+    else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
     HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

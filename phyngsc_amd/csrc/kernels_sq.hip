@@ -3,8 +3,11 @@
 // records, so every cache line that comes in is consumed by the wave that asked for it) and processed four
 // bytes per instruction where the format allows it.  No LDS tile, no barriers inside the record loop.
 //
-//   k_sq_stats_reg   N-transfer test, DNA symbol counts, per-position quality histogram   (phyNGSC.cpp:462-653,
-//                                                                                         tasks.cpp:260-286)
+//   k_sq_stats_reg    N-transfer test, DNA symbol counts, per-position quality histogram   (phyNGSC.cpp:462-653,
+//                                                                                          tasks.cpp:260-286)
+//   k_sq_measure_reg  quality / DNA payload bits per record and per 256-record tile
+//   k_sq_pack_reg     StoreQuality and StoreDNA payloads (tasks.cpp:544-557, 609-619): every lane merges up to
+//                     four codes per put, ORs whole words into LDS staging; one coalesced copy-out per stream
 //
 // The LDS-tiled kernels of kernels_tile.hip spent ~23 VALU instructions per input byte and wave on per-byte
 // index arithmetic; here the common case (all lanes inside their read, only A/C/G/T, qualities '!'..'`') costs
@@ -277,6 +280,377 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
     }
 }
 
+// ====================================================================================================
+// Measure / pack
+// ====================================================================================================
+// Quality code tables in LDS, indexed by the raw quality byte: column = q - 33 (64 columns), row = position
+// (tasks.cpp:609-619 uses Huffman tree j+1 for position j).  Bytes outside 33..96 - the transferred qualities
+// 128..247 among them - and rows past the LDS budget are looked up in the global table through qua_code.
+struct SqTabs {
+    const uint32_t *qg;     // global [qrows][256] by code index
+    const uint8_t *qcode;   // LDS [256] quality byte -> code index
+    const uint8_t *amb;     // LDS [256]
+    const uint32_t *dcode;  // LDS [256] base byte -> code << 5 | len
+    uint32_t lds_rows;
+};
+
+template <class T>
+__device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const SbState &sb, T *s_qtab, uint32_t lds_rows)
+{
+    const uint32_t nq = sb.nqual;
+    const uint32_t *qg = A.qcodes + (size_t)s * A.qrows * 256;
+    for (uint32_t k = threadIdx.x; k < lds_rows * SR_HCOLS; k += SR_THREADS) s_qtab[k] = 0;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < lds_rows * nq; k += SR_THREADS) {
+        const uint32_t row = k / nq, ci = k % nq;
+        const uint32_t col = (uint32_t)sb.qualities[ci] - 33u;
+        if (col < SR_HCOLS) {
+            const uint32_t e = qg[(size_t)row * 256 + ci];
+            s_qtab[row * SR_HCOLS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
+        }
+    }
+}
+
+// entry (code << 5 | len) of quality byte q at position row-1, any q, any row
+__device__ __forceinline__ uint32_t sq_qentry_slow(const SqTabs &T, uint32_t row, uint32_t q)
+{
+    return T.qg[(size_t)row * 256 + T.qcode[q]];
+}
+
+// ---- measure: payload bits per record and per 256-record tile ----
+__global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw)
+{
+    if (*A.err) return;
+    extern __shared__ __align__(16) uint8_t s_qlen[];   // [lds_rows][64] code lengths
+    __shared__ uint32_t s_dcode[256];
+    __shared__ uint8_t s_qcode[256], s_amb[256];
+    __shared__ uint32_t s_tot[2];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t ntiles = (n + SR_THREADS - 1) / SR_THREADS;
+    const uint32_t tile_first = blockIdx.x * tpw;
+    if (tile_first >= ntiles) return;
+    const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+
+    s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
+    s_qcode[tid] = sb.qua_code[tid];
+    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
+    if (tid < 2) s_tot[tid] = 0;
+    sq_fill_qtab(A, s, sb, s_qlen, lds_rows);
+    __syncthreads();
+    SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
+    const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
+    // code lengths of A, C, T, G (the order of (c >> 1) & 3) as a v_perm table
+    const uint32_t ltab = (s_dcode['A'] & 31u) | ((s_dcode['C'] & 31u) << 8) | ((s_dcode['T'] & 31u) << 16) | ((s_dcode['G'] & 31u) << 24);
+
+    for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
+        const uint32_t i = tile * SR_THREADS + tid;
+        const bool valid = i < n;
+        const uint32_t g = rec_lo + (valid ? i : 0);
+        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t L = valid ? se - te - 1 : 0;
+        const uint32_t s0 = te + 1, q0 = se + 3;
+        const uint32_t sl = valid ? A.slen[g] : 0;
+        const bool xfer = sl >> 31;
+        const bool need_s = !plain || __any(xfer);   // bases matter for the Huffman DNA lengths and for the transferred positions
+        uint32_t qb = 0, db = plain ? 2u * (sl & 0x7fffffffu) : 0u;
+        for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
+            const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
+            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
+            if (nv) {
+                Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
+                if (need_s) S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
+            }
+            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            uint32_t qbad = 0, dacc = 0, idx[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                qbad |= sr_q_out(qw[k]) & vm;
+                const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                idx[k] = sr_idx(w);
+                dacc |= sr_not_acgt(w, idx[k]);
+            }
+            const bool amb_here = need_s && dacc != 0;   // some non-ACGT base in this lane's chunk
+            const bool rows_ok = 16 * ch + 17 <= lds_rows;
+            const bool odd = qbad != 0 || (nv != 0 && nv != 16) || (xfer && amb_here);
+            // quality bits
+            if (rows_ok && !__any(odd)) {
+                if (nv) {
+                    const uint8_t *rowp = s_qlen + (16 * ch + 1) * SR_HCOLS - 33;
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u) qb += rowp[u * SR_HCOLS + sr_byte(qw, u)];
+                }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < 16; ++u) {
+                    if (u < nv) {
+                        uint32_t q = sr_byte(qw, u);
+                        const uint32_t row = 16 * ch + u + 1;
+                        if (xfer && amb_here) {
+                            const uint32_t a = s_amb[sr_byte(sw, u)];
+                            if (a > 1) q = transfer_quality(a, (uint8_t)q);   // phyNGSC.cpp:579
+                        }
+                        const uint32_t col = q - 33;
+                        qb += (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SR_HCOLS + col] : (sq_qentry_slow(T, row, q) & 31u);
+                    }
+                }
+            }
+            // DNA bits of a Huffman-coded alphabet (more than four symbols, tasks.cpp:525-557)
+            if (!plain) {
+                if (!__any(amb_here)) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                        db = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, 0u, db);
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u) {
+                        if (u < nv) {
+                            const uint32_t c = sr_byte(sw, u);
+                            if (!(xfer && s_amb[c] > 1)) db += s_dcode[c] & 31u;
+                        }
+                    }
+                }
+            }
+        }
+        const size_t tix = (size_t)A.tile_lo[s] + tile;
+        A.ubits[tix * SR_THREADS + tid] = qb | (db << 16);
+        const uint32_t wq = sr_wsum(qb), wd = sr_wsum(db);
+        if (lane == 0) { atomicAdd(&s_tot[0], wq); atomicAdd(&s_tot[1], wd); }
+        __syncthreads();
+        if (tid == 0) { A.wq[tix] = s_tot[0]; A.wd[tix] = s_tot[1]; s_tot[0] = 0; s_tot[1] = 0; }
+        __syncthreads();
+    }
+}
+
+// ---- pack ----
+// One lane's MSB-first bit writer into LDS staging (or, for a tile whose stream outgrows the staging area,
+// straight into the zeroed output).  Fewer than 32 bits stay pending, so a put of up to 32 bits fits the
+// 64-bit accumulator; complete big-endian words leave with an OR (a lane's first and last word are shared).
+struct SqWriter {
+    uint32_t *words;
+    uint64_t widx;
+    uint64_t acc;
+    uint32_t nacc;
+    __device__ __forceinline__ void init(uint32_t *w, uint64_t word0, uint64_t bitpos)
+    {
+        words = w;
+        widx = (bitpos >> 5) - word0;
+        acc = 0;
+        nacc = (uint32_t)(bitpos & 31);
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb)   // nb <= 32, v < 2^nb
+    {
+        acc = (acc << nb) | v;
+        nacc += nb;
+        if (nacc >= 32) {
+            const uint32_t word = (uint32_t)(acc >> (nacc - 32));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            ++widx;
+            nacc -= 32;
+            acc &= (1ull << nacc) - 1ull;
+        }
+    }
+    __device__ __forceinline__ void finish()
+    {
+        if (nacc) {
+            const uint32_t word = (uint32_t)(acc << (32 - nacc));
+            if (word) atomicOr(&words[widx], __builtin_bswap32(word));
+            nacc = 0;
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t sq_scan_excl256(uint32_t v, uint32_t *s_part)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    __syncthreads();   // s_part may still be read from the previous call
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t basev = 0;
+#pragma unroll
+    for (int w = 0; w < SR_THREADS / 64; ++w) basev += w < wave ? s_part[w] : 0;
+    return basev + incl - v;
+}
+
+__global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw)
+{
+    if (*A.err) return;
+    extern __shared__ __align__(16) uint32_t s_dynw[];   // [lds_rows][64] quality entries | staging (quality sw_q, DNA sw_d words)
+    __shared__ uint32_t s_dcode[256];
+    __shared__ uint8_t s_qcode[256], s_amb[256];
+    __shared__ uint32_t s_part[SR_THREADS / 64];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t ntiles = (n + SR_THREADS - 1) / SR_THREADS;
+    const uint32_t tile_first = blockIdx.x * tpw;
+    if (tile_first >= ntiles) return;
+    const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
+    const int tid = threadIdx.x;
+    uint32_t *s_qtab = s_dynw;
+    uint32_t *st_q = s_dynw + lds_rows * SR_HCOLS, *st_d = st_q + sw_q;
+
+    s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
+    s_qcode[tid] = sb.qua_code[tid];
+    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
+    sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
+    __syncthreads();
+    SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
+    const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
+    const uint32_t eA = s_dcode['A'], eC = s_dcode['C'], eT = s_dcode['T'], eG = s_dcode['G'];
+    const uint32_t ltab = (eA & 31u) | ((eC & 31u) << 8) | ((eT & 31u) << 16) | ((eG & 31u) << 24);
+    const uint32_t ctab = ((eA >> 5) & 0xffu) | (((eC >> 5) & 0xffu) << 8) | (((eT >> 5) & 0xffu) << 16) | (((eG >> 5) & 0xffu) << 24);
+    // four Huffman base codes can be merged bytewise when each is at most 8 bits long
+    const bool short_codes = (eA & 31u) <= 8 && (eC & 31u) <= 8 && (eT & 31u) <= 8 && (eG & 31u) <= 8;
+    uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
+    const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
+    const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
+
+    for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
+        __syncthreads();   // the previous tile's copy-out is done
+        for (uint32_t k = tid; k < sw_q + sw_d; k += SR_THREADS) st_q[k] = 0;
+        const bool last_tile = tile + 1 == ntiles;
+        const size_t tix = (size_t)A.tile_lo[s] + tile;
+        const uint64_t qb0 = qbase + A.wq[tix], qb1 = qbase + (last_tile ? sb.qbits : A.wq[tix + 1]);
+        const uint64_t db0 = dbase + A.wd[tix], db1 = dbase + (last_tile ? sb.dbits : A.wd[tix + 1]);
+        const uint64_t qw0 = qb0 >> 5, dw0 = db0 >> 5;
+        const uint32_t qnw = (uint32_t)(((qb1 + 31) >> 5) - qw0), dnw = (uint32_t)(((db1 + 31) >> 5) - dw0);
+        const bool q_lds = qnw + 1 <= sw_q, d_lds = dnw + 1 <= sw_d;   // else: straight into the zeroed output
+
+        const uint32_t i = tile * SR_THREADS + tid;
+        const bool valid = i < n;
+        const uint32_t g = rec_lo + (valid ? i : 0);
+        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t L = valid ? se - te - 1 : 0;
+        const uint32_t s0 = te + 1, q0 = se + 3;
+        const bool xfer = valid ? (A.slen[g] >> 31) : false;
+        const uint32_t ub = A.ubits[tix * SR_THREADS + tid];
+        const uint32_t qo = sq_scan_excl256(ub & 0xffffu, s_part);
+        const uint32_t dofs = sq_scan_excl256(ub >> 16, s_part);   // (its first barrier also orders the staging clear)
+        SqWriter wq_, wd_;
+        wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
+        wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
+
+        for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
+            const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
+            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
+            if (nv) {
+                S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
+                Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
+            }
+            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            uint32_t qbad = 0, dacc = 0, idx[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                qbad |= sr_q_out(qw[k]) & vm;
+                const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                idx[k] = sr_idx(w);
+                dacc |= sr_not_acgt(w, idx[k]);
+            }
+            const bool amb_here = dacc != 0;
+            const bool rows_ok = 16 * ch + 17 <= lds_rows;
+            const bool odd = qbad != 0 || (nv != 0 && nv != 16) || (xfer && amb_here);
+
+            // ---- quality (tasks.cpp:609-619) ----
+            if (rows_ok && !__any(odd)) {
+                if (nv) {
+                    const uint32_t *rowp = s_qtab + (16 * ch + 1) * SR_HCOLS - 33;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {   // four symbols per put when their codes fit 32 bits together
+                        const uint32_t e0 = rowp[(4 * k + 0) * SR_HCOLS + sr_byte(qw, 4 * k + 0)];
+                        const uint32_t e1 = rowp[(4 * k + 1) * SR_HCOLS + sr_byte(qw, 4 * k + 1)];
+                        const uint32_t e2 = rowp[(4 * k + 2) * SR_HCOLS + sr_byte(qw, 4 * k + 2)];
+                        const uint32_t e3 = rowp[(4 * k + 3) * SR_HCOLS + sr_byte(qw, 4 * k + 3)];
+                        const uint32_t l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
+                        const uint32_t tl = (e0 & 31u) + l1 + l2 + l3;
+                        if (__any(tl > 32)) {
+                            wq_.put(e0 >> 5, e0 & 31u); wq_.put(e1 >> 5, l1); wq_.put(e2 >> 5, l2); wq_.put(e3 >> 5, l3);
+                        } else {
+                            wq_.put(((((((e0 >> 5) << l1) | (e1 >> 5)) << l2) | (e2 >> 5)) << l3) | (e3 >> 5), tl);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < 16; ++u) {
+                    if (u < nv) {
+                        uint32_t q = sr_byte(qw, u);
+                        const uint32_t row = 16 * ch + u + 1;
+                        if (xfer && amb_here) {
+                            const uint32_t a = s_amb[sr_byte(sw, u)];
+                            if (a > 1) q = transfer_quality(a, (uint8_t)q);
+                        }
+                        const uint32_t col = q - 33;
+                        const uint32_t e = (col < SR_HCOLS && row < lds_rows) ? s_qtab[row * SR_HCOLS + col] : sq_qentry_slow(T, row, q);
+                        wq_.put(e >> 5, e & 31u);
+                    }
+                }
+            }
+
+            // ---- DNA (tasks.cpp:544-557) ----
+            if (!__any(amb_here) && (plain || short_codes)) {
+                if (nv) {
+                    if (plain) {
+                        // two bits per base: the four code bytes of a dword collapse with one multiply
+                        uint32_t x = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k)
+                            x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
+                        wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
+                    } else {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                            const uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vm;
+                            const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
+                            const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
+                            wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < 16; ++u) {
+                    if (u < nv) {
+                        const uint32_t c = sr_byte(sw, u);
+                        if (!(xfer && s_amb[c] > 1)) { const uint32_t e = s_dcode[c]; wd_.put(e >> 5, e & 31u); }
+                    }
+                }
+            }
+        }
+        if (L) { wq_.finish(); wd_.finish(); }
+        __syncthreads();
+        if (q_lds) {
+            for (uint32_t k = tid; k < qnw; k += SR_THREADS) {
+                const uint64_t w = qw0 + k;
+                const uint32_t v = st_q[k];
+                if ((w << 5) >= qb0 && ((w + 1) << 5) <= qb1) outw[w] = v;
+                else if (v) atomicOr(&outw[w], v);
+            }
+        }
+        if (d_lds) {
+            for (uint32_t k = tid; k < dnw; k += SR_THREADS) {
+                const uint64_t w = dw0 + k;
+                const uint32_t v = st_d[k];
+                if ((w << 5) >= db0 && ((w + 1) << 5) <= db1) outw[w] = v;
+                else if (v) atomicOr(&outw[w], v);
+            }
+        }
+    }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 static uint32_t sr_records_per_wg()
 {
@@ -294,6 +668,37 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const size_t lds = (size_t)rows * SR_HSTRIDE * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_stats_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
     hipLaunchKernelGGL(k_sq_stats_reg, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
+}
+
+static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)
+{
+    const uint32_t max_rows = budget / (SR_HCOLS * entry_bytes);
+    return qrows < max_rows ? qrows : max_rows;
+}
+
+void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
+    const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
+    dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
+    hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS, st, A, rows, tpw);
+}
+
+void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+{
+    const uint32_t rows = sr_rows_for(A.qrows, 4, 48u << 10);
+    // staging sized for typical streams (5 bits per quality symbol, 3 per base); a tile that needs more writes
+    // straight to the zeroed output with atomics
+    const uint32_t maxq = A.qrows - 1;
+    uint32_t sw_q = (uint32_t)(((uint64_t)SR_THREADS * maxq * 5) / 32) + 64;
+    uint32_t sw_d = (uint32_t)(((uint64_t)SR_THREADS * maxq * 3) / 32) + 64;
+    if (sw_q > 8192) sw_q = 8192;
+    if (sw_d > 6144) sw_d = 6144;
+    const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
+    dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
+    const size_t lds = ((size_t)rows * SR_HCOLS + sw_q + sw_d) * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_pack_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+    hipLaunchKernelGGL(k_sq_pack_reg, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw);
 }
 
 }  // namespace ngsc

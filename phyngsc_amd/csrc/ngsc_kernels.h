@@ -21,6 +21,8 @@ void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_l
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 
 // ---- kernels_stats.hip ----
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
