@@ -323,12 +323,9 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         launch_nl_write(st, buf, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_cap);
     }
     {
-        KScope k(c, st, "k_validate");
-        launch_validate(st, buf, d_te, d_se, d_ls, n_rec_total, d_maxq, d_maxrec, d_maxtitle, d_err);
-    }
-    {
-        KScope k(c, st, "k_cuts");
-        launch_cuts(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_ls, d_total, d_first, d_cuts, max_cuts, d_plans, d_err);
+        KScope k(c, st, "k_cuts_validate");
+        launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, n_rec_total, d_total, d_first, d_cuts,
+                             max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err);
     }
     // ---- sync 2: cut list ----
     size_t plan_bytes = cs.off - o_plans;

@@ -141,23 +141,22 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
         }
         uint32_t line = line_base + wbase + incl - c;
         line_base += total;
-        if (c) {
+        // one bit per byte of the thread's 32 bytes, then a single walk over the set bits (a 36-bp record has a
+        // newline every ~29 bytes, so the walk is 1-2 steps; eight separate per-word walks cost 4x the VALU work)
+        uint32_t m = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                uint32_t f = flags[i];
-                while (f) {
-                    uint32_t k = (uint32_t)(__ffs(f) - 1) >> 3;
-                    f &= f - 1;
-                    uint32_t pos = base + i * 4 + k;
-                    uint32_t r = line >> 2, kind = line & 3;
-                    if (r < rec_cap) {
-                        if (kind == 0) te[r] = pos;
-                        else if (kind == 1) se[r] = pos;
-                        else if (kind == 3) ls[r + 1] = pos + 1;
-                    }
-                    ++line;
-                }
+        for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
+        while (m) {
+            const uint32_t k = (uint32_t)__ffs(m) - 1;
+            m &= m - 1;
+            const uint32_t pos = base + k;
+            const uint32_t r = line >> 2, kind = line & 3;
+            if (r < rec_cap) {
+                if (kind == 0) te[r] = pos;
+                else if (kind == 1) se[r] = pos;
+                else if (kind == 3) ls[r + 1] = pos + 1;
             }
+            ++line;
         }
     }
 }
@@ -165,35 +164,33 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
 // Structural validation of every record + job-wide max quality length and record size.
 //   quality length must equal sequence length (README.md:97-103); line 2 == "+" is checked later.
 // The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
-__global__ __launch_bounds__(256) void k_validate(const uint8_t *buf, const uint32_t *te, const uint32_t *se,
-                                                  const uint32_t *ls, uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec,
-                                                  uint32_t *max_title, int32_t *err)
+__device__ __forceinline__ void validate_records(const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec,
+                                                 uint32_t first, uint32_t stride, uint32_t *max_q, uint32_t *max_rec,
+                                                 uint32_t *max_title, int32_t *err)
 {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t L = 0, RB = 0, TL = 0;
+    uint32_t mq = 0, mr = 0, mt = 0;
     bool bad = false;
-    if (r < n_rec) {
-        uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
-        L = s - t - 1;
-        RB = l1 - l0;
-        TL = t - l0 + 1;
-        // the bare '+' line is checked by the statistics kernels, which have the bytes in LDS anyway
-        bad = !(t >= l0 && s > t) || l1 != 2 * s - t + 3;
+    for (uint32_t r = first; r < n_rec; r += stride) {
+        const uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
+        const uint32_t L = s - t - 1, RB = l1 - l0, TL = t - l0 + 1;
+        // the bare '+' line is checked by the statistics kernels, which read the bytes anyway
+        bad = bad || !(t >= l0 && s > t) || l1 != 2 * s - t + 3;
+        mq = L > mq ? L : mq;
+        mr = RB > mr ? RB : mr;
+        mt = TL > mt ? TL : mt;
     }
     if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
-    uint32_t m = L;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
-    // same-address atomics serialise (~180 M/s): only the few waves that raise the maximum issue one
-    if ((threadIdx.x & 63) == 0 && m > *max_q) atomicMax(max_q, m);
-    uint32_t mb = RB;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mb, d); mb = o > mb ? o : mb; }
-    if ((threadIdx.x & 63) == 0 && mb > *max_rec) atomicMax(max_rec, mb);
-    uint32_t mt = TL;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mt, d); mt = o > mt ? o : mt; }
-    if ((threadIdx.x & 63) == 0 && mt > *max_title) atomicMax(max_title, mt);
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = __shfl_xor(mq, d); mq = o > mq ? o : mq;
+        o = __shfl_xor(mr, d); mr = o > mr ? o : mr;
+        o = __shfl_xor(mt, d); mt = o > mt ? o : mt;
+    }
+    if ((threadIdx.x & 63) == 0) {   // same-address atomics serialise: only waves that raise a maximum issue one
+        if (mq > *max_q) atomicMax(max_q, mq);
+        if (mr > *max_rec) atomicMax(max_rec, mr);
+        if (mt > *max_title) atomicMax(max_title, mt);
+    }
 }
 
 // First-record synchronisation of every virtual rank > 0 (phyNGSC.cpp:131-156): first '@' at or after
@@ -238,19 +235,27 @@ __global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t 
     }
 }
 
-// Sub-block cuts: one thread per rank (binary searches over the record table; see plan_rank()).
-__global__ __launch_bounds__(64) void k_cuts(uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks,
-                                             uint64_t buf_off, const uint32_t *te, const uint32_t *ls,
-                                             const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
-                                             uint32_t max_cuts, RankPlan *plans, int32_t *err)
+// One launch, two jobs that do not depend on each other: workgroups [0, n_ranks) plan the sub-block cuts of
+// one rank each (a serial chain of binary searches over the record table, see plan_rank()), the others
+// validate the structure of every record and reduce the job-wide maxima while those chains run.
+__global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks,
+                                                       uint64_t buf_off, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
+                                                       const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
+                                                       uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
+                                                       uint32_t *max_title, int32_t *err)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_ranks) return;
-    uint32_t n_rec_total = *total_lines / 4;
-    int rc = plan_rank(file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i], cuts + (size_t)i * max_cuts,
-                       max_cuts, &plans[i]);
-    plans[i].err = rc;
-    if (rc) atomicMin(err, (int32_t)rc);
+    const uint32_t n_rec_total = *total_lines / 4;
+    if (blockIdx.x < n_ranks) {
+        if (threadIdx.x) return;
+        const uint32_t i = blockIdx.x;
+        int rc = plan_rank(file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i], cuts + (size_t)i * max_cuts,
+                           max_cuts, &plans[i]);
+        plans[i].err = rc;
+        if (rc) atomicMin(err, (int32_t)rc);
+        return;
+    }
+    const uint32_t vb = blockIdx.x - n_ranks, nvb = gridDim.x - n_ranks;
+    validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err);
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
@@ -281,21 +286,16 @@ void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uin
     hipLaunchKernelGGL(k_nl_write, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_off, te, se, ls, rec_cap);
 }
 
-void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
-                     uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, uint32_t *max_title, int32_t *err)
+void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
+                          const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
+                          const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err)
 {
-    if (!n_rec) return;
-    hipLaunchKernelGGL(k_validate, dim3((n_rec + 255) / 256), dim3(256), 0, st, buf, te, se, ls, n_rec, max_q, max_rec,
-                       max_title, err);
-}
-
-void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
-                 const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
-                 uint32_t max_cuts, RankPlan *plans, int32_t *err)
-{
-    // one workgroup per rank so that the ranks' dependent search chains run on different CUs
-    hipLaunchKernelGGL(k_cuts, dim3(n_ranks), dim3(1), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, ls,
-                       total_lines, first_abs, cuts, max_cuts, plans, err);
+    // 8 records per validating thread: few fat workgroups instead of one tiny wave per 64 records
+    uint32_t vblocks = (n_rec + 2047) / 2048;
+    if (vblocks < 1) vblocks = 1;
+    hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err);
 }
 
 }  // namespace ngsc

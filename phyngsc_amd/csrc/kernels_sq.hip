@@ -99,11 +99,14 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         boff[b] = bb * SR_HSTRIDE * 4;
     }
 
+    uint32_t te_n = 0, se_n = 0;   // the next batch's record table entries are fetched one batch ahead
+    if (first + tid < last) { te_n = A.te[rec_lo + first + tid]; se_n = A.se[rec_lo + first + tid]; }
     for (uint32_t base = first; base < last; base += SR_THREADS) {
         const uint32_t i = base + tid;
         const bool valid = i < last;
         const uint32_t g = rec_lo + (valid ? i : first);
-        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t te = te_n, se = se_n;
+        if (i + SR_THREADS < last) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; }
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
         if (valid) {
@@ -117,12 +120,18 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
 
         // ---- one pass over the 16-byte chunks: everything except the ambiguous positions ----
         uint32_t fl = 0, namb = 0;   // N-transfer test (phyNGSC.cpp:549-571): bit0 some ambiguity code, bit1 a failure
+        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
+        if (L) {
+            Sn = load16_unaligned(A.buf, s0, A.buf_len);
+            Qn = load16_unaligned(A.buf, q0, A.buf_len);
+        }
         for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
             const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
-            if (nv) {
-                S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
-                Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
+            const uint4 S = Sn, Q = Qn;
+            Sn = Qn = make_uint4(0, 0, 0, 0);
+            if (L > 16 * ch + 16) {
+                Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
+                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
             uint32_t d[4], idx[4], dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
@@ -345,23 +354,35 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
     // code lengths of A, C, T, G (the order of (c >> 1) & 3) as a v_perm table
     const uint32_t ltab = (s_dcode['A'] & 31u) | ((s_dcode['C'] & 31u) << 8) | ((s_dcode['T'] & 31u) << 16) | ((s_dcode['G'] & 31u) << 24);
 
+    uint32_t te_n = 0, se_n = 0, sl_n = 0;   // the next tile's record table entries are fetched one tile ahead
+    if (tile_first * SR_THREADS + tid < n) {
+        const uint32_t g0 = rec_lo + tile_first * SR_THREADS + tid;
+        te_n = A.te[g0]; se_n = A.se[g0]; sl_n = A.slen[g0];
+    }
     for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
         const uint32_t i = tile * SR_THREADS + tid;
         const bool valid = i < n;
         const uint32_t g = rec_lo + (valid ? i : 0);
-        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t te = te_n, se = se_n;
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
-        const uint32_t sl = valid ? A.slen[g] : 0;
+        const uint32_t sl = valid ? sl_n : 0;
+        if (tile + 1 < tile_last && i + SR_THREADS < n) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; sl_n = A.slen[g + SR_THREADS]; }
         const bool xfer = sl >> 31;
         const bool need_s = !plain || __any(xfer);   // bases matter for the Huffman DNA lengths and for the transferred positions
         uint32_t qb = 0, db = plain ? 2u * (sl & 0x7fffffffu) : 0u;
+        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
+        if (L) {
+            Qn = load16_unaligned(A.buf, q0, A.buf_len);
+            if (need_s) Sn = load16_unaligned(A.buf, s0, A.buf_len);
+        }
         for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
             const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
-            if (nv) {
-                Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
-                if (need_s) S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
+            const uint4 S = Sn, Q = Qn;
+            Sn = Qn = make_uint4(0, 0, 0, 0);
+            if (L > 16 * ch + 16) {
+                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
+                if (need_s) Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
             uint32_t qbad = 0, dacc = 0, idx[4];
@@ -517,6 +538,12 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
 
+    uint32_t te_n = 0, se_n = 0, sl_n = 0, ub_n = 0;   // the next tile's per-record entries are fetched one tile ahead
+    if (tile_first * SR_THREADS + tid < n) {
+        const uint32_t g0 = rec_lo + tile_first * SR_THREADS + tid;
+        te_n = A.te[g0]; se_n = A.se[g0]; sl_n = A.slen[g0];
+    }
+    ub_n = A.ubits[((size_t)A.tile_lo[s] + tile_first) * SR_THREADS + tid];
     for (uint32_t tile = tile_first; tile < tile_last; ++tile) {
         __syncthreads();   // the previous tile's copy-out is done
         for (uint32_t k = tid; k < sw_q + sw_d; k += SR_THREADS) st_q[k] = 0;
@@ -531,23 +558,33 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
         const uint32_t i = tile * SR_THREADS + tid;
         const bool valid = i < n;
         const uint32_t g = rec_lo + (valid ? i : 0);
-        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t te = te_n, se = se_n;
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
-        const bool xfer = valid ? (A.slen[g] >> 31) : false;
-        const uint32_t ub = A.ubits[tix * SR_THREADS + tid];
+        const bool xfer = valid ? (sl_n >> 31) : false;
+        const uint32_t ub = ub_n;
+        if (tile + 1 < tile_last) {
+            if (i + SR_THREADS < n) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; sl_n = A.slen[g + SR_THREADS]; }
+            ub_n = A.ubits[(tix + 1) * SR_THREADS + tid];
+        }
         const uint32_t qo = sq_scan_excl256(ub & 0xffffu, s_part);
         const uint32_t dofs = sq_scan_excl256(ub >> 16, s_part);   // (its first barrier also orders the staging clear)
         SqWriter wq_, wd_;
         wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
         wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
 
+        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
+        if (L) {
+            Sn = load16_unaligned(A.buf, s0, A.buf_len);
+            Qn = load16_unaligned(A.buf, q0, A.buf_len);
+        }
         for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
             const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
-            if (nv) {
-                S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
-                Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
+            const uint4 S = Sn, Q = Qn;
+            Sn = Qn = make_uint4(0, 0, 0, 0);
+            if (L > 16 * ch + 16) {
+                Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
+                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
             uint32_t qbad = 0, dacc = 0, idx[4];

@@ -13,11 +13,10 @@ void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uin
 void launch_scan_tiles(hipStream_t st, uint32_t *tile_cnt, uint32_t n_tiles, uint32_t *total_lines);
 void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, const uint32_t *tile_off,
                      uint32_t *te, uint32_t *se, uint32_t *ls, uint32_t rec_cap);
-void launch_validate(hipStream_t st, const uint8_t *buf, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
-                     uint32_t n_rec, uint32_t *max_q, uint32_t *max_rec, uint32_t *max_title, int32_t *err);
-void launch_cuts(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
-                 const uint32_t *te, const uint32_t *ls, const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
-                 uint32_t max_cuts, RankPlan *plans, int32_t *err);
+void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
+                          const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
+                          const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err);
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
