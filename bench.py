@@ -47,6 +47,14 @@ def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
         "k_nl_count": raw,
         "k_nl_write": raw + 12 * n_rec,
         "k_validate": 12 * n_rec,
+        "k_cuts_validate": 16 * n_rec,
+        # register-streaming kernels (one lane per record): record table entries + the bytes they parse
+        "k_title_stats_swar": title_in + 8 * n_rec + 8 * n_rec,           # ls/te in, separator mask out
+        "k_title_measure_swar": 8 * n_rec + 8 * n_rec + ncf_words + 4 * n_rec + title_in // 4,  # masks + numeric fields only
+        "k_sq_stats_reg": 2 * bases + 8 * n_rec + 4 * n_rec,              # te/se in, slen out
+        "k_sq_measure_reg": bases + 12 * n_rec + 4 * n_rec,               # qualities only (2-bit DNA needs no bases)
+        "k_sq_pack_reg": 2 * bases + 16 * n_rec + sq_out,
+        # byte-serial / LDS-tiled fallbacks
         "k_title_stats_reg": title_in,
         "k_title_measure_reg": title_in + ncf_words + 4 * n_rec,
         "k_title_pack_reg": ncf_words + 4 * n_rec + title_out,
@@ -149,7 +157,17 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
+    # untimed pass with an event pair around EVERY kernel: the per-kernel table, and which kernel dominates
     eng.set_profiling(True)
+    eng.reset_kernel_times()
+    for _ in range(2):
+        res = step()
+    torch.cuda.synchronize()
+    ktimes_all = eng.kernel_times()
+    dom = max(ktimes_all, key=lambda k: ktimes_all[k][0] / max(ktimes_all[k][1], 1))
+    # timed region: only the dominant kernel carries HIP events (two records per step; an event pair around each
+    # of the ~30 launches costs ~0.3 ms per step in launch gaps)
+    eng.profile_only(dom)
     eng.reset_kernel_times()
     barrier()
     t0 = time.perf_counter()
@@ -158,6 +176,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
+    eng.profile_only(None)
     if world > 1:
         # the one data-path-free collective: block sizes -> file offsets (RCCL all-gather over xGMI)
         sizes_local = [[b.size for b in api.plan_blocks(P, rk.rank, [res.subblocks[rk.first_subblock + k].size
@@ -177,9 +196,9 @@ def main():
     ktimes = eng.kernel_times()
     if rank == 0:
         alg = algorithmic_bytes(res, my_raw)
-        per_kernel = {k: {"ms_avg": ms / max(n, 1), "launches": n} for k, (ms, n) in ktimes.items() if n}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_avg"])
-        dom_ms = per_kernel[dom]["ms_avg"]
+        per_kernel = {k: {"ms_avg": ms / max(n, 1), "launches": n} for k, (ms, n) in ktimes_all.items() if n}
+        dom_ms = ktimes[dom][0] / max(ktimes[dom][1], 1)   # measured inside the timed region
+        per_kernel[dom]["ms_avg"] = dom_ms
         achieved = alg.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")

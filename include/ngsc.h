@@ -103,6 +103,8 @@ int ngsc_ctx_device(ngsc_ctx *ctx); /* the HIP device the context was created on
 
 /* Per-kernel device timing (hipEvent pairs around every launch). Off by default. */
 int ngsc_set_profiling(ngsc_ctx *ctx, int enable);
+int ngsc_profile_only(ngsc_ctx *ctx, const char *kernel_name); /* time just this kernel (NULL: all); event records
+                                                                  * between launches cost ~10 us each */
 int ngsc_reset_kernel_times(ngsc_ctx *ctx);
 uint32_t ngsc_get_kernel_times(ngsc_ctx *ctx, ngsc_kernel_time_t *out, uint32_t cap);
 

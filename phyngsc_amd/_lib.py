@@ -17,7 +17,7 @@ EXPORTS = [
     "ngsc_set_profiling", "ngsc_reset_kernel_times", "ngsc_get_kernel_times", "ngsc_compress_device",
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
-    "ngsc_compress_file_multi", "ngsc_ctx_device",
+    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -81,6 +81,7 @@ def lib():
     L.ngsc_last_hip_error.argtypes = [vp]
     L.ngsc_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ngsc_reset_kernel_times.argtypes = [vp]
+    L.ngsc_profile_only.argtypes = [vp, ctypes.c_char_p]
     L.ngsc_get_kernel_times.restype = u32
     L.ngsc_get_kernel_times.argtypes = [vp, ctypes.POINTER(KernelTime), u32]
     L.ngsc_compress_device.restype = ctypes.c_int

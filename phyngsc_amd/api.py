@@ -74,6 +74,10 @@ class Engine:
     def set_profiling(self, on: bool):
         self._L.ngsc_set_profiling(self._h, int(on))
 
+    def profile_only(self, kernel_name):
+        """Time just this kernel (None: all of them): every timed launch costs two event records (~10 us)."""
+        self._L.ngsc_profile_only(self._h, kernel_name.encode() if kernel_name else None)
+
     def reset_kernel_times(self):
         self._L.ngsc_reset_kernel_times(self._h)
 

@@ -43,6 +43,7 @@ struct ngsc_ctx {
     hipStream_t own_stream = nullptr;
     std::string hip_err;
     bool profiling = false;
+    std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
 
@@ -110,6 +111,7 @@ struct KScope {
     KScope(ngsc_ctx *ctx, hipStream_t s, const char *name) : c(ctx), st(s)
     {
         if (!c->profiling) return;
+        if (!c->profile_only.empty() && c->profile_only != name) return;
         for (size_t i = 0; i < c->ktimes.size(); ++i)
             if (c->ktimes[i].name == name || !strcmp(c->ktimes[i].name, name)) idx = (int)i;
         if (idx < 0) {
@@ -210,6 +212,13 @@ int ngsc_set_profiling(ngsc_ctx *c, int enable)
 {
     if (!c) return NGSC_ERR_ARG;
     c->profiling = enable != 0;
+    return NGSC_OK;
+}
+
+int ngsc_profile_only(ngsc_ctx *c, const char *kernel_name)
+{
+    if (!c) return NGSC_ERR_ARG;
+    c->profile_only = kernel_name ? kernel_name : "";
     return NGSC_OK;
 }
 
