@@ -41,6 +41,8 @@ struct KTime {
 struct ngsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;          // title kernels run here, beside the sequence/quality kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string hip_err;
     bool profiling = false;
     std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
@@ -183,7 +185,10 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return NGSC_ERR_HIP;
     ngsc_ctx *c = new ngsc_ctx();
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return NGSC_ERR_HIP;
     }
@@ -201,6 +206,9 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
     collect_times(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -483,32 +491,51 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     memcpy(h_grp + S, tile_lo.data(), 4 * (size_t)S);
     HIPCHK(c, hipMemcpyAsync(A.tile_lo, h_grp + S, 4 * (size_t)S, hipMemcpyHostToDevice, st));
 
-    // ---- stage C ----
-    { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
+    // ---- stage C: statistics, trees, measure.  The title chain and the sequence/quality chain share nothing
+    // until the trees are built, so they run on two streams (one is VALU-bound, the other waits on memory). ----
+    const char *ov_env = getenv("NGSC_OVERLAP");
+    const bool overlap = !(ov_env && !strcmp(ov_env, "0"));
+    hipStream_t st2 = overlap ? c->side_stream : st;
+    auto fork = [&]() -> int {
+        if (!overlap) return NGSC_OK;
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(st2, c->ev_fork, 0));
+        return NGSC_OK;
+    };
+    auto join = [&]() -> int {
+        if (!overlap) return NGSC_OK;
+        HIPCHK(c, hipEventRecord(c->ev_join, st2));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        return NGSC_OK;
+    };
     // titles of at most 64 bytes take the word-parallel kernels (NGSC_TITLE_PATH=reg forces the byte-serial ones)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
     const bool t_swar = max_title <= 64 && !(tp_env && !strcmp(tp_env, "reg"));
-    if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
-    else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+    if ((rc = fork())) return rc;
+    { KScope k(c, st2, "k_rec0_fields"); launch_rec0_fields(st2, A); }
+    if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec); }
+    else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
+    { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
+    { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec); }
     if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
     else if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
-    { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
-    { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec); }
+    if ((rc = join())) return rc;
     { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-    { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
+    if ((rc = fork())) return rc;
+    { KScope k(c, st2, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st2, A, max_rec, t_swar); }
     if (sq_reg) {
         { KScope k(c, st, "k_sq_measure_reg"); launch_sq_measure_reg(st, A, max_rec); }
-        { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     } else if (R) {
         { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
-        { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     } else {
         { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
-        { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     }
+    if ((rc = join())) return rc;
+    if (R) { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
+    else { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
     // ---- sync 3: sizes ----
     HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, st));
@@ -543,10 +570,12 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)std::min<uint64_t>(out_cap, (total + 15) & ~15ull), st));
     { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
-    { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
+    if ((rc = fork())) return rc;
+    { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
     if (sq_reg) { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec); }
     else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    if ((rc = join())) return rc;
     HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());

@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t sr_amb_mask(const uint32_t (&sw)[4], uint32_
 __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw)
 {
     if (*A.err) return;
-    extern __shared__ __align__(16) uint32_t s_hist[];   // [lds_rows][SR_HSTRIDE]
+    extern __shared__ __align__(16) uint32_t s_hist[];   // [lds_rows][SR_HSTRIDE], then 64 trash words
     __shared__ uint32_t s_occ[256];
     __shared__ uint8_t s_amb[256];
     __shared__ uint32_t s_red[3];
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
 
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     uint8_t *hb = reinterpret_cast<uint8_t *>(s_hist);
+    const uint32_t trash = (hwords + lane) * 4;   // 64 words after the histogram
     uint32_t t0 = 0, t1 = 0, t01 = 0, nok = 0, mq = 0, ms = 0, sum_l = 0;   // per-lane totals over this workgroup's records
     const uint32_t lj = lane & 3;                                            // rotation of the quality bytes: word ...
     uint32_t bsh[4], boff[4];                                                // ... and byte inside the word
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         const uint32_t s0 = te + 1, q0 = se + 3;
         if (valid) {
             // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it
-            if (A.buf[se + 1] != '+' || A.buf[se + 2] != '\n') atomicMin(A.err, (int32_t)ERR_FORMAT);
+            // (bytes se .. se+3 are "\n+\n" and the first quality byte or the newline of an empty quality line)
+            if ((load4_unaligned(A.buf, se) & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
             if (i == 0 && L >= 2) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
                 const uint8_t c1 = A.buf[s0 + 1];
                 if (c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
@@ -134,9 +136,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                 Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
-            uint32_t d[4], idx[4], dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
+            uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
+            const bool wany[4] = {true, (bool)__any(nv > 4), (bool)__any(nv > 8), (bool)__any(nv > 12)};   // words any lane still needs
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
+                if (!wany[k]) continue;
                 const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
                 const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);   // bytes past the read count as 'A': no bits below
                 idx[k] = sr_idx(w);
@@ -150,6 +154,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
             }
             const bool rows_ok = 16 * ch + 17 <= lds_rows;
             const bool odd = dacc != 0 || qbad != 0 || (nv != 0 && nv != 16);
+            const unsigned long long live = __ballot(nv != 0);
+            const uint32_t nv_first = live ? (uint32_t)__builtin_amdgcn_readlane((int)nv, __builtin_ctzll(live)) : 0u;
             if (rows_ok && !__any(odd)) {
                 if (nv) {
                     // tasks.cpp:268-283: position histogram rows 1..max_q.  All lanes are at the same 16 positions, so
@@ -169,10 +175,22 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                     }
                     t0 += c0; t1 += c1; t01 += c01; nok += 16;
                 }
+            } else if (16 * ch + nv_first + 1 <= lds_rows && !__any(dacc != 0 || qbad != 0) && !__any(nv != 0 && nv != nv_first)) {
+                // the read tails of equally long reads: the same nv < 16 bytes in every lane, nothing odd about them
+                if (nv) {
+                    const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
+                    for (uint32_t u = 0; u < nv_first; ++u) {
+                        const uint32_t w = u < 4 ? qw[0] : (u < 8 ? qw[1] : (u < 12 ? qw[2] : qw[3]));
+                        const uint32_t q = (w >> (8 * (u & 3))) & 0xffu;
+                        atomicAdd(reinterpret_cast<uint32_t *>(hb + rb + u * SR_HSTRIDE * 4 + 4 * q), 1u);
+                    }
+                    t0 += c0; t1 += c1; t01 += c01; nok += nv;
+                }
             } else {
                 uint32_t ambm = 0, qbm = 0;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k) {
+                    if (!wany[k]) continue;
                     ambm |= t_movemask(t_nonzero01(d[k])) << (4 * k);
                     qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
                 }
@@ -195,16 +213,18 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                 }
                 t0 += c0; t1 += c1; t01 += c01; nok += nv - __builtin_popcount(ambm);
                 const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
-                if (__any(okm)) {
+                if (__any(okm)) {   // branch-free: bytes that do not count go to the lane's own trash word
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
                         const uint32_t j = (k + lj) & 3;
                         const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
                         const uint32_t joff = rb + j * (4 * SR_HSTRIDE * 4);
+                        const uint32_t okw = okm >> (4 * j);
 #pragma unroll
                         for (uint32_t b = 0; b < 4; ++b) {
                             const uint32_t q = (wsel >> bsh[b]) & 0xffu;
-                            if ((okm >> (4 * j + (bsh[b] >> 3))) & 1u) atomicAdd(reinterpret_cast<uint32_t *>(hb + joff + boff[b] + 4 * q), 1u);
+                            const uint32_t a = ((okw >> (bsh[b] >> 3)) & 1u) ? joff + boff[b] + 4 * q : trash;
+                            atomicAdd(reinterpret_cast<uint32_t *>(hb + a), 1u);
                         }
                     }
                 }
@@ -702,8 +722,8 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     if (rows > max_rows) rows = max_rows;
     const uint32_t rpw = sr_records_per_wg();
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
-    const size_t lds = (size_t)rows * SR_HSTRIDE * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_stats_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+    const size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
+    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_stats_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
     hipLaunchKernelGGL(k_sq_stats_reg, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
 }
 
@@ -734,7 +754,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     const size_t lds = ((size_t)rows * SR_HCOLS + sw_q + sw_d) * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_pack_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_pack_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
     hipLaunchKernelGGL(k_sq_pack_reg, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw);
 }
 

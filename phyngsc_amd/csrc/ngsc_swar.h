@@ -28,6 +28,9 @@ __device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a,
     return make_uint2(w[0], w[1]);
 }
 
+struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
+__device__ __forceinline__ uint32_t load4_unaligned(const uint8_t *buf, uint32_t a) { return reinterpret_cast<const U1u *>(buf + a)->x; }
+
 // 0x01 flags in bytes 0..3 -> bits 0..3
 __device__ __forceinline__ uint32_t t_movemask(uint32_t flags01) { return (flags01 * 0x01020408u) >> 24; }
 // per byte: 0x01 where the byte of x is non-zero
