@@ -411,6 +411,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
     size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
     size_t p_tw = cp.take(4 * (size_t)NCF_CAP * rec_cap);
+    size_t p_tv = cp.take(4 * (size_t)NUM_CAND_CAP * rec_cap);
     size_t p_rec0 = cp.take(sizeof(Rec0Tab) * (size_t)S);
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
@@ -438,6 +439,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.wd = (uint32_t *)(pb + p_wd);
     A.ubits = (uint32_t *)(pb + p_ubits);
     A.tw = (uint32_t *)(pb + p_tw);
+    A.tv = (uint32_t *)(pb + p_tv);
     A.tw_stride = (uint32_t)rec_cap;
     A.rec0 = (Rec0Tab *)(pb + p_rec0);
     A.tile_lo = (uint32_t *)(pb + p_tilelo);

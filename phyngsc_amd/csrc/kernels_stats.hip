@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
     uint32_t p = A.ls[sb.rec_lo], e = 0;
     for (uint32_t k = 0; k <= f; ++k) { e = field_end(buf, p); if (k < f) p = e + 1; }
     FieldDesc d;
-    for (int k = 0; k < 4; ++k) d.pad[k] = 0;
+    for (int k = 0; k < 3; ++k) d.pad[k] = 0;
+    d.cand = A.rec0[s].kmap[f];
     int rc = finalize_field(A.fstat[(size_t)s * MAX_FIELDS + f], p, e - p, buf[e], sb.n_rec, f, sb.nf, d);
     if (rc == OK && d.kind == KIND_TEXT) {
         uint32_t slot = atomicAdd(A.slot_counter, 1u);

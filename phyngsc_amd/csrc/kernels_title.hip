@@ -373,18 +373,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
                 const uint64_t rem = pos < 64 ? sepmask >> pos : 0;
                 const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
                 const uint32_t kind = s_fd[f].kind;
-                if (kind == KIND_NUM) {
-                    uint32_t v = 0;
-                    if (valid) {
-                        const uint2 q = load8_unaligned(A.buf, ls + pos, A.buf_len);
-                        const uint64_t km = t_lowbytes(len);
-                        v = t_parse8(q.x & (uint32_t)km, q.y & (uint32_t)(km >> 32), len);
-                        if (len > 8) {   // wraps like utils::to_num (utils.h:117-125)
-                            v = 0;
-                            for (uint32_t j = 0; j < len; ++j) v = v * 10 + (A.buf[ls + pos + j] - '0');
-                        }
-                    }
-                    s_w[s_fd[f].kf][tid] = v;
+                if (kind == KIND_NUM) {   // parsed once, by k_title_stats_swar
+                    s_w[s_fd[f].kf][tid] = valid ? A.tv[(size_t)s_fd[f].cand * A.tw_stride + g] : 0u;
                 } else if (kind == KIND_TEXT) {
                     s_w[s_fd[f].kf][tid] = pos | (len << 16);
                 }
@@ -705,7 +695,10 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                     }
                 }
             }
-            if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
+            if (kk < NUM_CAND_CAP) {
+                s_val[kk][tid] = v;
+                if (owned) A.tv[(size_t)kk * A.tw_stride + g] = v;   // k_title_measure_reg<true> and k_title_hist read it back
+            }
             nummask |= (uint32_t)isn << f;
         }
 

@@ -195,7 +195,8 @@ struct FieldDesc {
     uint32_t slot;          // text statistics / code slot, 0xffffffff if none
     uint32_t ham[8];        // Hamming mask bits (1 = every record equals record 0 at that position)
     uint32_t kf;            // index among the sub-block's non-constant fields
-    uint32_t pad[4];
+    uint32_t cand;          // numeric candidate index of the field (Rec0Tab::kmap), 0xff if record 0's field is not numeric
+    uint32_t pad[3];
 };
 static_assert(sizeof(FieldDesc) == 128, "FieldDesc layout");
 
@@ -245,6 +246,7 @@ struct Arena {
     uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
     uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
     uint64_t *tsep;         // per record: separator mask of the title (word-parallel path, titles <= 64 B)
+    uint32_t *tv;           // [NUM_CAND_CAP][tw_stride]: value of every numeric candidate field per record (word-parallel path)
     uint32_t *tw;           // [NCF_CAP][tw_stride]: cached non-constant title fields per record (tiled path)
     uint32_t tw_stride;
     uint32_t *tile_lo;      // per sub-block: first tile index
