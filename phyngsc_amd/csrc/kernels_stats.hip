@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
 // atomics aggregated per wave and distinct character.
 constexpr uint32_t NH_LDS_FIELDS = 8;
 
-__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A)
+__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
@@ -212,19 +212,22 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A)
     __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
     __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
     __shared__ uint32_t s_need;       // bit f: field needs a histogram
+    __shared__ uint32_t s_walk;       // some needed field is text or has no LDS slot: walk the title bytes
     __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields (0xff: global atomics)
 
     for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
     if (tid == 0) {
-        uint32_t need = 0, kk = 0;
+        uint32_t need = 0, kk = 0, walk = 0;
         for (uint32_t f = 0; f < nf; ++f) {
             s_k[f] = 0xff;
             if (fd[f].kind == KIND_NUM && fd[f].has_huff && fd[f].n_sym > 1) {
                 need |= 1u << f;
                 if (kk < NH_LDS_FIELDS) s_k[f] = (uint8_t)kk++;
-            } else if (fd[f].kind == KIND_TEXT) need |= 1u << f;
+                else walk = 1;
+            } else if (fd[f].kind == KIND_TEXT) { need |= 1u << f; walk = 1; }
         }
         s_need = need;
+        s_walk = walk;
     }
     __syncthreads();
     const uint32_t need = s_need;
@@ -235,6 +238,11 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A)
     const bool owned = valid && tid >= 1;
     const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
     uint32_t pc = A.ls[g];
+    if (use_tv && !s_walk) {
+        // every needed field is numeric and k_title_stats_swar kept its values: no need to touch the titles
+        for (uint32_t f = 0; f < nf; ++f)
+            if ((need >> f) & 1) s_val[s_k[f]][tid] = valid ? A.tv[(size_t)fd[f].cand * A.tw_stride + g] : 0u;
+    } else
     // lockstep over fields so that the lanes of a wave look at the same field together
     for (uint32_t f = 0; f < nf; ++f) {
         uint32_t ec = field_end(buf, pc);
@@ -333,10 +341,10 @@ void launch_field_finalize(hipStream_t st, const Arena &A)
     hipLaunchKernelGGL(k_field_finalize, dim3(A.n_sb), dim3(64), 0, st, A);
 }
 
-void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec)
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv)
 {
     dim3 grid((max_rec + TS_OWNED - 1) / TS_OWNED, A.n_sb);
-    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A);
+    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u);
 }
 
 }  // namespace ngsc

@@ -27,7 +27,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_finalize(hipStream_t st, const Arena &A);
 void launch_field_finalize(hipStream_t st, const Arena &A);
-void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv);
 
 // ---- kernels_huffman.hip ----
 void launch_huffman_sb(hipStream_t st, const Arena &A);
