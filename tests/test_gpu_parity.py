@@ -109,12 +109,15 @@ PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "tit
               "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
 
 
-@pytest.mark.parametrize("tile_records", ["1", "64", "128", "256"])
+@pytest.mark.parametrize("tile_records", ["reg", "1", "64", "128", "256"])
 def test_kernel_paths_agree(eng, monkeypatch, tile_records):
-    """The sequence/quality kernels exist in an LDS-tiled form (64/128/256 records per tile, 4/2/1 threads
-    per record) and an untiled wave-per-record form (NGSC_TILE_RECORDS=1: no tile size allowed): every form
-    must reproduce the reference."""
-    monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
+    """The sequence/quality kernels exist in three forms: register-streaming (one lane per record, the default
+    for records up to 2 KB), LDS-tiled (NGSC_SQ_PATH=tile: 64/128/256 records per tile, 4/2/1 threads per
+    record) and wave-per-record (records above 2 KB; forced here with NGSC_TILE_RECORDS=1 = no tile size
+    allowed): every form must reproduce the reference."""
+    if tile_records != "reg":
+        monkeypatch.setenv("NGSC_SQ_PATH", "tile")
+        monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
     for name in PATH_CASES:
         stem, P = name.rsplit(".p", 1)
         with open(os.path.join(GOLDEN, "small", stem + ".fastq"), "rb") as f:
@@ -172,15 +175,17 @@ def test_title_separator_and_digit_classes(eng):
     assert out == want      # (no round trip here: the format keeps ONE separator byte per field position)
 
 
-def test_long_records_take_the_untiled_path(eng):
-    """300-400 bp reads: records of ~850 B do not fit the LDS tile budget (and exceed the reference's
-    500-byte overlap, where it reads past its buffer - Q7 - so the oracle, which sees the real bytes, is
-    the comparison)."""
-    cfg = fastq_gen.GenConfig(seed=31, style=1, len_min=300, len_max=400, qual_model=2, n_rate_ppm=2000, n_lowq_pct=70)
-    data = fastq_gen.generate(cfg, target_bytes=40_000_000)
+@pytest.mark.parametrize("lo,hi,size", [(300, 400, 40_000_000), (1200, 1500, 30_000_000)])
+def test_long_records(eng, lo, hi, size):
+    """300-400 bp reads (~850 B records: many 16-byte chunks per lane in the register-streaming kernels) and
+    1200-1500 bp reads (~3 KB records: the wave-per-record kernels).  Both exceed the reference's 500-byte
+    overlap, where it reads past its buffer (Q7), so the oracle, which sees the real bytes, is the comparison."""
+    cfg = fastq_gen.GenConfig(seed=31, style=1, len_min=lo, len_max=hi, qual_model=2, n_rate_ppm=2000, n_lowq_pct=70)
+    data = fastq_gen.generate(cfg, target_bytes=size)
     _, out = _gpu(eng, data, 4)
     want, _ = orc.compress_file(data, 4, threads=4)
     assert out == want
+    assert orc.decompress(out) == data.tobytes()
 
 
 def test_rank_split_invariance_and_repeatability(eng):
