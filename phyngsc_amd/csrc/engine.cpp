@@ -50,7 +50,7 @@ struct ngsc_ctx {
     std::vector<hipEvent_t> event_pool;
 
     // workspace
-    DevBuf small, tiles, recs, persb, zero, slots, misc;
+    DevBuf small, tiles, recs, recs2, persb, zero, slots, misc;
     // pinned host staging
     void *h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -200,7 +200,7 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->persb, &c->zero, &c->slots, &c->misc})
+    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc})
         if (b->p) (void)hipFree(b->p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     collect_times(c);
@@ -303,45 +303,35 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemsetAsync(sm, 0, o_first, st));
 
     const uint32_t ntiles = index_num_tiles(len);
-    rc = ensure(c, c->tiles, sizeof(uint32_t) * (size_t)ntiles);
+    // The record table is sized for the smallest possible record (8 bytes), so the line count never has to come back
+    // to the host before the table is written.
+    const size_t mask_words = index_mask_words(len);
+    rc = ensure(c, c->tiles, 4 * (size_t)ntiles + 64 + 4 * mask_words);
     if (rc) return rc;
     uint32_t *d_tiles = (uint32_t *)c->tiles.p;
+    uint32_t *d_nlmask = (uint32_t *)((uint8_t *)c->tiles.p + ((4 * (size_t)ntiles + 63) & ~(size_t)63));
+    rc = ensure_pinned(c, cs.off);
+    if (rc) return rc;
+    uint8_t *hp = (uint8_t *)c->h_pin;
+    const size_t rec_bound = (size_t)len / 8 + 2;
+    Carver cr;
+    size_t o_te = cr.take(4 * rec_bound), o_se = cr.take(4 * rec_bound), o_ls = cr.take(4 * (rec_bound + 1));
+    rc = ensure(c, c->recs, cr.off);
+    if (rc) return rc;
+    uint8_t *rb = (uint8_t *)c->recs.p;
+    uint32_t *d_te = (uint32_t *)(rb + o_te), *d_se = (uint32_t *)(rb + o_se), *d_ls = (uint32_t *)(rb + o_ls);
 
     // ---- stage A: line index ----
     {
         KScope k(c, st, "k_sync_first");
         launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err);
     }
-    { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles); }
+    { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
-    rc = ensure_pinned(c, cs.off);
-    if (rc) return rc;
-    uint8_t *hp = (uint8_t *)c->h_pin;
-    HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
-    const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
-    if (!n_rec_total) return NGSC_ERR_FORMAT;
-
-    // record table + per-record arrays
-    const size_t rec_cap = (size_t)n_rec_total + 2;
-    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
-    Carver cr;
-    size_t o_te = cr.take(4 * rec_cap), o_se = cr.take(4 * rec_cap), o_ls = cr.take(4 * (rec_cap + 1));
-    size_t o_slen = cr.take(4 * rec_cap), o_qoff = cr.take(4 * rec_cap), o_doff = cr.take(4 * rec_cap);
-    size_t o_goff = cr.take(4 * grp_cap), o_gflags = cr.take(4 * grp_cap), o_tbits = cr.take(4 * rec_cap);
-    size_t o_tsep = cr.take(8 * rec_cap);
-    rc = ensure(c, c->recs, cr.off);
-    if (rc) return rc;
-    uint8_t *rb = (uint8_t *)c->recs.p;
-    uint32_t *d_te = (uint32_t *)(rb + o_te), *d_se = (uint32_t *)(rb + o_se), *d_ls = (uint32_t *)(rb + o_ls);
-    {
-        KScope k(c, st, "k_nl_write");
-        launch_nl_write(st, buf, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_cap);
-    }
+    { KScope k(c, st, "k_nl_write"); launch_nl_write(st, d_nlmask, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_bound); }
     {
         KScope k(c, st, "k_cuts_validate");
-        launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, n_rec_total, d_total, d_first, d_cuts,
+        launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
                              max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err);
     }
     // ---- sync 2: cut list ----
@@ -350,6 +340,18 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemcpyAsync(hp + o_plans, sm + o_plans, plan_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
+    const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
+    if (!n_rec_total || (size_t)n_rec_total + 2 > rec_bound) return NGSC_ERR_FORMAT;
+    // per-record arrays
+    const size_t rec_cap = (size_t)n_rec_total + 2;
+    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
+    Carver cr2;
+    size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * rec_cap), o_doff = cr2.take(4 * rec_cap);
+    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * rec_cap);
+    size_t o_tsep = cr2.take(8 * rec_cap);
+    rc = ensure(c, c->recs2, cr2.off);
+    if (rc) return rc;
+    uint8_t *rb2 = (uint8_t *)c->recs2.p;
     const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
     const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
     const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
@@ -429,12 +431,12 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     memset(&A, 0, sizeof A);
     A.buf = buf; A.buf_len = len;
     A.te = d_te; A.se = d_se; A.ls = d_ls;
-    A.slen = (uint32_t *)(rb + o_slen); A.qoff = (uint32_t *)(rb + o_qoff); A.doff = (uint32_t *)(rb + o_doff);
-    A.goff = (uint32_t *)(rb + o_goff);
+    A.slen = (uint32_t *)(rb2 + o_slen); A.qoff = (uint32_t *)(rb2 + o_qoff); A.doff = (uint32_t *)(rb2 + o_doff);
+    A.goff = (uint32_t *)(rb2 + o_goff);
     A.grp_lo = (uint32_t *)(pb + p_grplo);
-    A.tbits = (uint32_t *)(rb + o_tbits);
-    A.tsep = (uint64_t *)(rb + o_tsep);
-    A.gflags = (uint32_t *)(rb + o_gflags);
+    A.tbits = (uint32_t *)(rb2 + o_tbits);
+    A.tsep = (uint64_t *)(rb2 + o_tsep);
+    A.gflags = (uint32_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);
     A.ubits = (uint32_t *)(pb + p_ubits);

@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 }
 
 __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
-                                                           uint32_t *tile_cnt)
+                                                           uint32_t *tile_cnt, uint32_t *nl_mask)
 {
     __shared__ uint32_t s_part[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
@@ -78,8 +78,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
 #pragma unroll
     for (uint32_t pc = 0; pc < PIECES; ++pc) {
         const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-        uint32_t flags[8];
+        uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         c += (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+        // one bit per byte: the write pass reads 1/8 of a byte per input byte instead of the input again
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
+        nl_mask[base / BYTES_PER_THREAD] = m;
     }
     c = wave_reduce_add(c);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *tile_cnt, uint32_
 
 // Writes the record table.  Line L (0-based from *start_ptr) ends at a newline; L&3 == 0: title end of
 // record L>>2, 1: sequence end, 3: the next record's line start.
-__global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
+__global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint32_t *nl_mask, const uint32_t *start_ptr,
                                                            const uint32_t *tile_off, uint32_t *te, uint32_t *se,
                                                            uint32_t *ls, uint32_t rec_cap)
 {
@@ -127,8 +132,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
     uint32_t line_base = tile_off[blockIdx.x];
     for (uint32_t pc = 0; pc < PIECES; ++pc) {
         const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-        uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        uint32_t c = (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
+        uint32_t m = nl_mask[base / BYTES_PER_THREAD];   // (the mask array covers whole tiles)
+        const uint32_t c = (uint32_t)__popc(m);
         uint32_t incl = wave_scan_incl(c);
         __syncthreads();  // s_wave of the previous piece has been consumed
         if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
@@ -143,9 +148,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint8_t *buf, u
         line_base += total;
         // one bit per byte of the thread's 32 bytes, then a single walk over the set bits (a 36-bp record has a
         // newline every ~29 bytes, so the walk is 1-2 steps; eight separate per-word walks cost 4x the VALU work)
-        uint32_t m = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
         while (m) {
             const uint32_t k = (uint32_t)__ffs(m) - 1;
             m &= m - 1;
@@ -268,22 +270,24 @@ void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_
                        start_rel, err);
 }
 
-void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt)
+void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask)
 {
     uint32_t nt = index_num_tiles(len);
-    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt);
+    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt, nl_mask);
 }
+
+size_t index_mask_words(uint32_t len) { return (size_t)index_num_tiles(len) * (TILE_BYTES / BYTES_PER_THREAD); }
 
 void launch_scan_tiles(hipStream_t st, uint32_t *tile_cnt, uint32_t n_tiles, uint32_t *total_lines)
 {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, n_tiles, total_lines);
 }
 
-void launch_nl_write(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, const uint32_t *tile_off,
+void launch_nl_write(hipStream_t st, const uint32_t *nl_mask, uint32_t len, const uint32_t *start_rel, const uint32_t *tile_off,
                      uint32_t *te, uint32_t *se, uint32_t *ls, uint32_t rec_cap)
 {
     uint32_t nt = index_num_tiles(len);
-    hipLaunchKernelGGL(k_nl_write, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_off, te, se, ls, rec_cap);
+    hipLaunchKernelGGL(k_nl_write, dim3(nt), dim3(TILE_THREADS), 0, st, nl_mask, start_rel, tile_off, te, se, ls, rec_cap);
 }
 
 void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
@@ -291,9 +295,11 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
                           uint32_t *max_rec, uint32_t *max_title, int32_t *err)
 {
-    // 8 records per validating thread: few fat workgroups instead of one tiny wave per 64 records
+    // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
+    // wave per 64 records
     uint32_t vblocks = (n_rec + 2047) / 2048;
     if (vblocks < 1) vblocks = 1;
+    if (vblocks > 16384) vblocks = 16384;
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
                        ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err);
 }
