@@ -237,6 +237,42 @@ __global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t 
     }
 }
 
+// plan_rank() search policy for a whole wave: 64 probes per round (a 2^21-record window needs 4 rounds instead of 21
+// binary-search steps; every round is one memory latency, and the planner's chain of searches is serial).
+struct WaveSearch {
+    __device__ uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const
+    {
+        uint32_t r0, r1;
+        pair(a, n, key, a, 0, 0, 0, n, r0, r1);
+        return r0;
+    }
+    __device__ void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
+                         uint32_t span, uint32_t &ra, uint32_t &rb) const
+    {
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t la = lo < na ? lo : na, ha = (uint64_t)lo + span < na ? lo + span : na;
+        uint32_t lb = lo < nb ? lo : nb, hb = (uint64_t)lo + span < nb ? lo + span : nb;
+        while (la < ha || lb < hb) {
+            const uint32_t sa = (ha - la + 63) >> 6, sb = (hb - lb + 63) >> 6;
+            const uint32_t pa = la + lane * sa, pb = lb + lane * sb;
+            const bool ina = la < ha && pa < ha, inb = lb < hb && pb < hb;
+            const uint32_t va = ina ? a[pa] : 0u, vb = inb ? b[pb] : 0u;   // both rounds' loads are in flight together
+            const uint32_t ca = (uint32_t)__popcll(__ballot(ina && (uint64_t)va < ka));
+            const uint32_t cb = (uint32_t)__popcll(__ballot(inb && (uint64_t)vb < kb));
+            if (la < ha) {
+                if (ca == 0) ha = la;
+                else { const uint32_t top = la + ca * sa; la = la + (ca - 1) * sa + 1; ha = top < ha ? top : ha; }
+            }
+            if (lb < hb) {
+                if (cb == 0) hb = lb;
+                else { const uint32_t top = lb + cb * sb; lb = lb + (cb - 1) * sb + 1; hb = top < hb ? top : hb; }
+            }
+        }
+        ra = la;
+        rb = lb;
+    }
+};
+
 // One launch, two jobs that do not depend on each other: workgroups [0, n_ranks) plan the sub-block cuts of
 // one rank each (a serial chain of binary searches over the record table, see plan_rank()), the others
 // validate the structure of every record and reduce the job-wide maxima while those chains run.
@@ -248,12 +284,14 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
 {
     const uint32_t n_rec_total = *total_lines / 4;
     if (blockIdx.x < n_ranks) {
-        if (threadIdx.x) return;
+        if (threadIdx.x >= 64) return;   // one wave per rank; all lanes run the (uniform) planner, the searches are wave-wide
         const uint32_t i = blockIdx.x;
-        int rc = plan_rank(file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i], cuts + (size_t)i * max_cuts,
-                           max_cuts, &plans[i]);
-        plans[i].err = rc;
-        if (rc) atomicMin(err, (int32_t)rc);
+        int rc = plan_rank_with(WaveSearch(), file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
+                                cuts + (size_t)i * max_cuts, max_cuts, &plans[i]);
+        if (threadIdx.x == 0) {
+            plans[i].err = rc;
+            if (rc) atomicMin(err, (int32_t)rc);
+        }
         return;
     }
     const uint32_t vb = blockIdx.x - n_ranks, nvb = gridDim.x - n_ranks;

@@ -660,6 +660,24 @@ NGSC_HD uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t key)
     return lo;
 }
 
+// Two lower bounds, a[ra] >= ka and b[rb] >= kb, searched in lockstep over the index window [lo, lo + span): the
+// two loads of a step are independent, which halves the latency chain of the cut planner (its searches are the
+// serial part of the index stage).  Results are clamped to the window.
+NGSC_HD void lower_bound_pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb,
+                              uint32_t lo, uint32_t span, uint32_t &ra, uint32_t &rb)
+{
+    uint32_t la = lo < na ? lo : na, ha = (uint64_t)lo + span < na ? lo + span : na;
+    uint32_t lb = lo < nb ? lo : nb, hb = (uint64_t)lo + span < nb ? lo + span : nb;
+    while (la < ha || lb < hb) {
+        const uint32_t ma = la + ((ha - la) >> 1), mb = lb + ((hb - lb) >> 1);
+        const uint32_t va = la < ha ? a[ma] : 0u, vb = lb < hb ? b[mb] : 0u;
+        if (la < ha) { if ((uint64_t)va < ka) la = ma + 1; else ha = ma; }
+        if (lb < hb) { if ((uint64_t)vb < kb) lb = mb + 1; else hb = mb; }
+    }
+    ra = la;
+    rb = lb;
+}
+
 struct RankGeom {
     int64_t region, wr_start, wr_end, bsize;
     uint32_t overlap;
@@ -682,14 +700,26 @@ NGSC_HD RankGeom rank_geometry(uint64_t file_size, uint32_t P, uint32_t r)
 
 // te/ls are offsets inside the job buffer whose first byte is file offset buf_off; ls has n_rec+1 entries.
 // first_abs: file offset of the rank's first record (from the sync heuristic).  Returns an error code.
-NGSC_HD int plan_rank(uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_off, const uint32_t *te,
-                      const uint32_t *ls, uint32_t n_rec_total, uint64_t first_abs, Cut *cuts, uint32_t max_cuts,
-                      RankPlan *plan)
+// Search policy of plan_rank(): one thread (host harness, reference semantics) ...
+struct ScalarSearch {
+    NGSC_HD uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const { return lower_bound_u32(a, n, key); }
+    NGSC_HD void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
+                      uint32_t span, uint32_t &ra, uint32_t &rb) const
+    {
+        lower_bound_pair(a, na, ka, b, nb, kb, lo, span, ra, rb);
+    }
+};
+// (... or a whole wave probing 64 positions per round, see kernels_index.hip)
+
+template <class Search>
+NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_off, const uint32_t *te,
+                           const uint32_t *ls, uint32_t n_rec_total, uint64_t first_abs, Cut *cuts, uint32_t max_cuts,
+                           RankPlan *plan)
 {
     RankGeom g = rank_geometry(file_size, P, r);
     plan->n_cuts = 0;
     plan->overlap_used = (int32_t)((int64_t)first_abs - g.wr_start);
-    uint32_t cur = lower_bound_u32(ls, n_rec_total + 1, first_abs - buf_off);
+    uint32_t cur = search.one(ls, n_rec_total + 1, first_abs - buf_off);
     plan->first_rec = cur;
     if (cur > n_rec_total || (uint64_t)ls[cur] + buf_off != first_abs) return ERR_FORMAT;
     int64_t bytes_read = 0, win_pos = g.wr_start, bsize = g.bsize;
@@ -699,12 +729,14 @@ NGSC_HD int plan_rank(uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_o
         int64_t wend = win_pos + bsize, stop_at = win_pos + bsize - (int64_t)overlap;
         uint32_t last = cur;
         // candidates after the first record need their title end inside the window (phyNGSC.cpp:268, 303-306)
-        int64_t wend_rel = wend - (int64_t)buf_off;
-        uint32_t m = wend_rel > 0 ? lower_bound_u32(te, n_rec_total, (uint64_t)wend_rel) : 0;  // te[m-1] < wend
+        // A window holds at most 2^21 records (8 MiB, >= 4 bytes each), so both bounds lie in [cur, cur + 2^21 + 4);
+        // a bound below the window clamps to cur, which the tests below treat like any value <= cur.
+        int64_t wend_rel = wend - (int64_t)buf_off, stop_rel = stop_at - (int64_t)buf_off;
+        uint32_t m, lb;
+        search.pair(te, n_rec_total, wend_rel > 0 ? (uint64_t)wend_rel : 0, ls, n_rec_total + 1,
+                    stop_rel > 0 ? (uint64_t)stop_rel : 0, cur, (1u << 21) + 4, m, lb);  // te[m-1] < wend
         if (m > cur + 1) {
             // first record (other than `cur`, which is never tested: :295-300) whose next offset >= stop_at
-            int64_t stop_rel = stop_at - (int64_t)buf_off;
-            uint32_t lb = stop_rel > 0 ? lower_bound_u32(ls, n_rec_total + 1, (uint64_t)stop_rel) : 0;
             uint32_t j = lb > 0 ? lb - 1 : 0;
             if (j < cur + 1) j = cur + 1;
             last = j < m - 1 ? j : m - 1;
@@ -725,6 +757,13 @@ NGSC_HD int plan_rank(uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_o
         cur = last + 1;
     }
     return OK;
+}
+
+NGSC_HD int plan_rank(uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_off, const uint32_t *te,
+                      const uint32_t *ls, uint32_t n_rec_total, uint64_t first_abs, Cut *cuts, uint32_t max_cuts,
+                      RankPlan *plan)
+{
+    return plan_rank_with(ScalarSearch(), file_size, P, r, buf_off, te, ls, n_rec_total, first_abs, cuts, max_cuts, plan);
 }
 
 // =====================================================================================================
