@@ -414,47 +414,67 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 idx[k] = sr_idx(w);
                 dacc |= sr_not_acgt(w, idx[k]);
             }
-            const bool amb_here = need_s && dacc != 0;   // some non-ACGT base in this lane's chunk
-            const bool rows_ok = 16 * ch + 17 <= lds_rows;
-            const bool odd = qbad != 0 || (nv != 0 && nv != 16) || (xfer && amb_here);
-            // quality bits
-            if (rows_ok && !__any(odd)) {
-                if (nv) {
-                    const uint8_t *rowp = s_qlen + (16 * ch + 1) * SR_HCOLS - 33;
+            // per-byte exceptions as 16-bit masks (see k_sq_pack_reg, which makes the same decisions)
+            const uint32_t validm = (1u << nv) - 1u;
+            uint32_t ambm = 0, qbm = 0;
+            if (__any((need_s && dacc != 0) || qbad != 0)) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 16; ++u) qb += rowp[u * SR_HCOLS + sr_byte(qw, u)];
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                    const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                    if (need_s) ambm |= t_movemask(t_nonzero01(sr_not_acgt(w, idx[k]))) << (4 * k);
+                    qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
                 }
-            } else {
+                qbm &= validm;
+            }
+            const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;
+            const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
+            const uint32_t qpatch = (qbm | (xfer ? ambm : 0u) | (validm & ~rowm));
+            // quality bits: table lengths of the (clamped) bytes, then corrections for the exceptions
+            {
+                const uint32_t row0 = 16 * ch + 1;
 #pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) {
-                    if (u < nv) {
-                        uint32_t q = sr_byte(qw, u);
-                        const uint32_t row = 16 * ch + u + 1;
-                        if (xfer && amb_here) {
-                            const uint32_t a = s_amb[sr_byte(sw, u)];
-                            if (a > 1) q = transfer_quality(a, (uint8_t)q);   // phyNGSC.cpp:579
-                        }
-                        const uint32_t col = q - 33;
-                        qb += (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SR_HCOLS + col] : (sq_qentry_slow(T, row, q) & 31u);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!__any(nv > 4 * k)) continue;
+                    uint32_t l[4];
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t u = 4 * k + b;
+                        const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
+                        l[b] = s_qlen[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
                     }
+                    if (__any((qpatch >> (4 * k)) & 15u)) {
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t u = 4 * k + b;
+                            if ((qpatch >> u) & 1u) {
+                                uint32_t q = sr_byte(qw, u);
+                                if (xfer && ((ambm >> u) & 1u)) q = transfer_quality(s_amb[sr_byte(sw, u)], (uint8_t)q);   // phyNGSC.cpp:579
+                                l[b] = sq_qentry_slow(T, row0 + u, q) & 31u;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) qb += ((validm >> (4 * k + b)) & 1u) ? l[b] : 0u;
                 }
             }
             // DNA bits of a Huffman-coded alphabet (more than four symbols, tasks.cpp:525-557)
             if (!plain) {
-                if (!__any(amb_here)) {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                        db = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, 0u, db);
-                    }
-                } else {
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!__any(nv > 4 * k)) continue;
+                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                    uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm;
+                    if (__any((ambm >> (4 * k)) & 15u)) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 16; ++u) {
-                        if (u < nv) {
-                            const uint32_t c = sr_byte(sw, u);
-                            if (!(xfer && s_amb[c] > 1)) db += s_dcode[c] & 31u;
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            if ((ambm >> (4 * k + b)) & 1u) {
+                                const uint32_t ll = xfer ? 0u : (s_dcode[sr_byte(sw, 4 * k + b)] & 31u);
+                                l4 = (l4 & ~(0xffu << (8 * b))) | (ll << (8 * b));
+                            }
                         }
                     }
+                    db = __builtin_amdgcn_sad_u8(l4, 0u, db);
                 }
             }
         }
@@ -553,7 +573,13 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     const uint32_t ltab = (eA & 31u) | ((eC & 31u) << 8) | ((eT & 31u) << 16) | ((eG & 31u) << 24);
     const uint32_t ctab = ((eA >> 5) & 0xffu) | (((eC >> 5) & 0xffu) << 8) | (((eT >> 5) & 0xffu) << 16) | (((eG >> 5) & 0xffu) << 24);
     // four Huffman base codes can be merged bytewise when each is at most 8 bits long
-    const bool short_codes = (eA & 31u) <= 8 && (eC & 31u) <= 8 && (eT & 31u) <= 8 && (eG & 31u) <= 8;
+    // the byte-vector DNA path needs every code of the alphabet to fit a byte (length <= 8)
+    __shared__ uint32_t s_longcode;
+    if (tid == 0) s_longcode = 0;
+    __syncthreads();
+    if ((s_dcode[tid] & 31u) > 8) atomicOr(&s_longcode, 1u);
+    __syncthreads();
+    const bool short_codes = !s_longcode;
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
@@ -616,66 +642,94 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                 idx[k] = sr_idx(w);
                 dacc |= sr_not_acgt(w, idx[k]);
             }
-            const bool amb_here = dacc != 0;
-            const bool rows_ok = 16 * ch + 17 <= lds_rows;
-            const bool odd = qbad != 0 || (nv != 0 && nv != 16) || (xfer && amb_here);
-
-            // ---- quality (tasks.cpp:609-619) ----
-            if (rows_ok && !__any(odd)) {
-                if (nv) {
-                    const uint32_t *rowp = s_qtab + (16 * ch + 1) * SR_HCOLS - 33;
+            // Per-byte exceptions as 16-bit masks.  The common bytes go through the table / v_perm paths four at a time;
+            // a word (4 bytes) is patched byte by byte only if some lane of the wave has an exception in that word.
+            const uint32_t validm = (1u << nv) - 1u;
+            uint32_t ambm = 0, qbm = 0;
+            if (__any(dacc != 0 || qbad != 0)) {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {   // four symbols per put when their codes fit 32 bits together
-                        const uint32_t e0 = rowp[(4 * k + 0) * SR_HCOLS + sr_byte(qw, 4 * k + 0)];
-                        const uint32_t e1 = rowp[(4 * k + 1) * SR_HCOLS + sr_byte(qw, 4 * k + 1)];
-                        const uint32_t e2 = rowp[(4 * k + 2) * SR_HCOLS + sr_byte(qw, 4 * k + 2)];
-                        const uint32_t e3 = rowp[(4 * k + 3) * SR_HCOLS + sr_byte(qw, 4 * k + 3)];
-                        const uint32_t l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
-                        const uint32_t tl = (e0 & 31u) + l1 + l2 + l3;
-                        if (__any(tl > 32)) {
-                            wq_.put(e0 >> 5, e0 & 31u); wq_.put(e1 >> 5, l1); wq_.put(e2 >> 5, l2); wq_.put(e3 >> 5, l3);
-                        } else {
-                            wq_.put(((((((e0 >> 5) << l1) | (e1 >> 5)) << l2) | (e2 >> 5)) << l3) | (e3 >> 5), tl);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                    const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                    ambm |= t_movemask(t_nonzero01(sr_not_acgt(w, idx[k]))) << (4 * k);
+                    qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
+                }
+                qbm &= validm;
+            }
+            const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // table rows for this chunk's positions
+            const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
+            // quality bytes whose entry is not in the LDS table: odd bytes, transferred ones, rows past the table
+            const uint32_t qpatch = (qbm | (xfer ? ambm : 0u) | (validm & ~rowm));
+
+            // ---- quality (tasks.cpp:609-619): four symbols per put when their codes fit 32 bits together ----
+            {
+                const uint32_t row0 = 16 * ch + 1;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!__any(nv > 4 * k)) continue;
+                    uint32_t e[4];
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t u = 4 * k + b;
+                        const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
+                        e[b] = s_qtab[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
+                    }
+                    if (__any((qpatch >> (4 * k)) & 15u)) {
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t u = 4 * k + b;
+                            if ((qpatch >> u) & 1u) {
+                                uint32_t q = sr_byte(qw, u);
+                                if (xfer && ((ambm >> u) & 1u)) q = transfer_quality(s_amb[sr_byte(sw, u)], (uint8_t)q);   // phyNGSC.cpp:579
+                                e[b] = sq_qentry_slow(T, row0 + u, q);
+                            }
                         }
                     }
-                }
-            } else {
+                    if (__any(nv < 4 * k + 4)) {   // read tails: bytes past the read contribute no bits
 #pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) {
-                    if (u < nv) {
-                        uint32_t q = sr_byte(qw, u);
-                        const uint32_t row = 16 * ch + u + 1;
-                        if (xfer && amb_here) {
-                            const uint32_t a = s_amb[sr_byte(sw, u)];
-                            if (a > 1) q = transfer_quality(a, (uint8_t)q);
-                        }
-                        const uint32_t col = q - 33;
-                        const uint32_t e = (col < SR_HCOLS && row < lds_rows) ? s_qtab[row * SR_HCOLS + col] : sq_qentry_slow(T, row, q);
-                        wq_.put(e >> 5, e & 31u);
+                        for (uint32_t b = 0; b < 4; ++b) e[b] = ((validm >> (4 * k + b)) & 1u) ? e[b] : 0u;
+                    }
+                    const uint32_t l1 = e[1] & 31u, l2 = e[2] & 31u, l3 = e[3] & 31u;
+                    const uint32_t tl = (e[0] & 31u) + l1 + l2 + l3;
+                    if (__any(tl > 32)) {
+                        wq_.put(e[0] >> 5, e[0] & 31u); wq_.put(e[1] >> 5, l1); wq_.put(e[2] >> 5, l2); wq_.put(e[3] >> 5, l3);
+                    } else {
+                        wq_.put(((((((e[0] >> 5) << l1) | (e[1] >> 5)) << l2) | (e[2] >> 5)) << l3) | (e[3] >> 5), tl);
                     }
                 }
             }
 
             // ---- DNA (tasks.cpp:544-557) ----
-            if (!__any(amb_here) && (plain || short_codes)) {
+            if (plain && !__any(ambm != 0)) {
                 if (nv) {
-                    if (plain) {
-                        // two bits per base: the four code bytes of a dword collapse with one multiply
-                        uint32_t x = 0;
+                    // two bits per base: the four code bytes of a dword collapse with one multiply
+                    uint32_t x = 0;
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k)
-                            x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
-                        wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
-                    } else {
+                    for (uint32_t k = 0; k < 4; ++k)
+                        x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
+                    wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
+                }
+            } else if (short_codes) {
+                // code and length bytes of the four bases of a dword from v_perm tables; ambiguity codes are patched in
+                // from the byte table (or dropped: transferred records carry them in the quality stream)
 #pragma unroll
-                        for (uint32_t k = 0; k < 4; ++k) {
-                            const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                            const uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vm;
-                            const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
-                            const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
-                            wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!__any(nv > 4 * k)) continue;
+                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                    uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vm;
+                    if (__any((ambm >> (4 * k)) & 15u)) {
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            if ((ambm >> (4 * k + b)) & 1u) {
+                                const uint32_t ee = xfer ? 0u : s_dcode[sr_byte(sw, 4 * k + b)];
+                                l4 = (l4 & ~(0xffu << (8 * b))) | ((ee & 31u) << (8 * b));
+                                c4 = (c4 & ~(0xffu << (8 * b))) | ((ee >> 5) << (8 * b));
+                            }
                         }
                     }
+                    const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
+                    const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
+                    wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
                 }
             } else {
 #pragma unroll
