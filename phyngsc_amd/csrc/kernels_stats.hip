@@ -194,9 +194,15 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Title histograms.  Numeric Huffman fields: LDS-privatised [8][512] counters; text fields: global
-// atomics aggregated per wave and distinct character.
+// Title histograms (tasks.cpp:83-93 chars[][], :149-184 num_values / delta_values).  A workgroup walks
+// TH_BATCHES batches of 255 records (+ the previous record as delta halo) and keeps its counts in LDS until
+// the end: numeric Huffman fields in [8][512] counters, the first 16 positions of up to two text fields in
+// packed 16-bit counters.  Everything else (more fields, later positions) goes to global memory with one
+// atomic per wave and distinct character.  Few fat workgroups matter here: the per-(position, character)
+// counters of a sub-block are a handful of addresses, and same-address global atomics serialise.
 constexpr uint32_t NH_LDS_FIELDS = 8;
+constexpr uint32_t TH_BATCHES = 16;
+constexpr uint32_t TH_TEXT = 2, TH_ROWS = 16;
 
 __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv)
 {
@@ -204,27 +210,34 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
-    if (blockIdx.x * TS_OWNED >= n) return;
+    const uint32_t wg_first = blockIdx.x * TS_OWNED * TH_BATCHES;
+    if (wg_first >= n) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t *buf = A.buf;
     const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
 
     __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
     __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
-    __shared__ uint32_t s_need;       // bit f: field needs a histogram
-    __shared__ uint32_t s_walk;       // some needed field is text or has no LDS slot: walk the title bytes
-    __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields (0xff: global atomics)
+    __shared__ uint32_t s_th[TH_TEXT][TH_ROWS][128];   // two 16-bit counters per word: character c -> word c >> 1, half c & 1
+    __shared__ uint32_t s_need;          // bit f: field needs a histogram
+    __shared__ uint32_t s_walk;          // some needed field is text or has no LDS slot: field boundaries are needed
+    __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields / text fields (0xff: global atomics)
 
     for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
+    for (uint32_t k = tid; k < TH_TEXT * TH_ROWS * 128; k += TS_THREADS) (&s_th[0][0][0])[k] = 0;
     if (tid == 0) {
-        uint32_t need = 0, kk = 0, walk = 0;
+        uint32_t need = 0, kk = 0, kt = 0, walk = 0;
         for (uint32_t f = 0; f < nf; ++f) {
             s_k[f] = 0xff;
             if (fd[f].kind == KIND_NUM && fd[f].has_huff && fd[f].n_sym > 1) {
                 need |= 1u << f;
                 if (kk < NH_LDS_FIELDS) s_k[f] = (uint8_t)kk++;
                 else walk = 1;
-            } else if (fd[f].kind == KIND_TEXT) { need |= 1u << f; walk = 1; }
+            } else if (fd[f].kind == KIND_TEXT) {
+                need |= 1u << f;
+                walk = 1;
+                if (kt < TH_TEXT) s_k[f] = (uint8_t)kt++;
+            }
         }
         s_need = need;
         s_walk = walk;
@@ -232,92 +245,124 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     __syncthreads();
     const uint32_t need = s_need;
     if (!need) return;
+    const bool walk = s_walk != 0;
 
-    const int64_t i = (int64_t)blockIdx.x * TS_OWNED + tid - 1;
-    const bool valid = i >= 0 && i < (int64_t)n;
-    const bool owned = valid && tid >= 1;
-    const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
-    uint32_t pc = A.ls[g];
-    if (use_tv && !s_walk) {
-        // every needed field is numeric and k_title_stats_swar kept its values: no need to touch the titles
-        for (uint32_t f = 0; f < nf; ++f)
-            if ((need >> f) & 1) s_val[s_k[f]][tid] = valid ? A.tv[(size_t)fd[f].cand * A.tw_stride + g] : 0u;
-    } else
-    // lockstep over fields so that the lanes of a wave look at the same field together
-    for (uint32_t f = 0; f < nf; ++f) {
-        uint32_t ec = field_end(buf, pc);
-        const FieldDesc &d = fd[f];
-        if ((need >> f) & 1) {
-            if (d.kind == KIND_NUM) {
-                uint32_t v = 0;
-                bool o;
-                parse_num(buf, pc, ec, v, o);
-                uint32_t k = s_k[f];
-                if (k != 0xff) {
-                    s_val[k][tid] = v;
-                } else if (owned) {  // more than 8 numeric Huffman fields: slow path, previous value re-parsed
-                    uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
-                    if (!d.delta_coding) {
-                        uint32_t idx = v - (uint32_t)d.min_v;
-                        if (idx < d.n_sym) atomicAdd(&nh[idx], i == 0 ? 2u : 1u);
-                    } else if (i >= 1) {
-                        uint32_t pp = A.ls[g - 1], ep = 0;
-                        for (uint32_t k2 = 0; k2 <= f; ++k2) { ep = field_end(buf, pp); if (k2 < f) pp = ep + 1; }
-                        uint32_t pv = 0;
-                        parse_num(buf, pp, ep, pv, o);
-                        uint32_t idx = v - pv - (uint32_t)d.min_d;
-                        if (idx < d.n_sym) atomicAdd(&nh[idx], 1u);
-                    }
+    for (uint32_t batch = 0; batch < TH_BATCHES; ++batch) {
+        const uint32_t b_first = wg_first + batch * TS_OWNED;
+        if (b_first >= n) break;
+        const int64_t i = (int64_t)b_first + tid - 1;
+        const bool valid = i >= 0 && i < (int64_t)n;
+        const bool owned = valid && tid >= 1;
+        const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
+        const uint32_t ls = A.ls[g];
+        if (!walk) {
+            // every needed field is numeric and k_title_stats_swar kept its values: no need to touch the titles
+            for (uint32_t f = 0; f < nf; ++f)
+                if ((need >> f) & 1) s_val[s_k[f]][tid] = (valid && use_tv) ? A.tv[(size_t)fd[f].cand * A.tw_stride + g] : 0u;
+        }
+        if (walk || !use_tv) {
+            const unsigned long long sepmask = (use_tv && valid) ? A.tsep[g] : 0ull;
+            uint32_t pc = ls;
+            // lockstep over fields so that the lanes of a wave look at the same field together
+            for (uint32_t f = 0; f < nf; ++f) {
+                uint32_t ec;
+                if (use_tv) {   // field boundaries from the separator mask of k_title_stats_swar
+                    const uint32_t rel = pc - ls;
+                    const unsigned long long rem = rel < 64 ? sepmask >> rel : 0ull;
+                    ec = pc + (rem ? (uint32_t)__builtin_ctzll(rem) : 0u);
+                } else {
+                    ec = field_end(buf, pc);
                 }
-            } else {
-                // text: chars[min(x,128)][c]++ (tasks.cpp:83-93), one atomic per wave and distinct character
-                uint32_t len = owned ? ec - pc : 0;
-                uint32_t wmax = len;
+                const FieldDesc &d = fd[f];
+                if ((need >> f) & 1) {
+                    if (d.kind == KIND_NUM) {
+                        uint32_t v = 0;
+                        if (use_tv) v = valid ? A.tv[(size_t)d.cand * A.tw_stride + g] : 0u;
+                        else { bool o; parse_num(buf, pc, ec, v, o); }
+                        const uint32_t k = s_k[f];
+                        if (k != 0xff) {
+                            s_val[k][tid] = v;
+                        } else if (owned) {  // more than 8 numeric Huffman fields: slow path, previous value re-parsed
+                            uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+                            if (!d.delta_coding) {
+                                uint32_t idx = v - (uint32_t)d.min_v;
+                                if (idx < d.n_sym) atomicAdd(&nh[idx], i == 0 ? 2u : 1u);
+                            } else if (i >= 1) {
+                                uint32_t pp = A.ls[g - 1], ep = 0;
+                                for (uint32_t k2 = 0; k2 <= f; ++k2) { ep = field_end(buf, pp); if (k2 < f) pp = ep + 1; }
+                                uint32_t pv = 0;
+                                bool o;
+                                parse_num(buf, pp, ep, pv, o);
+                                uint32_t idx = v - pv - (uint32_t)d.min_d;
+                                if (idx < d.n_sym) atomicAdd(&nh[idx], 1u);
+                            }
+                        }
+                    } else {
+                        // text: chars[min(x,128)][c]++ (tasks.cpp:83-93)
+                        const uint32_t len = owned ? ec - pc : 0;
+                        const uint32_t kt = s_k[f];
+                        uint32_t wmax = len;
 #pragma unroll
-                for (int dd = 32; dd >= 1; dd >>= 1) { uint32_t o2 = __shfl_xor(wmax, dd); wmax = o2 > wmax ? o2 : wmax; }
-                uint32_t *ch = A.chist + (size_t)d.slot * TEXT_TREES * 256;
-                for (uint32_t x = 0; x < wmax; ++x) {
-                    bool act = x < len;
-                    uint32_t c = act ? buf[pc + x] : 0x100u;
-                    uint32_t row = x < MAX_STAT_LEN ? x : MAX_STAT_LEN;
-                    unsigned long long m = __ballot(act);
-                    while (m) {
-                        int leader = __ffsll((long long)m) - 1;
-                        uint32_t c0 = __shfl(c, leader);
-                        unsigned long long same = __ballot(act && c == c0);
-                        if (lane == leader) atomicAdd(&ch[row * 256 + c0], (uint32_t)__popcll(same));
-                        if (c == c0) act = false;
-                        m &= ~same;
+                        for (int dd = 32; dd >= 1; dd >>= 1) { uint32_t o2 = __shfl_xor(wmax, dd); wmax = o2 > wmax ? o2 : wmax; }
+                        uint32_t *ch = A.chist + (size_t)d.slot * TEXT_TREES * 256;
+                        for (uint32_t x = 0; x < wmax; ++x) {
+                            bool act = x < len;
+                            const uint32_t c = act ? buf[pc + x] : 0x100u;
+                            if (kt != 0xff && x < TH_ROWS) {   // LDS counters (wave-uniform condition)
+                                if (act) atomicAdd(&s_th[kt][x][c >> 1], 1u << (16 * (c & 1)));
+                                continue;
+                            }
+                            const uint32_t row = x < MAX_STAT_LEN ? x : MAX_STAT_LEN;
+                            unsigned long long m = __ballot(act);
+                            while (m) {   // one atomic per wave and distinct character
+                                const int leader = __ffsll((long long)m) - 1;
+                                const uint32_t c0 = __shfl(c, leader);
+                                const unsigned long long same = __ballot(act && c == c0);
+                                if (lane == leader) atomicAdd(&ch[row * 256 + c0], (uint32_t)__popcll(same));
+                                if (c == c0) act = false;
+                                m &= ~same;
+                            }
+                        }
                     }
+                }
+                pc = ec + 1;
+            }
+        }
+        __syncthreads();
+        // numeric histograms staged in LDS: value coding counts record 0 twice (phyNGSC.cpp:368 + tasks.cpp:175-177)
+        for (uint32_t f = 0; f < nf; ++f) {
+            const uint32_t k = s_k[f];
+            if (k == 0xff || !((need >> f) & 1) || fd[f].kind != KIND_NUM) continue;
+            const FieldDesc &d = fd[f];
+            if (owned) {
+                const uint32_t v = s_val[k][tid];
+                if (!d.delta_coding) {
+                    const uint32_t idx = v - (uint32_t)d.min_v;
+                    if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], i == 0 ? 2u : 1u);
+                } else if (i >= 1) {
+                    const uint32_t idx = v - s_val[k][tid - 1] - (uint32_t)d.min_d;
+                    if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], 1u);
                 }
             }
         }
-        pc = ec + 1;
+        __syncthreads();   // s_val is rewritten by the next batch
     }
-    __syncthreads();
-    // numeric histograms staged in LDS: value coding counts record 0 twice (phyNGSC.cpp:368 + tasks.cpp:175-177)
+    // flush
     for (uint32_t f = 0; f < nf; ++f) {
-        uint32_t k = s_k[f];
-        if (k == 0xff || !((need >> f) & 1) || fd[f].kind != KIND_NUM) continue;
-        const FieldDesc &d = fd[f];
-        if (owned) {
-            uint32_t v = s_val[k][tid];
-            if (!d.delta_coding) {
-                uint32_t idx = v - (uint32_t)d.min_v;
-                if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], i == 0 ? 2u : 1u);
-            } else if (i >= 1) {
-                uint32_t idx = v - s_val[k][tid - 1] - (uint32_t)d.min_d;
-                if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], 1u);
+        const uint32_t k = s_k[f];
+        if (k == 0xff || !((need >> f) & 1)) continue;
+        if (fd[f].kind == KIND_NUM) {
+            uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+            for (uint32_t x = tid; x < fd[f].n_sym; x += TS_THREADS)
+                if (s_nh[k][x]) atomicAdd(&nh[x], s_nh[k][x]);
+        } else {
+            uint32_t *ch = A.chist + (size_t)fd[f].slot * TEXT_TREES * 256;
+            for (uint32_t x = tid; x < TH_ROWS * 128; x += TS_THREADS) {
+                const uint32_t w = s_th[k][x / 128][x % 128];
+                if (w & 0xffffu) atomicAdd(&ch[(x / 128) * 256 + 2 * (x % 128)], w & 0xffffu);
+                if (w >> 16) atomicAdd(&ch[(x / 128) * 256 + 2 * (x % 128) + 1], w >> 16);
             }
         }
-    }
-    __syncthreads();
-    for (uint32_t f = 0; f < nf; ++f) {
-        uint32_t k = s_k[f];
-        if (k == 0xff) continue;
-        uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
-        for (uint32_t x = tid; x < fd[f].n_sym; x += TS_THREADS)
-            if (s_nh[k][x]) atomicAdd(&nh[x], s_nh[k][x]);
     }
 }
 
@@ -343,7 +388,7 @@ void launch_field_finalize(hipStream_t st, const Arena &A)
 
 void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv)
 {
-    dim3 grid((max_rec + TS_OWNED - 1) / TS_OWNED, A.n_sb);
+    dim3 grid((max_rec + TS_OWNED * TH_BATCHES - 1) / (TS_OWNED * TH_BATCHES), A.n_sb);
     hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u);
 }
 
