@@ -576,7 +576,19 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
-    if (sq_reg) { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec); }
+    if (sq_reg) {
+        // LDS staging of a 256-record tile's output, sized from what the sub-blocks really need (+25 %; a tile that
+        // needs more writes straight to the zeroed output)
+        uint32_t sw_q = 0, sw_d = 0;
+        for (uint32_t s = 0; s < S; ++s) {
+            const SbState &x = h_sb[s];
+            const uint32_t nr = x.n_rec ? x.n_rec : 1;
+            sw_q = std::max(sw_q, (uint32_t)(((uint64_t)x.qbits * 320 / nr) / 32) + 64);
+            sw_d = std::max(sw_d, (uint32_t)(((uint64_t)x.dbits * 320 / nr) / 32) + 64);
+        }
+        KScope k(c, st, "k_sq_pack_reg");
+        launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d);
+    }
     else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
     if ((rc = join())) return rc;

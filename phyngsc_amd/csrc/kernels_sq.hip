@@ -122,6 +122,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
 
         // ---- one pass over the 16-byte chunks: everything except the ambiguous positions ----
         uint32_t fl = 0, namb = 0;   // N-transfer test (phyNGSC.cpp:549-571): bit0 some ambiguity code, bit1 a failure
+        uint32_t nall = 0, apos0 = 0, apos1 = 0;   // non-ACGT bytes of the record and the positions of the first four
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
         if (L) {
             Sn = load16_unaligned(A.buf, s0, A.buf_len);
@@ -233,9 +234,12 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                     for (uint32_t u = 0; u < 16; ++u)
                         if ((glm >> u) & 1u) atomicAdd(&qh[(size_t)(16 * ch + u + 1) * 256 + sr_byte(qw, u)], 1u);
                 }
-                if (__any(ambm)) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 16; ++u) {
+                for (uint32_t k = 0; k < 4; ++k) {   // only the dwords in which some lane holds an ambiguity code
+                    if (!__any((ambm >> (4 * k)) & 15u)) continue;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t u = 4 * k + b;
                         if ((ambm >> u) & 1u) {
                             const uint32_t a = s_amb[sr_byte(sw, u)];
                             if (a == 0) fl |= 2;
@@ -244,6 +248,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                                 fl |= (q < 33 || q > 40) ? 2u : 1u;
                                 ++namb;
                             }
+                            // remember where it was (up to four per record) for the pass below
+                            const uint32_t p16 = 16 * ch + u;
+                            if (nall < 2) apos0 |= p16 << (16 * nall);
+                            else if (nall < 4) apos1 |= p16 << (16 * (nall - 2));
+                            ++nall;
                         }
                     }
                 }
@@ -257,9 +266,24 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         sum_l += L;
 
         // ---- the ambiguous positions, now that the record's transfer decision is known (phyNGSC.cpp:573-599) ----
-        if (__any(fl != 0)) {
-            for (uint32_t ch = 0; __any(fl != 0 && 16 * ch < L); ++ch) {
-                if (fl != 0 && 16 * ch < L) {
+        for (uint32_t k = 0; k < 4 && __any(nall > k && nall <= 4); ++k) {
+            if (nall > k && nall <= 4) {
+                const uint32_t pos = ((k < 2 ? apos0 : apos1) >> (16 * (k & 1))) & 0xffffu, row = pos + 1;
+                const uint32_t c = A.buf[s0 + pos], q = A.buf[q0 + pos];
+                const uint32_t a = s_amb[c];
+                if (xfer && a > 1) {
+                    atomicAdd(&qh[(size_t)row * 256 + transfer_quality(a, (uint8_t)q)], 1u);   // 128..247: no LDS column
+                } else {
+                    const uint32_t col = q - 33;
+                    if (col < SR_HCOLS && row < lds_rows) atomicAdd(&s_hist[row * SR_HSTRIDE + col], 1u);
+                    else atomicAdd(&qh[(size_t)row * 256 + q], 1u);
+                    atomicAdd(&s_occ[c], 1u);
+                }
+            }
+        }
+        if (__any(nall > 4)) {   // records with many ambiguity codes: rescan
+            for (uint32_t ch = 0; __any(nall > 4 && 16 * ch < L); ++ch) {
+                if (nall > 4 && 16 * ch < L) {
                     const uint32_t nv = L - 16 * ch < 16 ? L - 16 * ch : 16;
                     const uint4 S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
                     const uint4 Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
@@ -795,14 +819,9 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS, st, A, rows, tpw);
 }
 
-void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
 {
     const uint32_t rows = sr_rows_for(A.qrows, 4, 48u << 10);
-    // staging sized for typical streams (5 bits per quality symbol, 3 per base); a tile that needs more writes
-    // straight to the zeroed output with atomics
-    const uint32_t maxq = A.qrows - 1;
-    uint32_t sw_q = (uint32_t)(((uint64_t)SR_THREADS * maxq * 5) / 32) + 64;
-    uint32_t sw_d = (uint32_t)(((uint64_t)SR_THREADS * maxq * 3) / 32) + 64;
     if (sw_q > 8192) sw_q = 8192;
     if (sw_d > 6144) sw_d = 6144;
     const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
