@@ -348,7 +348,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     Carver cr2;
     size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * rec_cap), o_doff = cr2.take(4 * rec_cap);
     size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * rec_cap);
-    size_t o_tsep = cr2.take(8 * rec_cap);
+    size_t o_tsep = cr2.take(8 * rec_cap), o_apos = cr2.take(8 * rec_cap);
     rc = ensure(c, c->recs2, cr2.off);
     if (rc) return rc;
     uint8_t *rb2 = (uint8_t *)c->recs2.p;
@@ -436,6 +436,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.grp_lo = (uint32_t *)(pb + p_grplo);
     A.tbits = (uint32_t *)(rb2 + o_tbits);
     A.tsep = (uint64_t *)(rb2 + o_tsep);
+    A.apos = (uint2 *)(rb2 + o_apos);
     A.gflags = (uint32_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);

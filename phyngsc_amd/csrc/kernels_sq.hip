@@ -111,9 +111,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
         if (valid) {
-            // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it
-            // (bytes se .. se+3 are "\n+\n" and the first quality byte or the newline of an empty quality line)
-            if ((load4_unaligned(A.buf, se) & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
+            // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it.  Checked below from
+            // the bytes that follow the read inside its last 16-byte chunk; an empty read has no chunk:
+            if (L == 0 && (load4_unaligned(A.buf, se) & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
             if (i == 0 && L >= 2) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
                 const uint8_t c1 = A.buf[s0 + 1];
                 if (c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
@@ -137,6 +137,20 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                 Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            if (__any(nv != 0 && L <= 16 * ch + 16)) {   // some lane is at the end of its read: "\n+\n" follows
+                if (nv != 0 && L <= 16 * ch + 16) {
+                    uint32_t two;   // the two bytes after the read's newline
+                    if (nv <= 13) {
+                        const uint32_t o = nv + 1, wi = o >> 2;
+                        const uint32_t lo = wi == 0 ? sw[0] : (wi == 1 ? sw[1] : (wi == 2 ? sw[2] : sw[3]));
+                        const uint32_t hi = wi == 0 ? sw[1] : (wi == 1 ? sw[2] : sw[3]);
+                        two = __builtin_amdgcn_alignbit(hi, lo, (o & 3) * 8) & 0xffffu;
+                    } else {
+                        two = (load4_unaligned(A.buf, se) >> 8) & 0xffffu;
+                    }
+                    if (two != 0x0a2bu) atomicMin(A.err, (int32_t)ERR_FORMAT);
+                }
+            }
             uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
             const bool wany[4] = {true, (bool)__any(nv > 4), (bool)__any(nv > 8), (bool)__any(nv > 12)};   // words any lane still needs
 #pragma unroll
@@ -260,7 +274,10 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         }
         const bool xfer = (fl & 1) && !(fl & 2);
         const uint32_t kept = L - (xfer ? namb : 0);
-        if (valid) A.slen[g] = kept | ((uint32_t)xfer << 31);
+        if (valid) {
+            A.slen[g] = kept | ((nall < 7 ? nall : 7u) << 28) | ((uint32_t)xfer << 31);
+            if (nall >= 1 && nall <= 4) A.apos[g] = make_uint2(apos0, apos1);
+        }
         mq = L > mq ? L : mq;
         ms = kept > ms ? kept : ms;
         sum_l += L;
@@ -412,9 +429,15 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         const uint32_t s0 = te + 1, q0 = se + 3;
         const uint32_t sl = valid ? sl_n : 0;
         if (tile + 1 < tile_last && i + SR_THREADS < n) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; sl_n = A.slen[g + SR_THREADS]; }
-        const bool xfer = sl >> 31;
+        // A transferred record's quality codes differ from the table only at its (few) ambiguity codes.  With at most
+        // four of them their positions come from k_sq_stats_reg and the lengths are corrected after the loop (with 2-bit
+        // DNA the bases are then not read at all); otherwise the bases are scanned for them chunk by chunk.
+        const uint32_t nall = (sl >> 28) & 7u;
+        const bool xfer_d = sl >> 31;                 // for the DNA lengths: a transferred record drops its ambiguity codes
+        const bool by_list = xfer_d && nall <= 4;
+        const bool xfer = xfer_d && !by_list;         // for the quality lengths inside the chunk loop
         const bool need_s = !plain || __any(xfer);   // bases matter for the Huffman DNA lengths and for the transferred positions
-        uint32_t qb = 0, db = plain ? 2u * (sl & 0x7fffffffu) : 0u;
+        uint32_t qb = 0, db = plain ? 2u * (sl & 0x0fffffffu) : 0u;
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
         if (L) {
             Qn = load16_unaligned(A.buf, q0, A.buf_len);
@@ -493,12 +516,25 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 #pragma unroll
                         for (uint32_t b = 0; b < 4; ++b) {
                             if ((ambm >> (4 * k + b)) & 1u) {
-                                const uint32_t ll = xfer ? 0u : (s_dcode[sr_byte(sw, 4 * k + b)] & 31u);
+                                const uint32_t ll = xfer_d ? 0u : (s_dcode[sr_byte(sw, 4 * k + b)] & 31u);
                                 l4 = (l4 & ~(0xffu << (8 * b))) | (ll << (8 * b));
                             }
                         }
                     }
                     db = __builtin_amdgcn_sad_u8(l4, 0u, db);
+                }
+            }
+        }
+        if (__any(by_list && nall)) {
+            uint2 ap = make_uint2(0, 0);
+            if (by_list && nall) ap = A.apos[g];
+            for (uint32_t k = 0; k < 4 && __any(by_list && nall > k); ++k) {
+                if (by_list && nall > k) {
+                    const uint32_t pos = ((k < 2 ? ap.x : ap.y) >> (16 * (k & 1))) & 0xffffu, row = pos + 1;
+                    const uint32_t q = A.buf[q0 + pos], col = q - 33;
+                    const uint32_t l_tab = (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SR_HCOLS + col] : (sq_qentry_slow(T, row, q) & 31u);
+                    const uint32_t qt = transfer_quality(s_amb[A.buf[s0 + pos]], (uint8_t)q);   // phyNGSC.cpp:579
+                    qb += (sq_qentry_slow(T, row, qt) & 31u) - l_tab;
                 }
             }
         }

@@ -236,7 +236,8 @@ struct Arena {
     const uint8_t *buf;     // FASTQ bytes of the job
     uint32_t buf_len;
     const uint32_t *te, *se, *ls;   // record table: title end, sequence end, line start (ls has n+1 entries)
-    uint32_t *slen;         // per record: post-transfer sequence length | transfer flag << 31
+    uint32_t *slen;         // per record: post-transfer sequence length | non-ACGT count (0..6, 7 = more) << 28 | transfer flag << 31
+    uint2 *apos;            // per record with 1..4 non-ACGT bases: their positions, 16 bits each (k_sq_stats_reg)
     uint32_t *qoff;         // per record: quality payload bits, then exclusive offsets
     uint32_t *doff;         // per record: DNA payload bits, then exclusive offsets
     uint32_t *goff;         // per title group: bytes, then exclusive offsets
