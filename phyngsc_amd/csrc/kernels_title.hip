@@ -145,7 +145,11 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
             T.start[nf0] = (uint16_t)start;
             T.len[nf0] = (uint16_t)(p - start);
             uint8_t km = 0xff;
+            T.val0[nf0] = 0;
+            T.ovf0[nf0] = 0;
             if (parse_num(A.buf, ls0 + start, ls0 + p, v, o)) {   // only a numeric record 0 can leave the field numeric
+                T.val0[nf0] = v;
+                T.ovf0[nf0] = o ? 1 : 0;
                 if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; T.cand_f[ncand++] = (uint8_t)nf0; }
                 else { km = 0xfe; A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1; }
             }
@@ -680,7 +684,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         // field numeric, and record 0's own lane marks it non-numeric otherwise
         bool isn = false, ovf = false;
         uint32_t v = 0;
-        if (kk != 0xff) {
+        if (kk != 0xff && !__any(valid && !same)) {
+            // every lane holds record 0's (numeric) field: nothing to parse
+            isn = true;
+            v = s_r0.val0[f];
+            ovf = s_r0.ovf0[f] != 0;
+            if (kk < NUM_CAND_CAP) {
+                s_val[kk][tid] = v;
+                if (owned) A.tv[(size_t)kk * A.tw_stride + g] = v;
+            }
+            nummask |= 1u << f;
+        } else if (kk != 0xff) {
             const uint64_t dm = pos < 64 ? digmask >> pos : 0, lm = t_lowbits(len);
             isn = (dm & lm) == lm && len > 0 && !(len > 1 && (w0 & 0xffu) == '0');
             v = t_parse8(w0, w1, len);

@@ -225,6 +225,8 @@ struct Rec0Tab {
     uint8_t kmap[MAX_FIELDS];                     // numeric candidate index, 0xff = not numeric, 0xfe = untracked
     uint8_t cand_f[NUM_CAND_CAP];                 // candidate index -> field
     uint8_t title[REC0_TITLE_CAP];
+    uint32_t val0[MAX_FIELDS];                    // value of record 0's field where it is numeric (kmap != 0xff)
+    uint8_t ovf0[MAX_FIELDS];                     // ... and whether it exceeds INT32_MAX
     uint16_t woff[MAX_FIELDS];                    // dword offset of the field inside al
     uint32_t al[(REC0_TITLE_CAP + 8 * MAX_FIELDS) / 4];  // field-aligned copy, each field zero padded to 8 bytes
 };
