@@ -497,9 +497,12 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemcpyAsync(A.tile_lo, h_grp + S, 4 * (size_t)S, hipMemcpyHostToDevice, st));
 
     // ---- stage C: statistics, trees, measure.  The title chain and the sequence/quality chain share nothing
-    // until the trees are built, so they run on two streams (one is VALU-bound, the other waits on memory). ----
+    // until the trees are built and can run on two streams. ----
+    // NGSC_OVERLAP=1: the title chain on a second stream beside the sequence/quality chain.  Worth 2-3 % on the bench
+    // workload (both chains are limited by the same per-CU resources), so the default keeps everything on the
+    // caller's stream, where per-kernel timings mean what they say.
     const char *ov_env = getenv("NGSC_OVERLAP");
-    const bool overlap = !(ov_env && !strcmp(ov_env, "0"));
+    const bool overlap = ov_env && !strcmp(ov_env, "1");
     hipStream_t st2 = overlap ? c->side_stream : st;
     auto fork = [&]() -> int {
         if (!overlap) return NGSC_OK;
