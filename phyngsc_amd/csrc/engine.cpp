@@ -436,7 +436,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.grp_lo = (uint32_t *)(pb + p_grplo);
     A.tbits = (uint32_t *)(rb2 + o_tbits);
     A.tsep = (uint64_t *)(rb2 + o_tsep);
-    A.apos = (uint2 *)(rb2 + o_apos);
+    A.apos = (AmbPos *)(rb2 + o_apos);
     A.gflags = (uint32_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);

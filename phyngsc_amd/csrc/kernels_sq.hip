@@ -276,7 +276,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         const uint32_t kept = L - (xfer ? namb : 0);
         if (valid) {
             A.slen[g] = kept | ((nall < 7 ? nall : 7u) << 28) | ((uint32_t)xfer << 31);
-            if (nall >= 1 && nall <= 4) A.apos[g] = make_uint2(apos0, apos1);
+            if (nall >= 1 && nall <= 4) A.apos[g] = AmbPos{apos0, apos1};
         }
         mq = L > mq ? L : mq;
         ms = kept > ms ? kept : ms;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
             }
         }
         if (__any(by_list && nall)) {
-            uint2 ap = make_uint2(0, 0);
+            AmbPos ap = {0, 0};
             if (by_list && nall) ap = A.apos[g];
             for (uint32_t k = 0; k < 4 && __any(by_list && nall > k); ++k) {
                 if (by_list && nall > k) {

@@ -232,6 +232,8 @@ struct Rec0Tab {
 };
 static_assert(sizeof(Rec0Tab) % 4 == 0, "Rec0Tab is copied word-wise");
 
+struct AmbPos { uint32_t x, y; };   // positions 0,1 in x, 2,3 in y
+
 // Everything a kernel needs to find a sub-block's working memory.
 struct Arena {
     // job-wide
@@ -239,7 +241,7 @@ struct Arena {
     uint32_t buf_len;
     const uint32_t *te, *se, *ls;   // record table: title end, sequence end, line start (ls has n+1 entries)
     uint32_t *slen;         // per record: post-transfer sequence length | non-ACGT count (0..6, 7 = more) << 28 | transfer flag << 31
-    uint2 *apos;            // per record with 1..4 non-ACGT bases: their positions, 16 bits each (k_sq_stats_reg)
+    AmbPos *apos;           // per record with 1..4 non-ACGT bases: their positions, 16 bits each (k_sq_stats_reg)
     uint32_t *qoff;         // per record: quality payload bits, then exclusive offsets
     uint32_t *doff;         // per record: DNA payload bits, then exclusive offsets
     uint32_t *goff;         // per title group: bytes, then exclusive offsets
