@@ -115,10 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # NGSC_BENCH_REHEARSE=1: every rank on cuda:0 with gloo collectives - a dry run of the N > 1 path on a one-GPU box
+    # (RCCL refuses two ranks on one device); never used by the driver
+    rehearse = os.environ.get("NGSC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev   # where the (tiny) collective tensors live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     per_gpu = args.size_mb * 1_000_000
     RANKS_PER_GPU = 8
@@ -182,12 +191,12 @@ def main():
         sizes_local = [[b.size for b in api.plan_blocks(P, rk.rank, [res.subblocks[rk.first_subblock + k].size
                                                                      for k in range(rk.n_subblocks)])] for rk in res.ranks]
         meta_local = [(rk.n_subblocks, rk.overlap_used) for rk in res.ranks]
-        sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=dev)
+        sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=cdev)
         api.file_offsets(sizes_all)
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([my_raw, res.total_bytes], dtype=torch.int64, device=dev)
+        tot = torch.tensor([my_raw, res.total_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_raw, total_out = int(tot[0].item()), int(tot[1].item())
     else:
