@@ -823,10 +823,17 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-static uint32_t sr_records_per_wg()
+// Records per workgroup: enough to amortise the table fill / histogram flush (1024), but never so many that the job
+// has fewer than ~8 workgroups per CU - long reads mean few records per byte, and a 1024-record workgroup of
+// 150-bp reads left the 256 CUs with four workgroups each.  (NGSC_SQ_RECORDS_PER_WG overrides.)
+static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec)
 {
-    static const uint32_t v = getenv("NGSC_SQ_RECORDS_PER_WG") ? (uint32_t)atoi(getenv("NGSC_SQ_RECORDS_PER_WG")) : 1024;
-    return v < SR_THREADS ? SR_THREADS : v;
+    static const uint32_t forced = getenv("NGSC_SQ_RECORDS_PER_WG") ? (uint32_t)atoi(getenv("NGSC_SQ_RECORDS_PER_WG")) : 0;
+    if (forced) return forced < SR_THREADS ? SR_THREADS : forced / SR_THREADS * SR_THREADS;
+    const uint64_t records = (uint64_t)max_rec * A.n_sb;   // upper estimate of the job's records
+    uint32_t rpw = 1024;
+    while (rpw > SR_THREADS && records / rpw < 2048) rpw /= 2;
+    return rpw;
 }
 
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
@@ -834,7 +841,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
     if (rows > max_rows) rows = max_rows;
-    const uint32_t rpw = sr_records_per_wg();
+    const uint32_t rpw = sr_records_per_wg(A, max_rec);
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
     const size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_stats_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
@@ -850,7 +857,7 @@ static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budge
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
-    const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS, st, A, rows, tpw);
 }
@@ -860,7 +867,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     const uint32_t rows = sr_rows_for(A.qrows, 4, 48u << 10);
     if (sw_q > 8192) sw_q = 8192;
     if (sw_d > 6144) sw_d = 6144;
-    const uint32_t tpw = sr_records_per_wg() / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     const size_t lds = ((size_t)rows * SR_HCOLS + sw_q + sw_d) * 4;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_pack_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
