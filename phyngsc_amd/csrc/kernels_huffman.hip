@@ -10,25 +10,34 @@
 // merge + code walk + pre-order serialisation by lane 0 (n <= 512, a few hundred LDS steps).
 // Latency-bound, negligible bytes: no roofline claim attached to this kernel.
 #include "ngsc_kernels.h"
+#include <type_traits>
 
 namespace ngsc {
 
-struct TreeLds {
-    uint64_t keys[MAX_NUM_HUF];
-    uint64_t sorted[MAX_NUM_HUF];
-    uint32_t ifreq[MAX_NUM_HUF];
-    uint32_t code[2 * MAX_NUM_HUF];
-    uint16_t lc[2 * MAX_NUM_HUF];
-    uint16_t rc[2 * MAX_NUM_HUF];
-    uint16_t stack[2 * MAX_NUM_HUF + 2];
-    uint8_t len[2 * MAX_NUM_HUF];
-    uint8_t blob[BLOB_SLOT_512];
+// Working set of one tree of up to CAP symbols.  The 512-symbol version (numeric title fields) is 26 KB, i.e.
+// six single-wave workgroups per CU; quality and DNA alphabets almost always fit 64 symbols (2.7 KB), which lets
+// a CU build 5x more trees at a time - the lane-0 merge is latency, not throughput.
+template <uint32_t CAP, uint32_t BLOB>
+struct TreeLdsT {
+    uint64_t keys[CAP];
+    uint64_t sorted[CAP];
+    uint32_t ifreq[CAP];
+    uint32_t code[2 * CAP];
+    uint16_t lc[2 * CAP];
+    uint16_t rc[2 * CAP];
+    uint16_t stack[2 * CAP + 2];
+    uint8_t len[2 * CAP];
+    uint8_t blob[BLOB];
     uint32_t blob_len;
     uint32_t max_len;
 };
+using TreeLds = TreeLdsT<MAX_NUM_HUF, BLOB_SLOT_512>;
+constexpr uint32_t SMALL_TREE = 64;
+using TreeLdsSmall = TreeLdsT<SMALL_TREE, 160>;
 
 // keys[0..n) must be filled (by all lanes) before the call.  Leaves T.code/T.len/T.blob/T.blob_len.
-__device__ void build_tree_wave(TreeLds &T, uint32_t n)
+template <class Tree>
+__device__ void build_tree_wave(Tree &T, uint32_t n)
 {
     const int lane = threadIdx.x & 63;
     __syncthreads();
@@ -47,14 +56,19 @@ __device__ void build_tree_wave(TreeLds &T, uint32_t n)
     __syncthreads();
 }
 
-// grid: (qrows + 1 + MAX_FIELDS, n_sb); block: 64 threads (one wave)
+// grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
+// sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
+template <bool SMALL>
 __global__ __launch_bounds__(64) void k_huffman_sb(Arena A)
 {
     if (*A.err) return;
-    __shared__ TreeLds T;
+    using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
+    __shared__ Tree T;
     const uint32_t s = blockIdx.y, t = blockIdx.x;
     const int lane = threadIdx.x;
     const SbState &sb = A.sb[s];
+    const bool fits_small = sb.nqual <= SMALL_TREE && sb.nsym <= SMALL_TREE;
+    if (t <= A.qrows && fits_small != SMALL) return;
     if (t < A.qrows) {
         // quality tree of row t (row 0: global statistics; row k+1: position k), tasks.cpp:590-605
         if (t > sb.max_q) return;
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(64) void k_huffman_sb(Arena A)
         if (lane == 0) A.dblob_len[s] = T.blob_len;
     } else {
         // numeric title field tree (tasks.cpp:338-347)
+        if (SMALL) return;   // (never launched for these)
         const uint32_t f = t - A.qrows - 1;
         if (f >= sb.nf) return;
         const FieldDesc &d = A.fdesc[(size_t)s * MAX_FIELDS + f];
@@ -131,7 +146,8 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A)
 
 void launch_huffman_sb(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_huffman_sb, dim3(A.qrows + 1 + MAX_FIELDS, A.n_sb), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1 + MAX_FIELDS, A.n_sb), dim3(64), 0, st, A);
 }
 
 void launch_huffman_text(hipStream_t st, const Arena &A)
