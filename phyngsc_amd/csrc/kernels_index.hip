@@ -12,8 +12,8 @@ namespace ngsc {
 constexpr int TILE_THREADS = 256;
 constexpr int BYTES_PER_THREAD = 32;
 constexpr uint32_t PIECE_BYTES = TILE_THREADS * BYTES_PER_THREAD;  // 8 KiB per coalesced piece
-constexpr uint32_t PIECES = 4;                                     // pieces per workgroup
-constexpr uint32_t TILE_BYTES = PIECE_BYTES * PIECES;              // 32 KiB per workgroup: 4x fewer counts to scan
+constexpr uint32_t PIECES = 8;                                     // pieces per workgroup
+constexpr uint32_t TILE_BYTES = PIECE_BYTES * PIECES;              // 64 KiB per workgroup: fewer tile counts for the single-workgroup scan
 
 // exact per-byte "== 0" flags (bit 7 of each byte) of a 32-bit word
 __device__ __forceinline__ uint32_t zero_bytes(uint32_t y)

@@ -124,54 +124,60 @@ __device__ __forceinline__ uint32_t t_parse8(uint32_t w0, uint32_t w1, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// One wave per sub-block: the table is built in LDS (lanes fetch the title and clear the table together, lane 0
+// walks the ~40 bytes) and copied out with coalesced stores.
 __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
 {
     if (*A.err) return;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= A.n_sb) return;
+    const uint32_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ Rec0Tab T;
     const SbState &sb = A.sb[s];
-    Rec0Tab &T = A.rec0[s];
     const uint32_t ls0 = A.ls[sb.rec_lo], te0 = A.te[sb.rec_lo];
     const uint32_t tlen = te0 - ls0 + 1;
-    if (tlen > REC0_TITLE_CAP) { atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
-    uint32_t nf0 = 0, ncand = 0, start = 0;
-    for (uint32_t p = 0; p < tlen; ++p) {
-        const uint8_t c = A.buf[ls0 + p];
-        T.title[p] = c;
-        if (!is_sep(c)) continue;
-        if (nf0 < MAX_FIELDS) {
-            uint32_t v;
-            bool o;
-            T.start[nf0] = (uint16_t)start;
-            T.len[nf0] = (uint16_t)(p - start);
-            uint8_t km = 0xff;
-            T.val0[nf0] = 0;
-            T.ovf0[nf0] = 0;
-            if (parse_num(A.buf, ls0 + start, ls0 + p, v, o)) {   // only a numeric record 0 can leave the field numeric
-                T.val0[nf0] = v;
-                T.ovf0[nf0] = o ? 1 : 0;
-                if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; T.cand_f[ncand++] = (uint8_t)nf0; }
-                else { km = 0xfe; A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1; }
+    if (tlen > REC0_TITLE_CAP) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
+    for (uint32_t k = lane; k < sizeof(Rec0Tab) / 4; k += 64) reinterpret_cast<uint32_t *>(&T)[k] = 0;
+    __syncthreads();
+    for (uint32_t p = lane; p < tlen; p += 64) T.title[p] = A.buf[ls0 + p];
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t nf0 = 0, ncand = 0, start = 0;
+        for (uint32_t p = 0; p < tlen; ++p) {
+            if (!is_sep(T.title[p])) continue;
+            if (nf0 < MAX_FIELDS) {
+                uint32_t v;
+                bool o;
+                T.start[nf0] = (uint16_t)start;
+                T.len[nf0] = (uint16_t)(p - start);
+                uint8_t km = 0xff;
+                if (parse_num(T.title, start, p, v, o)) {   // only a numeric record 0 can leave the field numeric
+                    T.val0[nf0] = v;
+                    T.ovf0[nf0] = o ? 1 : 0;
+                    if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; T.cand_f[ncand++] = (uint8_t)nf0; }
+                    else { km = 0xfe; A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1; }
+                }
+                T.kmap[nf0] = km;
             }
-            T.kmap[nf0] = km;
+            ++nf0;
+            start = p + 1;
         }
-        ++nf0;
-        start = p + 1;
+        // field-aligned copy of the title for the word-parallel path: every field starts on a dword and is zero
+        // padded to a multiple of eight bytes
+        uint32_t wcur = 0;
+        uint8_t *al = reinterpret_cast<uint8_t *>(T.al);
+        for (uint32_t f = 0; f < nf0 && f < MAX_FIELDS; ++f) {
+            T.woff[f] = (uint16_t)wcur;
+            for (uint32_t k = 0; k < T.len[f]; ++k) al[4 * wcur + k] = T.title[T.start[f] + k];
+            wcur += 2 * ((T.len[f] + 7u) / 8u);
+        }
+        T.nf0 = nf0;
+        T.ncand = ncand;
+        A.sb[s].nf = nf0;
+        if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
     }
-    // field-aligned copy of the title for the word-parallel path: every field starts on a dword and is zero
-    // padded to a multiple of eight bytes
-    uint32_t wcur = 0;
-    uint8_t *al = reinterpret_cast<uint8_t *>(T.al);
-    for (uint32_t k = 0; k < sizeof(T.al); ++k) al[k] = 0;
-    for (uint32_t f = 0; f < nf0 && f < MAX_FIELDS; ++f) {
-        T.woff[f] = (uint16_t)wcur;
-        for (uint32_t k = 0; k < T.len[f]; ++k) al[4 * wcur + k] = T.title[T.start[f] + k];
-        wcur += 2 * ((T.len[f] + 7u) / 8u);
-    }
-    T.nf0 = nf0;
-    T.ncand = ncand;
-    A.sb[s].nf = nf0;
-    if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
+    __syncthreads();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(A.rec0 + s);
+    for (uint32_t k = lane; k < sizeof(Rec0Tab) / 4; k += 64) dst[k] = reinterpret_cast<const uint32_t *>(&T)[k];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
 // ---- launchers ---------------------------------------------------------------------------------------
 void launch_rec0_fields(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_rec0_fields, dim3((A.n_sb + 63) / 64), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_rec0_fields, dim3(A.n_sb), dim3(64), 0, st, A);
 }
 
 void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
