@@ -1,0 +1,58 @@
+"""Crafted FASTQ inputs that sit on the decision boundaries of the GPU kernels (path switches, exception paths).
+Shared by the CPU tests (the oracle accepts them and round-trips them) and the GPU parity tests."""
+import random
+
+
+def _fq(recs):
+    return b"".join(b"@%s\n%s\n+\n%s\n" % r for r in recs)
+
+
+def build():
+    rnd = random.Random(7)
+    cases = {}
+    # title lines of 63..66 bytes: the word-parallel title kernels take titles of up to 64 bytes
+    for tl in (63, 64, 65, 66):
+        recs = []
+        for i in range(4000):
+            t = b"r%d " % (i * 7919 % 100000)
+            t = t + b"x" * (tl - 2 - len(t))        # '@' + t + '\n' = tl bytes
+            recs.append((t, b"ACGT" * 9, bytes(rnd.choice(b"ABCDEFGHI") for _ in range(36))))
+        cases["title_len_%d" % tl] = (_fq(recs), 2)
+    # empty reads and reads of 1..50 bases: tails of every length, records without a single 16-byte chunk
+    recs = []
+    for i in range(6000):
+        L = 0 if i % 97 == 5 else 1 + (i * 31 % 50)
+        recs.append((b"e.%d" % i, bytes(rnd.choice(b"ACGT") for _ in range(L)), bytes(rnd.choice(b"!#5?IJ") for _ in range(L))))
+    cases["len_0_to_50"] = (_fq(recs), 3)
+    # 0..7 transferred N per record (the position list holds four) and all-N reads
+    recs = []
+    for i in range(5000):
+        L = 40
+        s = bytearray(rnd.choice(b"ACGT") for _ in range(L))
+        q = bytearray(rnd.choice(b"5?IJ") for _ in range(L))
+        nn = L if i % 50 == 0 else i % 8
+        for p in rnd.sample(range(L), nn):
+            s[p] = ord("N")
+            q[p] = ord(rnd.choice("!#"))
+        recs.append((b"n.%d" % i, bytes(s), bytes(q)))
+    cases["n_counts"] = (_fq(recs), 2)
+    # quality bytes outside the 64 LDS columns ('a'..'~') and IUPAC codes with high quality (Huffman-coded DNA)
+    recs = []
+    for i in range(5000):
+        L = 36
+        s = bytearray(rnd.choice(b"ACGT") for _ in range(L))
+        q = bytearray(rnd.choice(b"IJKabcxyz~") for _ in range(L))
+        if i % 3 == 0:
+            s[i % L] = ord(rnd.choice("RYKMSWN"))
+        recs.append((b"q.%d" % i, bytes(s), bytes(q)))
+    cases["odd_quals_iupac"] = (_fq(recs), 2)
+    # records just below and above 2 KB (register-streaming vs wave-per-record kernels)
+    for L in (980, 1015, 1030):
+        recs = [(b"L.%d" % i, bytes(rnd.choice(b"ACGT") for _ in range(L)), bytes(rnd.choice(b"5?IJ") for _ in range(L)))
+                for i in range(600)]
+        cases["reclen_%d" % L] = (_fq(recs), 2)
+    # lowercase bases: not ambiguity codes, never transferred, part of the DNA alphabet
+    recs = [(b"lc.%d" % i, bytes(rnd.choice(b"ACGTacgtn") for _ in range(36)), bytes(rnd.choice(b"!#5I") for _ in range(36)))
+            for i in range(5000)]
+    cases["lowercase"] = (_fq(recs), 2)
+    return cases

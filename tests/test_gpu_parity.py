@@ -357,3 +357,20 @@ def test_round_trip_generated(eng, cfg, size, P):
     data = fastq_gen.generate(cfg, target_bytes=size)
     _, out = _gpu(eng, data, P)
     assert orc.decompress(out) == data.tobytes()
+
+
+def _edge_cases():
+    from tests.edge_cases import build
+    return build()
+
+
+@pytest.mark.parametrize("name", sorted(_edge_cases()))
+def test_edge_cases(eng, name):
+    """Inputs on the decision boundaries of the kernels (title length 64/65, empty and very short reads, 0..7 and
+    all-N reads, quality bytes outside the LDS columns, IUPAC codes, records around 2 KB, lowercase bases):
+    bit-exact against the oracle, and the output decodes to the input."""
+    data, P = _edge_cases()[name]
+    _, out = _gpu(eng, data, P)
+    want, _ = orc.compress_file(data, P)
+    assert out == want
+    assert orc.decompress(out) == data

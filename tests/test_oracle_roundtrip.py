@@ -67,3 +67,12 @@ def test_truncated_or_corrupt_subblock_is_rejected():
     bad[0:4] = b"\xff\xff\xff\xff"   # absurd record count
     with pytest.raises(orc.OracleError):
         orc.decode_subblock(bytes(bad))
+
+
+def test_edge_cases_round_trip_on_the_oracle():
+    """The crafted boundary inputs of tests/edge_cases.py (used by the GPU parity tests) are valid for the oracle and
+    survive encode -> decode."""
+    from tests.edge_cases import build
+    for name, (data, P) in build().items():
+        out, _ = orc.compress_file(data, P)
+        assert orc.decompress(out) == data, name
