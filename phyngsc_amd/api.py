@@ -110,8 +110,13 @@ class Engine:
         nsb = self._L.ngsc_result_num_subblocks(self._h)
         nrk = self._L.ngsc_result_num_ranks(self._h)
         sp, rp = self._L.ngsc_result_subblocks(self._h), self._L.ngsc_result_ranks(self._h)
-        sbs = [_copy_struct(sp[i]) for i in range(nsb)]
-        rks = [_copy_struct(rp[i]) for i in range(nrk)]
+        # one memmove per table (the context reuses its result storage on the next call)
+        sbs = (SubBlock * nsb)()
+        rks = (Rank * nrk)()
+        if nsb:
+            ctypes.memmove(sbs, sp, ctypes.sizeof(sbs))
+        if nrk:
+            ctypes.memmove(rks, rp, ctypes.sizeof(rks))
         return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
 
     def compress_file(self, in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
