@@ -151,7 +151,9 @@ int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path,
  * so the file is byte-identical for every n_ctx.  This replaces the reference's `mpiexec -np P`
  * fan-out (phyNGSC.cpp:45-57, 113-116) when one host drives several GPUs; there is no device-to-
  * device traffic, only the per-rank block lists meet on the host (phyNGSC.cpp:875-1057).
- * Every context's byte range (file_size / n_ctx + slack) must stay below 4 GiB.
+ * Files of any size: every context walks its ranks in jobs of consecutive ranks below the engine's
+ * 4 GiB job limit, reading each job's byte range from the file itself; only one rank's region
+ * (file_size / P) has to stay below 4 GiB.
  */
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
                              double *seconds_out);

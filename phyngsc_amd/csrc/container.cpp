@@ -153,45 +153,98 @@ static bool write_all(int fd, const void *p, size_t n)
     return true;
 }
 
-// One worker = one context (= one GPU): uploads the byte range of its virtual ranks, compresses them and
-// brings the sub-block streams back.  Workers share nothing but the read-only input.
+// One worker = one context (= one GPU).  It walks its virtual ranks in JOBS of consecutive ranks whose byte range
+// stays below the engine's 4 GiB limit (NGSC_JOB_BYTES lowers the limit for tests): reads the range from the file
+// into pinned memory, uploads, compresses, brings the sub-block streams back.  Workers share nothing but the file.
 struct Worker {
     ngsc_ctx *ctx = nullptr;
     uint32_t rank_lo = 0, rank_hi = 0;
     int rc = NGSC_OK;
-    std::vector<uint8_t> host;              // this worker's sub-block bytes
-    std::vector<ngsc_rank_t> ranks;
+    double io_s = 0;                        // time spent reading the file
+    std::vector<uint8_t> host;              // this worker's sub-block bytes, rank after rank
+    std::vector<ngsc_rank_t> ranks;         // stream_off relative to host, first_subblock into sb_sizes
     std::vector<uint32_t> sb_sizes;         // per sub-block, in result order
-    std::vector<uint32_t> sb_first;         // per local rank: first index into sb_sizes
 };
 
-static void run_worker(Worker *w, const uint8_t *h_in, uint64_t FS, uint32_t P)
+static uint64_t job_limit()
+{
+    const char *e = getenv("NGSC_JOB_BYTES");
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v ? v : 0xE0000000ull;   // 3.5 GiB
+}
+
+// byte range of ranks [a, b) (phyNGSC.cpp:113-116) + slack for the record that straddles the end
+static void job_range(uint64_t FS, uint32_t P, uint32_t a, uint32_t b, uint64_t &lo, uint64_t &hi)
+{
+    const RankGeom g0 = rank_geometry(FS, P, a), g1 = rank_geometry(FS, P, b - 1);
+    lo = (uint64_t)g0.wr_start & ~15ull;
+    hi = std::min<uint64_t>(FS, (uint64_t)g1.wr_end + 1 + 65536);
+}
+
+static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
 {
     if (hipSetDevice(ngsc_ctx_device(w->ctx)) != hipSuccess) { w->rc = NGSC_ERR_HIP; return; }
-    // byte range of the ranks (phyNGSC.cpp:113-116) + slack for the record that straddles the end
-    const RankGeom g0 = rank_geometry(FS, P, w->rank_lo), g1 = rank_geometry(FS, P, w->rank_hi - 1);
-    const uint64_t lo = (uint64_t)g0.wr_start & ~15ull;
-    const uint64_t hi = std::min<uint64_t>(FS, (uint64_t)g1.wr_end + 1 + 65536);
-    const uint64_t len = hi - lo;
-    if (len >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; return; }  // one job < 4 GiB: use more GPUs / ranks
-    void *d_in = nullptr, *d_out = nullptr;
-    const uint64_t out_cap = len + (len >> 2) + (64u << 20);
-    if (hipMalloc(&d_in, len + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess) w->rc = NGSC_ERR_HIP;
-    if (!w->rc && hipMemcpy(d_in, h_in + lo, len, hipMemcpyHostToDevice) != hipSuccess) w->rc = NGSC_ERR_HIP;
-    if (!w->rc) w->rc = ngsc_compress_device(w->ctx, d_in, len, lo, FS, P, w->rank_lo, w->rank_hi, d_out, out_cap, nullptr);
-    if (!w->rc) {
-        const uint64_t total = ngsc_result_bytes(w->ctx);
-        w->host.resize(total);
-        if (total && hipMemcpy(w->host.data(), d_out, total, hipMemcpyDeviceToHost) != hipSuccess) w->rc = NGSC_ERR_HIP;
+    int fd = ::open(in_path, O_RDONLY);
+    if (fd < 0) { w->rc = NGSC_ERR_IO; return; }
+    const uint64_t limit = job_limit();
+    // the jobs, and the largest one (buffers are allocated once)
+    std::vector<std::pair<uint32_t, uint32_t>> jobs;
+    uint64_t max_len = 0;
+    for (uint32_t a = w->rank_lo; a < w->rank_hi;) {
+        uint32_t b = a + 1;
+        uint64_t lo, hi;
+        job_range(FS, P, a, b, lo, hi);
+        if (hi - lo >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; break; }   // one rank alone is too big: use more ranks
+        while (b < w->rank_hi) {
+            uint64_t lo2, hi2;
+            job_range(FS, P, a, b + 1, lo2, hi2);
+            if (hi2 - lo2 > limit) break;
+            ++b;
+            hi = hi2;
+        }
+        max_len = std::max(max_len, hi - lo);
+        jobs.emplace_back(a, b);
+        a = b;
+    }
+    void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr;
+    const uint64_t out_cap = max_len + (max_len >> 2) + (64u << 20);
+    if (!w->rc && (hipMalloc(&d_in, max_len + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess ||
+                   hipHostMalloc(&h_in, max_len + 64, hipHostMallocDefault) != hipSuccess)) w->rc = NGSC_ERR_HIP;
+    for (size_t j = 0; j < jobs.size() && !w->rc; ++j) {
+        uint64_t lo, hi;
+        job_range(FS, P, jobs[j].first, jobs[j].second, lo, hi);
+        const uint64_t len = hi - lo;
+        const double t0 = now_s();
+        uint64_t got = 0;
+        while (got < len) {
+            const ssize_t r = ::pread(fd, (uint8_t *)h_in + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(lo + got));
+            if (r <= 0) break;
+            got += (uint64_t)r;
+        }
+        w->io_s += now_s() - t0;
+        if (got != len) { w->rc = NGSC_ERR_IO; break; }
+        if (hipMemcpy(d_in, h_in, len, hipMemcpyHostToDevice) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
+        w->rc = ngsc_compress_device(w->ctx, d_in, len, lo, FS, P, jobs[j].first, jobs[j].second, d_out, out_cap, nullptr);
+        if (w->rc) break;
+        const uint64_t total = ngsc_result_bytes(w->ctx), base = w->host.size();
+        w->host.resize(base + total);
+        if (total && hipMemcpy(w->host.data() + base, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
         const ngsc_subblock_t *sbs = ngsc_result_subblocks(w->ctx);
         const ngsc_rank_t *rks = ngsc_result_ranks(w->ctx);
         const uint32_t nr = ngsc_result_num_ranks(w->ctx), ns = ngsc_result_num_subblocks(w->ctx);
-        w->ranks.assign(rks, rks + nr);
-        w->sb_sizes.resize(ns);
-        for (uint32_t k = 0; k < ns; ++k) w->sb_sizes[k] = sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len;
+        const uint32_t sb_base = (uint32_t)w->sb_sizes.size();
+        for (uint32_t k = 0; k < nr; ++k) {
+            ngsc_rank_t rk = rks[k];
+            rk.stream_off += base;
+            rk.first_subblock += sb_base;
+            w->ranks.push_back(rk);
+        }
+        for (uint32_t k = 0; k < ns; ++k) w->sb_sizes.push_back(sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len);
     }
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
+    if (h_in) (void)hipHostFree(h_in);
+    ::close(fd);
 }
 
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
@@ -201,35 +254,21 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     for (uint32_t i = 0; i < n_ctx; ++i)
         if (!ctxs[i]) return NGSC_ERR_ARG;
     double t0 = now_s();
-    int fd = ::open(in_path, O_RDONLY);
-    if (fd < 0) return NGSC_ERR_IO;
     struct stat sbuf;
-    if (fstat(fd, &sbuf) != 0 || sbuf.st_size <= 0) { ::close(fd); return NGSC_ERR_IO; }
+    if (::stat(in_path, &sbuf) != 0 || sbuf.st_size <= 0) return NGSC_ERR_IO;
     const uint64_t FS = (uint64_t)sbuf.st_size;
-    void *h_in = nullptr;
-    if (hipSetDevice(ngsc_ctx_device(ctxs[0])) != hipSuccess ||
-        hipHostMalloc(&h_in, FS + 64, hipHostMallocPortable) != hipSuccess) { ::close(fd); return NGSC_ERR_HIP; }
-    uint64_t got = 0;
-    while (got < FS) {
-        ssize_t r = ::read(fd, (uint8_t *)h_in + got, (size_t)std::min<uint64_t>(FS - got, 1u << 30));
-        if (r <= 0) break;
-        got += (uint64_t)r;
-    }
-    ::close(fd);
-    if (got != FS) { (void)hipHostFree(h_in); return NGSC_ERR_IO; }
     double t1 = now_s();
 
     // virtual ranks are dealt to the contexts in contiguous runs (P is a multiple of the context count)
     std::vector<Worker> workers(n_ctx);
     const uint32_t per = P / n_ctx;
     for (uint32_t i = 0; i < n_ctx; ++i) { workers[i].ctx = ctxs[i]; workers[i].rank_lo = i * per; workers[i].rank_hi = (i + 1) * per; }
-    if (n_ctx == 1) run_worker(&workers[0], (const uint8_t *)h_in, FS, P);
+    if (n_ctx == 1) run_worker(&workers[0], in_path, FS, P);
     else {
         std::vector<std::thread> th;
-        for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], (const uint8_t *)h_in, FS, P);
+        for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], in_path, FS, P);
         for (auto &t : th) t.join();
     }
-    (void)hipHostFree(h_in);
     double t2 = now_s();
     for (auto &w : workers)
         if (w.rc) return w.rc;
@@ -272,7 +311,9 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     okw = okw && write_all(ofd, footer.data(), fl);
     ::close(ofd);
     double t3 = now_s();
-    if (seconds_out) { seconds_out[0] = t1 - t0; seconds_out[1] = t2 - t1; seconds_out[2] = t3 - t2; }
+    double io = 0;
+    for (auto &w : workers) io = std::max(io, w.io_s);
+    if (seconds_out) { seconds_out[0] = (t1 - t0) + io; seconds_out[1] = (t2 - t1) - io; seconds_out[2] = t3 - t2; }
     return okw ? NGSC_OK : NGSC_ERR_IO;
 }
 

@@ -71,11 +71,11 @@ int main(int argc, char **argv)
         destroy_all();
         return rc == NGSC_ERR_IO ? 2 : 3;
     }
-    unsigned nsb = 0;
-    unsigned long long bytes = 0;
-    for (ngsc_ctx *c : ctxs) { nsb += ngsc_result_num_subblocks(c); bytes += ngsc_result_bytes(c); }
-    printf("\nRANKS\tREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tN_SUBBLOCKS\tOUT_BYTES\n");
-    printf("%u\t%f\t%f\t%f\t%u\t\t%llu\n", P, sec[0], sec[1], sec[2], nsb, bytes);
+    // (a context's result tables describe its last job only: report the file that was written)
+    unsigned long long out_bytes = 0;
+    if (FILE *f = fopen(out, "rb")) { fseek(f, 0, SEEK_END); out_bytes = (unsigned long long)ftell(f); fclose(f); }
+    printf("\nRANKS\tREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tOUT_BYTES\n");
+    printf("%u\t%f\t%f\t%f\t%llu\n", P, sec[0], sec[1], sec[2], out_bytes);
     destroy_all();
     return 0;
 }

@@ -316,7 +316,7 @@ def test_cli_file_to_file(tmp_path):
     assert subprocess.run([exe, "/nonexistent.fastq", str(outp)], capture_output=True).returncode == 2
 
 
-def test_multi_context_file_driver(tmp_path):
+def test_multi_context_file_driver(tmp_path, monkeypatch):
     """ngsc_compress_file_multi: two contexts (here both on device 0, on two host threads) write the same
     file as one context -- the single-process multi-GPU driver (phyNGSC.cpp:113-116 rank split)."""
     data = fastq_gen.generate(fastq_gen.CFG5, target_bytes=30_000_000)
@@ -328,6 +328,13 @@ def test_multi_context_file_driver(tmp_path):
         outp = tmp_path / f"{name}.ngsc"
         api.compress_file_multi(engines, str(inp), str(outp), 8)
         assert outp.read_bytes() == want, name
+    # files larger than one engine job (4 GiB) are walked in jobs of consecutive ranks: force tiny jobs here
+    monkeypatch.setenv("NGSC_JOB_BYTES", str(9_000_000))   # a rank is 3.75 MB: two ranks per job
+    for engines, name in (([e0], "one_jobs"), ([e0, e1], "two_jobs")):
+        outp = tmp_path / f"{name}.ngsc"
+        api.compress_file_multi(engines, str(inp), str(outp), 8)
+        assert outp.read_bytes() == want, name
+    monkeypatch.delenv("NGSC_JOB_BYTES")
     with pytest.raises(api.NgscError) as ei:      # 8 ranks cannot be dealt to 3 contexts
         api.compress_file_multi([e0, e1, api.Engine(0)], str(inp), str(tmp_path / "x.ngsc"), 8)
     assert ei.value.code == -7
