@@ -14,7 +14,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -153,16 +155,17 @@ static bool write_all(int fd, const void *p, size_t n)
     return true;
 }
 
-// One worker = one context (= one GPU).  It walks its virtual ranks in JOBS of consecutive ranks whose byte range
-// stays below the engine's 4 GiB limit (NGSC_JOB_BYTES lowers the limit for tests): reads the range from the file
-// into pinned memory, uploads, compresses, brings the sub-block streams back.  Workers share nothing but the file.
+// One worker = one context (= one GPU).  It walks its virtual ranks in JOBS of consecutive ranks of about 512 MiB
+// (NGSC_JOB_BYTES sets the size; the engine's own limit is 4 GiB per job): a job's byte range is read from the file
+// into pinned memory, uploaded, compressed, and its sub-block streams brought back.  Workers share nothing but the file.
 struct Worker {
     ngsc_ctx *ctx = nullptr;
     uint32_t rank_lo = 0, rank_hi = 0;
     int rc = NGSC_OK;
     double io_s = 0;                        // time spent reading the file
-    std::vector<uint8_t> host;              // this worker's sub-block bytes, rank after rank
-    std::vector<ngsc_rank_t> ranks;         // stream_off relative to host, first_subblock into sb_sizes
+    std::vector<uint8_t *> chunks;          // one pinned buffer per job: its sub-block bytes, rank after rank
+    std::vector<const uint8_t *> rank_ptr;  // per entry of ranks: where that rank's stream starts
+    std::vector<ngsc_rank_t> ranks;         // first_subblock into sb_sizes
     std::vector<uint32_t> sb_sizes;         // per sub-block, in result order
 };
 
@@ -170,7 +173,7 @@ static uint64_t job_limit()
 {
     const char *e = getenv("NGSC_JOB_BYTES");
     const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-    return v ? v : 0xE0000000ull;   // 3.5 GiB
+    return v ? v : (512ull << 20);   // 512 MiB jobs: big enough for the kernels, small enough to overlap IO with compute
 }
 
 // byte range of ranks [a, b) (phyNGSC.cpp:113-116) + slack for the record that straddles the end
@@ -181,11 +184,21 @@ static void job_range(uint64_t FS, uint32_t P, uint32_t a, uint32_t b, uint64_t 
     hi = std::min<uint64_t>(FS, (uint64_t)g1.wr_end + 1 + 65536);
 }
 
+// Two-stage pipeline per worker: a reader thread fills one of two pinned buffers from the file and uploads it
+// while the worker thread compresses the previous job and brings its streams back.
+struct JobPipe {
+    std::mutex m;
+    std::condition_variable cv;
+    int uploaded = 0;    // jobs whose input is in device memory
+    int consumed = 0;    // jobs whose compression is finished (their input buffers are free again)
+    int reader_rc = NGSC_OK;
+    bool abort = false;
+};
+
 static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
 {
-    if (hipSetDevice(ngsc_ctx_device(w->ctx)) != hipSuccess) { w->rc = NGSC_ERR_HIP; return; }
-    int fd = ::open(in_path, O_RDONLY);
-    if (fd < 0) { w->rc = NGSC_ERR_IO; return; }
+    const int dev = ngsc_ctx_device(w->ctx);
+    if (hipSetDevice(dev) != hipSuccess) { w->rc = NGSC_ERR_HIP; return; }
     const uint64_t limit = job_limit();
     // the jobs, and the largest one (buffers are allocated once)
     std::vector<std::pair<uint32_t, uint32_t>> jobs;
@@ -194,7 +207,7 @@ static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
         uint32_t b = a + 1;
         uint64_t lo, hi;
         job_range(FS, P, a, b, lo, hi);
-        if (hi - lo >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; break; }   // one rank alone is too big: use more ranks
+        if (hi - lo >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; return; }   // one rank alone is too big: use more ranks
         while (b < w->rank_hi) {
             uint64_t lo2, hi2;
             job_range(FS, P, a, b + 1, lo2, hi2);
@@ -206,45 +219,121 @@ static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
         jobs.emplace_back(a, b);
         a = b;
     }
-    void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr;
+    const double t_alloc0 = now_s();
+    const int nbuf = jobs.size() > 1 ? 2 : 1;
+    void *d_in[2] = {nullptr, nullptr}, *h_in[2] = {nullptr, nullptr}, *d_out = nullptr;
+    hipStream_t copy_stream = nullptr;
     const uint64_t out_cap = max_len + (max_len >> 2) + (64u << 20);
-    if (!w->rc && (hipMalloc(&d_in, max_len + 64) != hipSuccess || hipMalloc(&d_out, out_cap) != hipSuccess ||
-                   hipHostMalloc(&h_in, max_len + 64, hipHostMallocDefault) != hipSuccess)) w->rc = NGSC_ERR_HIP;
+    for (int i = 0; i < nbuf && !w->rc; ++i)
+        if (hipMalloc(&d_in[i], max_len + 64) != hipSuccess || hipHostMalloc(&h_in[i], max_len + 64, hipHostMallocDefault) != hipSuccess)
+            w->rc = NGSC_ERR_HIP;
+    if (!w->rc && (hipMalloc(&d_out, out_cap) != hipSuccess || hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess))
+        w->rc = NGSC_ERR_HIP;
+
+    const bool verbose = getenv("NGSC_VERBOSE") != nullptr;
+    double t_comp = 0, t_d2h = 0, t_wait = 0;
+    const double t_alloc = now_s() - t_alloc0;
+    JobPipe pipe;
+    std::thread reader;
+    if (!w->rc) {
+        reader = std::thread([&]() {
+            int rc = NGSC_OK;
+            int fd = -1;
+            if (hipSetDevice(dev) != hipSuccess) rc = NGSC_ERR_HIP;
+            else if ((fd = ::open(in_path, O_RDONLY)) < 0) rc = NGSC_ERR_IO;
+            for (size_t j = 0; j < jobs.size() && !rc; ++j) {
+                {   // buffer j % nbuf is free once job j - nbuf has been compressed
+                    std::unique_lock<std::mutex> lk(pipe.m);
+                    pipe.cv.wait(lk, [&] { return pipe.abort || pipe.consumed + nbuf > (int)j; });
+                    if (pipe.abort) break;
+                }
+                uint64_t lo, hi;
+                job_range(FS, P, jobs[j].first, jobs[j].second, lo, hi);
+                const uint64_t len = hi - lo;
+                uint8_t *hb = (uint8_t *)h_in[j % nbuf];
+                const double t0 = now_s();
+                uint64_t got = 0;
+                while (got < len) {
+                    const ssize_t r = ::pread(fd, hb + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(lo + got));
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                w->io_s += now_s() - t0;
+                if (got != len) { rc = NGSC_ERR_IO; break; }
+                if (hipMemcpyAsync(d_in[j % nbuf], hb, len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                    hipStreamSynchronize(copy_stream) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+                {
+                    std::lock_guard<std::mutex> lk(pipe.m);
+                    pipe.uploaded = (int)j + 1;
+                }
+                pipe.cv.notify_all();
+            }
+            if (fd >= 0) ::close(fd);
+            {
+                std::lock_guard<std::mutex> lk(pipe.m);
+                pipe.reader_rc = rc;
+                if (rc) pipe.abort = true;
+            }
+            pipe.cv.notify_all();
+        });
+    }
     for (size_t j = 0; j < jobs.size() && !w->rc; ++j) {
+        double t0 = now_s();
+        {
+            std::unique_lock<std::mutex> lk(pipe.m);
+            pipe.cv.wait(lk, [&] { return pipe.abort || pipe.uploaded > (int)j; });
+            if (pipe.abort) { w->rc = pipe.reader_rc ? pipe.reader_rc : NGSC_ERR_IO; break; }
+        }
+        t_wait += now_s() - t0;
+        t0 = now_s();
         uint64_t lo, hi;
         job_range(FS, P, jobs[j].first, jobs[j].second, lo, hi);
-        const uint64_t len = hi - lo;
-        const double t0 = now_s();
-        uint64_t got = 0;
-        while (got < len) {
-            const ssize_t r = ::pread(fd, (uint8_t *)h_in + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(lo + got));
-            if (r <= 0) break;
-            got += (uint64_t)r;
-        }
-        w->io_s += now_s() - t0;
-        if (got != len) { w->rc = NGSC_ERR_IO; break; }
-        if (hipMemcpy(d_in, h_in, len, hipMemcpyHostToDevice) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
-        w->rc = ngsc_compress_device(w->ctx, d_in, len, lo, FS, P, jobs[j].first, jobs[j].second, d_out, out_cap, nullptr);
+        w->rc = ngsc_compress_device(w->ctx, d_in[j % nbuf], hi - lo, lo, FS, P, jobs[j].first, jobs[j].second, d_out, out_cap, nullptr);
         if (w->rc) break;
-        const uint64_t total = ngsc_result_bytes(w->ctx), base = w->host.size();
-        w->host.resize(base + total);
-        if (total && hipMemcpy(w->host.data() + base, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
+        t_comp += now_s() - t0;
+        t0 = now_s();
+        const uint64_t total = ngsc_result_bytes(w->ctx);
+        void *chunk = nullptr;   // pinned: a pageable destination makes the copy run at ~2 GB/s
+        if (hipHostMalloc(&chunk, total + 64, hipHostMallocDefault) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
+        w->chunks.push_back((uint8_t *)chunk);
+        if (total && hipMemcpy(chunk, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
+        t_d2h += now_s() - t0;
         const ngsc_subblock_t *sbs = ngsc_result_subblocks(w->ctx);
         const ngsc_rank_t *rks = ngsc_result_ranks(w->ctx);
         const uint32_t nr = ngsc_result_num_ranks(w->ctx), ns = ngsc_result_num_subblocks(w->ctx);
         const uint32_t sb_base = (uint32_t)w->sb_sizes.size();
         for (uint32_t k = 0; k < nr; ++k) {
             ngsc_rank_t rk = rks[k];
-            rk.stream_off += base;
+            w->rank_ptr.push_back((const uint8_t *)chunk + rk.stream_off);
             rk.first_subblock += sb_base;
             w->ranks.push_back(rk);
         }
         for (uint32_t k = 0; k < ns; ++k) w->sb_sizes.push_back(sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len);
+        {
+            std::lock_guard<std::mutex> lk(pipe.m);
+            pipe.consumed = (int)j + 1;
+        }
+        pipe.cv.notify_all();
     }
-    if (d_in) (void)hipFree(d_in);
+    if (reader.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(pipe.m);
+            if (w->rc) pipe.abort = true;
+        }
+        pipe.cv.notify_all();
+        reader.join();
+        if (!w->rc && pipe.reader_rc) w->rc = pipe.reader_rc;
+    }
+    const double t_free = now_s();
+    for (int i = 0; i < 2; ++i) {
+        if (d_in[i]) (void)hipFree(d_in[i]);
+        if (h_in[i]) (void)hipHostFree(h_in[i]);
+    }
     if (d_out) (void)hipFree(d_out);
-    if (h_in) (void)hipHostFree(h_in);
-    ::close(fd);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (verbose)
+        fprintf(stderr, "[ngsc] device %d: %zu jobs, buffers %.3f s (alloc, before the first job), wait-for-input %.3f s, compress %.3f s, "
+                        "D2H %.3f s, file read %.3f s (overlapped), free %.3f s\n", dev, jobs.size(), t_alloc, t_wait, t_comp, t_d2h, w->io_s, now_s() - t_free);
 }
 
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
@@ -270,8 +359,14 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
         for (auto &t : th) t.join();
     }
     double t2 = now_s();
+    auto free_chunks = [&]() {
+        for (auto &w : workers) {
+            for (uint8_t *c : w.chunks) (void)hipHostFree(c);
+            w.chunks.clear();
+        }
+    };
     for (auto &w : workers)
-        if (w.rc) return w.rc;
+        if (w.rc) { const int rc = w.rc; free_chunks(); return rc; }
 
     // container: blocks of every rank, deterministic order, footer (phyNGSC.cpp:842-1057)
     std::vector<std::vector<ngsc_block_t>> rb(P);
@@ -280,23 +375,24 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     std::vector<const uint8_t *> stream(P);
     uint32_t n_sub_total = 0, max_blocks = 0, n_blocks_total = 0;
     for (auto &w : workers) {
-        for (const ngsc_rank_t &rk : w.ranks) {
+        for (size_t ri = 0; ri < w.ranks.size(); ++ri) {
+            const ngsc_rank_t &rk = w.ranks[ri];
             const uint32_t r = rk.rank;
             uint32_t capb = (uint32_t)(rk.stream_bytes / (NGSC_BLOCK_SIZE - 4096)) + 4, nb = 0;
             rb[r].resize(capb);
             int rc = ngsc_plan_blocks(P, r, w.sb_sizes.data() + rk.first_subblock, rk.n_subblocks, rb[r].data(), capb, &nb);
-            if (rc) return rc;
+            if (rc) { free_chunks(); return rc; }
             rb[r].resize(nb);
             ov[r] = rk.overlap_used;
             lbs[r] = nb ? rb[r][nb - 1].size : 0;
-            stream[r] = w.host.data() + rk.stream_off;
+            stream[r] = w.rank_ptr[ri];
             n_sub_total += rk.n_subblocks;
             n_blocks_total += nb;
             max_blocks = std::max(max_blocks, nb);
         }
     }
     int ofd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (ofd < 0) return NGSC_ERR_IO;
+    if (ofd < 0) { free_chunks(); return NGSC_ERR_IO; }
     std::vector<uint32_t> cbo;
     bool okw = true;
     for (uint32_t k = 0; k < max_blocks && okw; ++k)
@@ -311,6 +407,7 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     okw = okw && write_all(ofd, footer.data(), fl);
     ::close(ofd);
     double t3 = now_s();
+    free_chunks();
     double io = 0;
     for (auto &w : workers) io = std::max(io, w.io_s);
     if (seconds_out) { seconds_out[0] = (t1 - t0) + io; seconds_out[1] = (t2 - t1) - io; seconds_out[2] = t3 - t2; }

@@ -16,7 +16,7 @@ inp, outp = "/tmp/big_in.fastq", "/tmp/big_out.ngsc"
 data.tofile(inp)
 print(f"generated {data.size/1e9:.2f} GB in {time.time()-t0:.1f} s", flush=True)
 t0 = time.time()
-r = subprocess.run([os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc"), inp, outp, "--ranks", str(P)], capture_output=True, text=True)
+r = subprocess.run([os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc"), inp, outp, "--ranks", str(P)], capture_output=True, text=True, env=dict(os.environ, NGSC_VERBOSE="1"))
 print(r.stdout.strip(), r.stderr.strip(), f"[ngsc wall {time.time()-t0:.1f} s, rc {r.returncode}]", flush=True)
 t0 = time.time()
 want, st = orc.compress_file(data, P, threads=min(P, os.cpu_count() or 1))
