@@ -201,4 +201,7 @@ def decompress(ngsc) -> bytes:
             if used != len(sb):
                 raise OracleError(-1)
             parts.append(text)
-    return b"".join(parts)
+    text = b"".join(parts)
+    # the footer records the FASTQ size: a file whose last line had no newline decodes with one too many
+    fs = ngsc_format.read_footer(bytes(ngsc)).FS
+    return text[:fs] if len(text) == fs + 1 and text.endswith(b"\n") else text

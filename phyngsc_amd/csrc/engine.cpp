@@ -326,7 +326,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         KScope k(c, st, "k_sync_first");
         launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err);
     }
-    { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask); }
+    { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask, buf_off + buf_len == file_size); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
     { KScope k(c, st, "k_nl_write"); launch_nl_write(st, d_nlmask, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_bound); }
     {

@@ -69,8 +69,10 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     return v;
 }
 
+// at_file_end: the job buffer ends where the file ends; if the file's last line has no newline, one is assumed just
+// past the last byte (the reference finds that record too: it works from positions, phyNGSC.cpp:308-312).
 __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
-                                                           uint32_t *tile_cnt, uint32_t *nl_mask)
+                                                           uint32_t *tile_cnt, uint32_t *nl_mask, uint32_t at_file_end)
 {
     __shared__ uint32_t s_part[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
@@ -84,6 +86,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
         uint32_t m = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
+        if (at_file_end && base <= len && len - base < BYTES_PER_THREAD && len > start && buf[len - 1] != '\n') {
+            m |= 1u << (len - base);   // the assumed newline at position len
+            ++c;
+        }
         nl_mask[base / BYTES_PER_THREAD] = m;
     }
     c = wave_reduce_add(c);
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
-uint32_t index_num_tiles(uint32_t len) { return (len + TILE_BYTES - 1) / TILE_BYTES; }
+uint32_t index_num_tiles(uint32_t len) { return len / TILE_BYTES + 1; }   // covers position len itself (assumed final newline)
 
 void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
                        uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err)
@@ -308,10 +314,11 @@ void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_
                        start_rel, err);
 }
 
-void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask)
+void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask,
+                     bool at_file_end)
 {
     uint32_t nt = index_num_tiles(len);
-    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt, nl_mask);
+    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt, nl_mask, at_file_end ? 1u : 0u);
 }
 
 size_t index_mask_words(uint32_t len) { return (size_t)index_num_tiles(len) * (TILE_BYTES / BYTES_PER_THREAD); }

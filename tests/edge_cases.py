@@ -55,4 +55,8 @@ def build():
     recs = [(b"lc.%d" % i, bytes(rnd.choice(b"ACGTacgtn") for _ in range(36)), bytes(rnd.choice(b"!#5I") for _ in range(36)))
             for i in range(5000)]
     cases["lowercase"] = (_fq(recs), 2)
+    # the file's last line without a newline (the reference works from positions and still finds the record)
+    recs = [(b"nn.%d" % i, bytes(rnd.choice(b"ACGT") for _ in range(36)), bytes(rnd.choice(b"5?IJ") for _ in range(36)))
+            for i in range(3000)]
+    cases["no_final_newline"] = (_fq(recs)[:-1], 3)
     return cases
