@@ -181,6 +181,13 @@ def small_cases():
     add("qual_1sym", case_alphabets(rng, 300, 40, "ACGT", 73, 73), [2])
     add("qual_2sym", case_alphabets(rng, 300, 40, "ACGT", 72, 73), [2])
     add("qual_wide", case_alphabets(rng, 1200, 60, "ACGT", 33, 126), [2])
+    # later additions draw from their own generator so that the cases above stay byte-identical
+    rng2 = random.Random(20261004)
+    add("no_final_newline", case_err_style(rng2, 1500)[:-1], [2, 3])
+    add("empty_reads", "".join(rec(f"@e.{i + 1}", rand_seq(rng2, L), rand_qual(rng2, L))
+                               for i in range(2500) for L in [0 if i % 53 == 7 else 1 + (i * 31) % 50]), [2, 3])
+    add("iupac_odd_quals", "".join(rec(f"@q.{i + 1}", rand_seq(rng2, 36, "ACGTACGTACGTRYKMSWN" if i % 3 == 0 else "ACGT"),
+                                       "".join(rng2.choice("IJKabcxyz~") for _ in range(36))) for i in range(2000)), [2])
     return cases
 
 
