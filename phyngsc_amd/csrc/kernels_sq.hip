@@ -21,8 +21,8 @@
 namespace ngsc {
 
 constexpr int SR_THREADS = 256;
-constexpr uint32_t SR_HSTRIDE = 65;   // dwords per LDS histogram row: quality bytes 33..96, one pad column
-constexpr uint32_t SR_HCOLS = 64;
+constexpr uint32_t SR_HCOLS = 48;     // LDS columns: quality bytes 33..80 ('!'..'P'); anything else takes the global tables
+constexpr uint32_t SR_HSTRIDE = SR_HCOLS + 1;   // dwords per LDS histogram row (odd: rows land in different banks)
 
 __device__ __forceinline__ uint32_t sr_wsum(uint32_t v)
 {
@@ -43,11 +43,11 @@ __device__ __forceinline__ uint32_t sr_not_acgt(uint32_t w, uint32_t idx)   // n
 {
     return __builtin_amdgcn_perm(0u, 0x47544341u, idx) ^ w;
 }
-// 0x80 per byte where the quality byte is outside 33..96 (the columns of the LDS histogram)
+// 0x80 per byte where the quality byte is outside 33 .. 32 + SR_HCOLS (the columns of the LDS tables)
 __device__ __forceinline__ uint32_t sr_q_out(uint32_t w)
 {
     const uint32_t t1 = (w | 0x80808080u) - 0x21212121u;   // bit 7 <=> (b & 0x7f) >= 33
-    const uint32_t t2 = (w & 0x7F7F7F7Fu) + 0x1F1F1F1Fu;   // bit 7 <=> (b & 0x7f) >= 97
+    const uint32_t t2 = (w & 0x7F7F7F7Fu) + (0x7Fu - (32u + SR_HCOLS)) * 0x01010101u;   // bit 7 <=> (b & 0x7f) > 32 + SR_HCOLS
     return (~t1 | t2 | w) & 0x80808080u;
 }
 __device__ __forceinline__ uint32_t sr_byte(const uint32_t (&w)[4], uint32_t u) { return (w[u >> 2] >> (8 * (u & 3))) & 0xffu; }
@@ -859,7 +859,7 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
-    hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS, st, A, rows, tpw);
+    hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS + 64, st, A, rows, tpw);
 }
 
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
