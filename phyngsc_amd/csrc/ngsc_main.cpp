@@ -1,4 +1,4 @@
-// ngsc - command line front end: `ngsc <in.fastq> <out.ngsc> [threads] [--ranks P] [--device D | --devices a,b,..]`.
+// ngsc - command line front end: `ngsc <in.fastq> <out.ngsc> [threads] [--ranks P] [--gpus N | --devices a,b,..]`.
 //
 // Keeps the reference's positional interface (phyNGSC.cpp:61-108: <input> <output> <threads>, exit codes
 // 1 usage, 2 open failure, 3 allocation failure).  `mpiexec -np P` becomes `--ranks P` (virtual ranks,
@@ -21,6 +21,10 @@ int main(int argc, char **argv)
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) P = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) {   // the first N devices
+            devices.clear();
+            for (int d = 0, n = atoi(argv[++i]); d < n; ++d) devices.push_back(d);
+        }
         else if ((!strcmp(argv[i], "--device") || !strcmp(argv[i], "--devices")) && i + 1 < argc) {
             devices.clear();
             for (const char *p = argv[++i]; *p;) {
@@ -36,7 +40,7 @@ int main(int argc, char **argv)
     }
     if (npos < 2 || npos > 3) {
         fprintf(stderr, "\n[E] ERROR: Incorrect number of arguments. Usage:\n");
-        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--devices D[,D..]]\n");
+        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--gpus N | --devices D[,D..]]\n");
         return 1;
     }
     if (P < 2) {
