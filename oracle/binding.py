@@ -101,7 +101,10 @@ def compress_file(data, P: int, threads: int = 1):
                                     ctypes.byref(st))
     if rc:
         raise OracleError(rc)
-    res = ctypes.string_at(out.value, n.value)
+    if n.value < (1 << 31):
+        res = ctypes.string_at(out.value, n.value)
+    else:   # (string_at takes a C int) multi-GB outputs come back as a numpy array
+        res = np.ctypeslib.as_array((ctypes.c_ubyte * n.value).from_address(out.value)).copy()
     _libc.free(out)
     return res, st
 
