@@ -377,12 +377,15 @@ static int title_stream(const titles_t *t, bw_t *w)
                 uint32_t s, e;
                 field_span(t, r, f, &s, &e);
                 uint64_t v = 0;
+                int big = 0;
                 for (uint32_t p = s; p < e; ++p) {
-                    v = v * 10 + (uint64_t)(buf[p] - '0');
-                    if (v > 0x7fffffffull) { rc = NGSC_O_ERANGE; break; }
+                    v = (v * 10 + (uint64_t)(buf[p] - '0')) & 0xffffffffull; /* uint32 arithmetic, utils.h:117-125 */
+                    if (v > 0x7fffffffull) big = 1;
                 }
-                if (rc) break;
-                val[r] = (int32_t)v;
+                /* a constant field is stored once as text and its (wrapped) value is never used; a varying
+                   one with a value the int32 cannot hold sends the reference into negative ranges */
+                if (big && !fd->is_const) { rc = NGSC_O_ERANGE; break; }
+                val[r] = (int32_t)(uint32_t)v;
             }
             if (rc) break;
             fd->min_v = fd->max_v = val[0];
@@ -672,6 +675,7 @@ int ngsc_o_subblock(const uint8_t *win, uint64_t avail, uint64_t wsize, uint64_t
     uint32_t max_q = 0, max_s = 0;
     for (uint32_t r = 0; r < n; ++r) {
         uint32_t s = te[r] + 1, e = se[r], L = e - s, q0 = se[r] + 3;
+        if ((uint64_t)q0 + L > avail) { rc = NGSC_O_EFORMAT; goto out; } /* quality line cut off by the end of the data */
         /* transfer test :549-571: every non-ACGT IUPAC base must have quality '!'..'(' */
         int any = 0, ok = 1;
         for (uint32_t j = 0; j < L; ++j) {
@@ -944,7 +948,11 @@ static void compress_rank(const uint8_t *fastq, uint64_t FS, uint32_t P, uint32_
 
     while (bytes_read < region) { /* :168 */
         uint64_t avail = (uint64_t)win_pos < FS ? FS - (uint64_t)win_pos : 0;
-        uint64_t cap = (uint64_t)bsize + 4096; /* bytes a longer buffer would expose past the window */
+        /* The reference reads records that end past its window out of whatever lies behind the buffer
+           (phyNGSC.cpp:308, :615: undefined once a record is longer than the overlap).  The oracle defines
+           that case: the bytes are the file's own.  1 MiB of them is kept; a record that still does not fit
+           is rejected in ngsc_o_subblock. */
+        uint64_t cap = (uint64_t)bsize + (1u << 20);
         if (avail > cap) avail = cap;
         uint8_t *sb = NULL;
         uint64_t sblen = 0;

@@ -46,6 +46,8 @@ struct ngsc_ctx {
     std::string hip_err;
     bool profiling = false;
     std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
+    uint32_t min_text_slots = 0;  // text-field table slots the last call turned out to need (kept for the next call)
+    bool slot_retry = false;
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
 
@@ -375,7 +377,9 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);
 
     // ---- per-sub-block arena ----
-    const uint32_t n_slots = std::max<uint32_t>(64, 2 * S);
+    // Table slots for the non-constant text fields of all sub-blocks.  FASTQ titles have one or two such fields; a
+    // call that needs more finds out from the slot counter and runs again with what it asked for.
+    const uint32_t n_slots = std::min<uint32_t>(S * MAX_FIELDS, std::max<uint32_t>({64u, 2 * S, c->min_text_slots}));
     Carver cz;  // zero-initialised every call
     size_t z_fstat = cz.take(sizeof(FieldStat) * (size_t)S * MAX_FIELDS);
     size_t z_occ = cz.take(4 * (size_t)S * 256);
@@ -552,6 +556,21 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);
     const uint64_t total = *(uint64_t *)(hp + sb_bytes + o_outtot);
     c->res_bytes = total;
+    if (err3 == NGSC_ERR_UNSUPPORTED && !c->slot_retry) {
+        const uint32_t asked = *(uint32_t *)(hp + sb_bytes + o_slotc);
+        if (asked > n_slots) {
+            // (kernels that start after the error flag is up return early, so the count can fall short: grow at least 2x)
+            c->slot_retry = true;
+            int r = NGSC_ERR_UNSUPPORTED;
+            for (uint32_t want = std::max(asked, 2 * n_slots);; want *= 2) {
+                c->min_text_slots = want;
+                r = ngsc_compress_device(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream);
+                if (r != NGSC_ERR_UNSUPPORTED || want >= S * MAX_FIELDS) break;
+            }
+            c->slot_retry = false;
+            return r;
+        }
+    }
     if (err3) return err3;
     c->res_sb.resize(S);
     for (uint32_t s = 0; s < S; ++s) {

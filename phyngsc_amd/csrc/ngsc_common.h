@@ -34,7 +34,7 @@ constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
 constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
 constexpr uint32_t REC0_TITLE_CAP = 512;      // longest first-record title the title kernels keep in LDS
-constexpr uint32_t NUM_CAND_CAP = 8;        // numeric candidate fields whose deltas the tiled statistics track
+constexpr uint32_t NUM_CAND_CAP = MAX_FIELDS;  // numeric candidate fields (numeric in a sub-block's first record) whose values and deltas are tracked: all of them
 
 constexpr uint32_t BLOB_SLOT_256 = 336;     // >= 9 + ceil((256*9 + 255)/8) = 329
 constexpr uint32_t BLOB_SLOT_512 = 720;     // >= 9 + ceil((512*10 + 511)/8) = 713
