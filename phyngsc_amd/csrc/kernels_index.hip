@@ -69,8 +69,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
     return v;
 }
 
-// at_file_end: the job buffer ends where the file ends; if the file's last line has no newline, one is assumed just
-// past the last byte (the reference finds that record too: it works from positions, phyNGSC.cpp:308-312).
+// at_file_end: the job buffer ends where the file ends.  A newline is assumed just past the last byte: it closes a
+// last quality line that has none (also an empty one, after "+\n"), as the reference does by working from positions
+// (phyNGSC.cpp:308-312); behind a complete file it opens a fifth line that no record owns and nothing reads.
 __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
                                                            uint32_t *tile_cnt, uint32_t *nl_mask, uint32_t at_file_end)
 {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
         uint32_t m = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
-        if (at_file_end && base <= len && len - base < BYTES_PER_THREAD && len > start && buf[len - 1] != '\n') {
+        if (at_file_end && base <= len && len - base < BYTES_PER_THREAD && len > start) {
             m |= 1u << (len - base);   // the assumed newline at position len
             ++c;
         }

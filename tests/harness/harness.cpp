@@ -214,8 +214,8 @@ int64_t h_plan_file(const uint8_t *buf, uint64_t file_size, uint32_t P, uint32_t
     std::vector<uint32_t> te, se, ls;
     ls.push_back(0);
     uint32_t line = 0;
-    // a last line without newline counts as if it had one (kernels_index.hip: k_nl_count, at_file_end)
-    const uint64_t scan_end = file_size + ((file_size && buf[file_size - 1] != '\n') ? 1 : 0);
+    // a newline is assumed just past the file's last byte (kernels_index.hip: k_nl_count, at_file_end)
+    const uint64_t scan_end = file_size + (file_size ? 1 : 0);
     for (uint64_t i = 0; i < scan_end; ++i) {
         if (i < file_size && buf[i] != '\n') continue;
         uint32_t k = line & 3;

@@ -38,11 +38,12 @@ def draw_dialect(rnd: random.Random, max_mb: float):
         if kind == "const":
             f["tok"] = bytes(rnd.choice(TEXT) for _ in range(rnd.randint(0, 12)))
         elif kind == "inc":
-            f["start"] = rnd.choice([0, 1, 9, 99, 12345, 2 ** 31 - 200000, rnd.randint(0, 10 ** 9)])
+            f["start"] = rnd.choice([0, 1, 9, 99, 12345, 99999, 10 ** 6 - 50, rnd.randint(0, 10 ** 9), rnd.randint(0, 10 ** 9),
+                                 2 ** 31 - 200000])
             f["step"] = rnd.choice([1, 1, 1, 2, 7, 1000])
             f["every"] = rnd.choice([1, 1, 2, 33, 1000])
         elif kind == "rand":
-            f["hi"] = rnd.choice([1, 2, 9, 10, 255, 256, 65535, 65536, 10 ** 6, 2 ** 31 - 1])
+            f["hi"] = rnd.choice([1, 2, 9, 10, 255, 256, 65535, 65536, 10 ** 6, 10 ** 6, 2 ** 29, 2 ** 29, 2 ** 29, 2 ** 31 - 1])
             f["lo"] = rnd.choice([0, 0, f["hi"] // 2])
         elif kind in ("text", "vtext"):
             f["alpha"] = bytes(rnd.sample(list(TEXT), rnd.randint(1, 20)))
@@ -85,6 +86,8 @@ def draw_dialect(rnd: random.Random, max_mb: float):
     d["n_qual"] = rnd.choice(["low", "low", "any", "two"])
     d["p_all_n"] = rnd.choice([0, 0, 0.01])
     d["final_newline"] = rnd.random() > 0.15
+    # how the file ends: complete, or with the damage real files show (both sides must agree on accept / reject)
+    d["tail"] = rnd.choice(["ok"] * 12 + ["blank", "blank2", "cut_quality", "cut_sequence", "cut_title", "cut_plus", "junk"])
     d["P"] = rnd.choice([2, 2, 3, 4, 5, 7, 8, 8, 13, 16])
     mb = rnd.choice([0.02, 0.1, 0.5, 1.0, 3.0, 9.0, 17.0, max_mb])
     d["bytes"] = int(min(mb, max_mb) * (1 << 20))
@@ -164,8 +167,22 @@ def build_file(d, seed):
         size += len(rec)
         i += 1
     data = b"".join(out)
-    if not d["final_newline"]:
-        data = data[:-1]
+    tail = d.get("tail", "ok")
+    last = out[-1]
+    if tail == "ok":
+        if not d["final_newline"]:
+            data = data[:-1]
+    elif tail == "blank":
+        data += b"\n"
+    elif tail == "blank2":
+        data += b"\n\n"
+    elif tail == "junk":
+        data += b"xyz\n"
+    else:
+        nl = [k for k, c in enumerate(last) if c == 10]          # title, sequence, plus, quality newlines
+        keep = {"cut_title": max(1, nl[0] // 2), "cut_sequence": (nl[0] + nl[1] + 1) // 2,
+                "cut_plus": nl[1] + 2, "cut_quality": (nl[2] + nl[3] + 1) // 2}[tail]
+        data = data[: len(data) - len(last) + keep]
     return data
 
 
@@ -197,7 +214,7 @@ def main():
         eng = api.Engine(0)
     t_end = time.time() + a.seconds
     seed = a.first_seed
-    n_ok = n_rej = n_bad = n_skip = 0
+    n_ok = n_rej = n_bad = n_skip = n_crash = 0
     total = 0
     last = time.time()
     while time.time() < t_end and seed < a.first_seed + a.seeds:
@@ -212,7 +229,7 @@ def main():
         except orc.OracleError as e:
             ref, o_rc = None, e.rc
         verdict = "ok"
-        if a.reference and (o_rc or max_rec > 480 or d["P"] > 8):
+        if a.reference and (o_rc or max_rec > 480 or d["P"] > 8 or d["tail"] != "ok"):
             n_skip += 1          # outside the reference's defined behaviour or too slow here
             seed += 1
             continue
@@ -225,6 +242,12 @@ def main():
             r = subprocess.run([mpiexec, "-np", str(d["P"]), ref_bin, fq, outp, "1"], capture_output=True, text=True,
                                timeout=300)
             r_ok = r.returncode == 0 and os.path.exists(outp) and "WARNING" not in r.stdout
+            if not r_ok and r.returncode in (11, 139, -11):
+                # the reference segfaults on inputs the oracle takes: known cases are MakeFooter's log2(0) when every
+                # rank region starts on a record; counted, not compared
+                n_crash += 1
+                seed += 1
+                continue
             if r_ok != (o_rc == 0):
                 verdict = f"reference ok={r_ok} (rc {r.returncode}: {r.stdout[-200:]!r}), oracle rc {o_rc}"
             elif r_ok:
@@ -239,8 +262,11 @@ def main():
                 except orc.OracleError as e:
                     back = None
                     verdict = f"oracle decoder rc {e.rc}"
-                if back is not None and back != data:
+                whole = data if d["tail"] != "ok" or d["final_newline"] else data + b"\n"
+                if back is not None and d["tail"] == "ok" and back != data:
                     verdict = "oracle round trip differs"
+                elif back is not None and not whole.startswith(back[:-1]):    # damaged tail: the records before it
+                    verdict = "oracle round trip is not a prefix of the input"
         else:
             arr = np.frombuffer(data, dtype=np.uint8)
             d_in = torch.from_numpy(arr.copy()).cuda()
@@ -269,7 +295,7 @@ def main():
                   flush=True)
         seed += 1
     print(f"fuzz: seeds {a.first_seed}..{seed - 1}: {n_ok} equal, {n_rej} rejected by both, {n_bad} mismatches, "
-          f"{n_skip} skipped, {total / 1e6:.0f} MB of FASTQ", flush=True)
+          f"{n_skip} skipped, {n_crash} reference crashes, {total / 1e6:.0f} MB of FASTQ", flush=True)
     if eng is not None:
         eng.close()
     sys.exit(1 if n_bad else 0)
