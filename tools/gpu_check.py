@@ -71,6 +71,16 @@ def compare_case(eng, name, data: bytes, P: int, golden: bytes | None, verbose=T
                 lo = max(0, first - 8)
                 print(f"       mine  : {mine[lo:first + 24].hex()}")
                 print(f"       theirs: {theirs[lo:first + 24].hex()}")
+                try:   # what the two streams decode to
+                    ta, tb = orc.decode_subblock(mine)[0], orc.decode_subblock(theirs)[0]
+                    m2 = min(len(ta), len(tb))
+                    fd = next((i for i in range(m2) if ta[i] != tb[i]), m2)
+                    a0 = ta.rfind(b"\n@", 0, fd) + 1
+                    print(f"       decoded texts differ at byte {fd} of {len(ta)} / {len(tb)}; record {ta[:fd].count(bytes([10])) // 4}")
+                    print(f"       mine  : {ta[a0:fd + 60]!r}")
+                    print(f"       theirs: {tb[a0:fd + 60]!r}")
+                except Exception as e:  # noqa: BLE001
+                    print(f"       (decode: {e})")
                 break
     except Exception as e:  # noqa: BLE001
         print(f"     (could not localise: {e})")
@@ -95,6 +105,15 @@ def main():
                                  ("cfg2", fastq_gen.CFG2, 100_000_000, 8)]:
             data = fastq_gen.generate(cfg, target_bytes=size).tobytes()
             bad += not compare_case(eng, f"{nm}_{size}", data, P, None)
+    for w in which:
+        if w.startswith("fuzz:"):      # replay a seed of tools/fuzz_parity.py
+            import random
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import fuzz_parity as fz
+            seed = int(w[5:])
+            d = fz.draw_dialect(random.Random(seed), 24)
+            print("dialect", d)
+            bad += not compare_case(eng, w, fz.build_file(d, seed), d["P"], None)
     print("FAILED" if bad else "ALL OK", bad)
     return 1 if bad else 0
 
