@@ -59,4 +59,29 @@ def build():
     recs = [(b"nn.%d" % i, bytes(rnd.choice(b"ACGT") for _ in range(36)), bytes(rnd.choice(b"5?IJ") for _ in range(36)))
             for i in range(3000)]
     cases["no_final_newline"] = (_fq(recs)[:-1], 3)
+    # ---- found by the randomised runs (tools/fuzz_parity.py) ----
+    # the file ends with "+\n" and an empty, unterminated quality line
+    recs = [(b"el.%d" % i, bytes(rnd.choice(b"ACGT") for _ in range(i % 5)), bytes(rnd.choice(b"5?IJ") for _ in range(i % 5)))
+            for i in range(3001)]
+    recs[-1] = (b"el.3000", b"", b"")
+    cases["empty_last_quality_no_newline"] = (_fq(recs)[:-1], 3)
+    # constant numeric fields beyond int32 / uint32 (stored once as text; the reference never uses the wrapped value)
+    recs = [(b"c%d 4294967295 x:%d 99999999999" % (i % 7, i), bytes(rnd.choice(b"ACGT") for _ in range(36)),
+             bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(5000)]
+    cases["const_numeric_beyond_int32"] = (_fq(recs), 2)
+    # twelve varying numeric fields (more than the eight the first engine versions tracked)
+    recs = [(b"M" + b":".join(b"%d" % ((i * (k + 3) + k * k) % (10 ** (1 + k % 6))) for k in range(12)),
+             bytes(rnd.choice(b"ACGT") for _ in range(36)), bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(6000)]
+    cases["twelve_numeric_fields"] = (_fq(recs), 2)
+    # eight varying text fields in each of ten sub-blocks: more text-field tables than the engine reserves up front
+    def word(k):
+        return bytes(rnd.choice(b"abcdefgh") for _ in range(1 + (k + rnd.randrange(3)) % 4))
+    recs = [(b"T" + b" ".join(word(k) for k in range(8)), bytes(rnd.choice(b"ACGT") for _ in range(50)),
+             bytes(rnd.choice(b"5?IJ") for _ in range(50))) for i in range(6000)]
+    cases["many_text_fields"] = (_fq(recs), 10)
+    # 3000-base reads: records of 6 KB, far longer than the reference's 500-byte overlap (the bytes behind a window
+    # are the file's own)
+    recs = [(b"long.%d" % i, bytes(rnd.choice(b"ACGTN") for _ in range(3000 + i % 11)),
+             bytes(rnd.choice(b"#5?IJ") for _ in range(3000 + i % 11))) for i in range(300)]
+    cases["reads_3000bp"] = (_fq(recs), 2)
     return cases

@@ -188,6 +188,17 @@ def small_cases():
                                for i in range(2500) for L in [0 if i % 53 == 7 else 1 + (i * 31) % 50]), [2, 3])
     add("iupac_odd_quals", "".join(rec(f"@q.{i + 1}", rand_seq(rng2, 36, "ACGTACGTACGTRYKMSWN" if i % 3 == 0 else "ACGT"),
                                        "".join(rng2.choice("IJKabcxyz~") for _ in range(36))) for i in range(2000)), [2])
+    # inputs the randomised runs (tools/fuzz_parity.py) found the first engine / oracle versions wrong or too strict on
+    rng3 = random.Random(20261005)
+    el = [rec(f"@el.{i + 1}", rand_seq(rng3, i % 5), rand_qual(rng3, i % 5)) for i in range(1500)] + [rec("@el.1501", "", "")]
+    add("empty_last_quality", "".join(el)[:-1], [2, 3])            # ends with "+\n" and an unterminated empty line
+    add("const_numeric_beyond_int32", "".join(rec(f"@c{i % 7} 4294967295 x:{i} 99999999999", rand_seq(rng3, 36), rand_qual(rng3, 36))
+                                              for i in range(1500)), [2])
+    add("twelve_numeric_fields", "".join(rec("@M" + ":".join(str((i * (k + 3) + k * k) % (10 ** (1 + k % 6))) for k in range(12)),
+                                             rand_seq(rng3, 36), rand_qual(rng3, 36)) for i in range(1500)), [2])
+    add("many_text_fields", "".join(rec("@T" + " ".join("".join(rng3.choice("abcdefgh") for _ in range(1 + (k + rng3.randrange(3)) % 4))
+                                                        for k in range(8)), rand_seq(rng3, 50), rand_qual(rng3, 50))
+                                    for i in range(1800)), [10])   # 10 sub-blocks x 8 varying text fields
     return cases
 
 

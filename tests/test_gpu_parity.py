@@ -381,3 +381,50 @@ def test_edge_cases(eng, name):
     want, _ = orc.compress_file(data, P)
     assert out == want
     assert orc.decompress(out) == data
+
+
+@pytest.mark.parametrize("seed", range(0, 64))
+def test_random_dialects(eng, seed):
+    """Random FASTQ dialects (tests/dialects.py; the longer runs are tools/fuzz_parity.py): the engine and the oracle
+    produce the same container or both refuse the input."""
+    import random
+    from tests.dialects import build_file, draw_dialect
+    d = draw_dialect(random.Random(seed), 3.0)
+    data = build_file(d, seed)
+    try:
+        want, _ = orc.compress_file(data, d["P"], threads=8)
+    except orc.OracleError:
+        want = None
+    try:
+        _, out = _gpu(eng, data, d["P"])
+    except api.NgscError as e:
+        if want is not None and e.code == -8:
+            # the documented limit: rank regions of about one record's size
+            assert len(data) // d["P"] < 4 * max(len(x) for x in data.split(b"\n@")), (seed, e)
+            return
+        assert want is None, (seed, e)
+        return
+    assert want is not None, f"seed {seed}: the oracle refuses what the engine took"
+    assert out == want, seed
+
+
+def test_shared_record_between_ranks_is_refused(eng):
+    """file_size / P of about one record's size: the last record of a rank is also the first of the next (a sub-block
+    always takes its second record, phyNGSC.cpp:295-300).  The engine's per-record arrays have one owner per record: it
+    refuses the job (NGSC_ERR_UNSUPPORTED) instead of racing."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i in range(40):
+        L = rnd.randint(36, 536)
+        recs.append(b"@%d\n%s\n+\n%s\n" % (10 ** 9 + rnd.randrange(10 ** 9), bytes(rnd.choice(b"ACGT") for _ in range(L)),
+                                            bytes(rnd.choice(b"(=") for _ in range(L))))
+    data = b"".join(recs)
+    for P in (16, 24):
+        try:
+            _, out = _gpu(eng, data, P)
+        except api.NgscError as e:
+            assert e.code == -8
+            continue
+        want, _ = orc.compress_file(data, P)    # no shared record with this P: then it has to be right
+        assert out == want
