@@ -631,10 +631,13 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     constexpr uint32_t OWNED = TT_THREADS - 1;
     if (blockIdx.x * OWNED >= n) return;
     const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
 
     __shared__ uint32_t s_stat[MAX_FIELDS * 24];
-    __shared__ uint32_t s_val[NUM_CAND_CAP][TT_THREADS];
-    __shared__ uint32_t s_nummask[TT_THREADS];
+    // value deltas between neighbouring records (tasks.cpp:149-166): inside a wave by shuffle, across the three wave
+    // boundaries of the workgroup through these (last lane's value / first lane's value, per numeric candidate)
+    __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
+    __shared__ uint32_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
     __shared__ uint32_t s_w[TS_ROWS][TT_THREADS];
     __shared__ Rec0Tab s_r0;
 
@@ -695,10 +698,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             isn = true;
             v = s_r0.val0[f];
             ovf = s_r0.ovf0[f] != 0;
-            if (kk < NUM_CAND_CAP) {
-                s_val[kk][tid] = v;
-                if (owned) A.tv[(size_t)kk * A.tw_stride + g] = v;
-            }
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g] = v;
             nummask |= 1u << f;
         } else if (kk != 0xff) {
             const uint64_t dm = pos < 64 ? digmask >> pos : 0, lm = t_lowbits(len);
@@ -715,11 +715,19 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                     }
                 }
             }
-            if (kk < NUM_CAND_CAP) {
-                s_val[kk][tid] = v;
-                if (owned) A.tv[(size_t)kk * A.tw_stride + g] = v;   // k_title_measure_reg<true> and k_title_hist read it back
-            }
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g] = v;   // k_title_measure_reg<true> and k_title_hist read it back
             nummask |= (uint32_t)isn << f;
+        }
+        if (kk < NUM_CAND_CAP) {   // (uniform) delta to the previous record, both numeric
+            const uint32_t pv = (uint32_t)__shfl_up((int)v, 1);
+            const bool pisn = __shfl_up((int)isn, 1) != 0;
+            if (lane == 63) s_last[kk][tid >> 6] = v;
+            if (lane == 0) s_first[kk][tid >> 6] = v;
+            if (owned && i >= 1 && lane >= 1 && isn && pisn) {
+                const uint32_t bd = bias((int32_t)(v - pv));
+                if (bd > s_stat[f * 24 + 8]) atomicMax(&s_stat[f * 24 + 8], bd);
+                if (~bd > s_stat[f * 24 + 9]) atomicMax(&s_stat[f * 24 + 9], ~bd);
+            }
         }
 
         // A field identical to record 0's cannot change any statistic beyond what record 0's own lane
@@ -746,16 +754,16 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         }
         pos += len + 1;
     }
-    s_nummask[tid] = nummask;
+    if (lane == 63) s_nm_last[tid >> 6] = nummask;
+    if (lane == 0) s_nm_first[tid >> 6] = (owned && i >= 1) ? nummask : 0u;
     __syncthreads();
-    if (owned && i >= 1) {
-        const uint32_t both = nummask & s_nummask[tid - 1];
-        const uint32_t ncand = s_r0.ncand;
-        for (uint32_t kk = 0; kk < ncand; ++kk) {
+    {
+        // the first lanes of waves 1..3 against the last lanes of waves 0..2
+        const uint32_t ncand = s_r0.ncand, kk = (uint32_t)tid >> 2, w = (uint32_t)tid & 3u;
+        if (w >= 1 && kk < ncand) {
             const uint32_t ff = s_r0.cand_f[kk];
-            if ((both >> ff) & 1) {
-                const int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
-                const uint32_t bd = bias(d);
+            if (((s_nm_first[w] & s_nm_last[w - 1]) >> ff) & 1) {
+                const uint32_t bd = bias((int32_t)(s_first[kk][w] - s_last[kk][w - 1]));
                 if (bd > s_stat[ff * 24 + 8]) atomicMax(&s_stat[ff * 24 + 8], bd);
                 if (~bd > s_stat[ff * 24 + 9]) atomicMax(&s_stat[ff * 24 + 9], ~bd);
             }
