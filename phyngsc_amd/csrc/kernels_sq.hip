@@ -22,6 +22,7 @@ namespace ngsc {
 
 constexpr int SR_THREADS = 256;
 constexpr uint32_t SR_HCOLS = 48;     // LDS columns: quality bytes 33..80 ('!'..'P'); anything else takes the global tables
+constexpr uint32_t NB = 4;           // 16-byte chunks a lane fetches back to back (eight are no faster on 150-base reads)
 constexpr uint32_t SR_HSTRIDE = SR_HCOLS + 1;   // dwords per LDS histogram row (odd: rows land in different banks)
 
 __device__ __forceinline__ uint32_t sr_wsum(uint32_t v)
@@ -65,6 +66,7 @@ __device__ __forceinline__ uint32_t sr_amb_mask(const uint32_t (&sw)[4], uint32_
     return m;
 }
 
+template <bool BURST>
 __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw)
 {
     if (*A.err) return;
@@ -123,150 +125,176 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         // ---- one pass over the 16-byte chunks: everything except the ambiguous positions ----
         uint32_t fl = 0, namb = 0;   // N-transfer test (phyNGSC.cpp:549-571): bit0 some ambiguity code, bit1 a failure
         uint32_t nall = 0, apos0 = 0, apos1 = 0;   // non-ACGT bytes of the record and the positions of the first four
-        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
-        if (L) {
+        // NBX chunks of a record per trip.  BURST: NB = 4 chunks (64 bytes) are fetched back to back and each is used as it
+        // arrives - lanes are a whole record apart, so a cache line serves one lane and has to stay in L1 until that lane
+        // has read all of it (with one chunk per trip the lines of 150-base records were fetched again and again).
+        // Otherwise one chunk per trip, the next one loaded while the current one is processed (better for short reads).
+        constexpr uint32_t NBX = BURST ? NB : 1u;
+        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
+        if (!BURST && L) {
             Sn = load16_unaligned(A.buf, s0, A.buf_len);
             Qn = load16_unaligned(A.buf, q0, A.buf_len);
         }
-        for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
-            const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            const uint4 S = Sn, Q = Qn;
-            Sn = Qn = make_uint4(0, 0, 0, 0);
-            if (L > 16 * ch + 16) {
-                Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
-                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
-            }
-            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
-            if (__any(nv != 0 && L <= 16 * ch + 16)) {   // some lane is at the end of its read: "\n+\n" follows
-                if (nv != 0 && L <= 16 * ch + 16) {
-                    uint32_t two;   // the two bytes after the read's newline
-                    if (nv <= 13) {
-                        const uint32_t o = nv + 1, wi = o >> 2;
-                        const uint32_t lo = wi == 0 ? sw[0] : (wi == 1 ? sw[1] : (wi == 2 ? sw[2] : sw[3]));
-                        const uint32_t hi = wi == 0 ? sw[1] : (wi == 1 ? sw[2] : sw[3]);
-                        two = __builtin_amdgcn_alignbit(hi, lo, (o & 3) * 8) & 0xffffu;
-                    } else {
-                        two = (load4_unaligned(A.buf, se) >> 8) & 0xffffu;
-                    }
-                    if (two != 0x0a2bu) atomicMin(A.err, (int32_t)ERR_FORMAT);
-                }
-            }
-            uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
-            const bool wany[4] = {true, (bool)__any(nv > 4), (bool)__any(nv > 8), (bool)__any(nv > 12)};   // words any lane still needs
+        for (uint32_t grp = 0; __any(16 * NBX * grp < L); ++grp) {
+            uint4 Sb[NBX], Qb[NBX];
+            if constexpr (BURST) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if (!wany[k]) continue;
-                const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);   // bytes past the read count as 'A': no bits below
-                idx[k] = sr_idx(w);
-                d[k] = sr_not_acgt(w, idx[k]);
-                dacc |= d[k];
-                qbad |= sr_q_out(qw[k]) & vm;
-                const uint32_t p0 = idx[k] & 0x01010101u, p1 = (idx[k] >> 1) & 0x01010101u;
-                c0 += __builtin_popcount(p0);
-                c1 += __builtin_popcount(p1);
-                c01 += __builtin_popcount(p0 & p1);
-            }
-            const bool rows_ok = 16 * ch + 17 <= lds_rows;
-            const bool odd = dacc != 0 || qbad != 0 || (nv != 0 && nv != 16);
-            const unsigned long long live = __ballot(nv != 0);
-            const uint32_t nv_first = live ? (uint32_t)__builtin_amdgcn_readlane((int)nv, __builtin_ctzll(live)) : 0u;
-            if (rows_ok && !__any(odd)) {
-                if (nv) {
-                    // tasks.cpp:268-283: position histogram rows 1..max_q.  All lanes are at the same 16 positions, so
-                    // each lane walks them in its own rotated order (word lj, byte lb): 16 different rows per
-                    // instruction instead of one, or the LDS atomics serialise on the popular quality values.
-                    const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        const uint32_t j = (k + lj) & 3;
-                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
-                        const uint32_t joff = rb + j * (4 * SR_HSTRIDE * 4);
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
-                            atomicAdd(reinterpret_cast<uint32_t *>(hb + joff + boff[b] + 4 * q), 1u);
-                        }
+                for (uint32_t k = 0; k < NBX; ++k) {
+                    const uint32_t off = 16 * NBX * grp + 16 * k;
+                    Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
+                    if (L > off) {
+                        Sb[k] = load16_unaligned(A.buf, s0 + off, A.buf_len);
+                        Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
                     }
-                    t0 += c0; t1 += c1; t01 += c01; nok += 16;
-                }
-            } else if (16 * ch + nv_first + 1 <= lds_rows && !__any(dacc != 0 || qbad != 0) && !__any(nv != 0 && nv != nv_first)) {
-                // the read tails of equally long reads: the same nv < 16 bytes in every lane, nothing odd about them
-                if (nv) {
-                    const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
-                    for (uint32_t u = 0; u < nv_first; ++u) {
-                        const uint32_t w = u < 4 ? qw[0] : (u < 8 ? qw[1] : (u < 12 ? qw[2] : qw[3]));
-                        const uint32_t q = (w >> (8 * (u & 3))) & 0xffu;
-                        atomicAdd(reinterpret_cast<uint32_t *>(hb + rb + u * SR_HSTRIDE * 4 + 4 * q), 1u);
-                    }
-                    t0 += c0; t1 += c1; t01 += c01; nok += nv;
                 }
             } else {
-                uint32_t ambm = 0, qbm = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!wany[k]) continue;
-                    ambm |= t_movemask(t_nonzero01(d[k])) << (4 * k);
-                    qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
+                Sb[0] = Sn; Qb[0] = Qn;
+                Sn = Qn = make_uint4(0, 0, 0, 0);
+                if (L > 16 * grp + 16) {
+                    Sn = load16_unaligned(A.buf, s0 + 16 * grp + 16, A.buf_len);
+                    Qn = load16_unaligned(A.buf, q0 + 16 * grp + 16, A.buf_len);
                 }
-                const uint32_t validm = (1u << nv) - 1u;
-                const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // rows 16ch+1.. inside LDS
-                const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
-                ambm &= validm;
-                const uint32_t okm = validm & ~ambm & ~qbm & rowm;    // added to the LDS histogram now
-                const uint32_t glm = validm & ~ambm & ~okm;           // unambiguous but outside the LDS histogram
-                if (ambm) {   // recount the bases without the ambiguous ones
-                    c0 = c1 = c01 = 0;
+            }
+#pragma unroll
+            for (uint32_t kb = 0; kb < NBX; ++kb) {
+                if (kb == 0 || __any(16 * (NBX * grp + kb) < L)) {
+                    const uint32_t ch = NBX * grp + kb;
+                    const uint4 S = Sb[kb], Q = Qb[kb];
+                    const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
+                    const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+                    if (__any(nv != 0 && L <= 16 * ch + 16)) {   // some lane is at the end of its read: "\n+\n" follows
+                        if (nv != 0 && L <= 16 * ch + 16) {
+                            uint32_t two;   // the two bytes after the read's newline
+                            if (nv <= 13) {
+                                const uint32_t o = nv + 1, wi = o >> 2;
+                                const uint32_t lo = wi == 0 ? sw[0] : (wi == 1 ? sw[1] : (wi == 2 ? sw[2] : sw[3]));
+                                const uint32_t hi = wi == 0 ? sw[1] : (wi == 1 ? sw[2] : sw[3]);
+                                two = __builtin_amdgcn_alignbit(hi, lo, (o & 3) * 8) & 0xffffu;
+                            } else {
+                                two = (load4_unaligned(A.buf, se) >> 8) & 0xffffu;
+                            }
+                            if (two != 0x0a2bu) atomicMin(A.err, (int32_t)ERR_FORMAT);
+                        }
+                    }
+                    uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
+                    const bool wany[4] = {true, (bool)__any(nv > 4), (bool)__any(nv > 8), (bool)__any(nv > 12)};   // words any lane still needs
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
-                        const uint32_t ok01 = t_nonzero01(d[k]) ^ 0x01010101u;
-                        const uint32_t p0 = idx[k] & ok01, p1 = (idx[k] >> 1) & ok01;
+                        if (!wany[k]) continue;
+                        const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                        const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);   // bytes past the read count as 'A': no bits below
+                        idx[k] = sr_idx(w);
+                        d[k] = sr_not_acgt(w, idx[k]);
+                        dacc |= d[k];
+                        qbad |= sr_q_out(qw[k]) & vm;
+                        const uint32_t p0 = idx[k] & 0x01010101u, p1 = (idx[k] >> 1) & 0x01010101u;
                         c0 += __builtin_popcount(p0);
                         c1 += __builtin_popcount(p1);
                         c01 += __builtin_popcount(p0 & p1);
                     }
-                }
-                t0 += c0; t1 += c1; t01 += c01; nok += nv - __builtin_popcount(ambm);
-                const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
-                if (__any(okm)) {   // branch-free: bytes that do not count go to the lane's own trash word
+                    const bool rows_ok = 16 * ch + 17 <= lds_rows;
+                    const bool odd = dacc != 0 || qbad != 0 || (nv != 0 && nv != 16);
+                    const unsigned long long live = __ballot(nv != 0);
+                    const uint32_t nv_first = live ? (uint32_t)__builtin_amdgcn_readlane((int)nv, __builtin_ctzll(live)) : 0u;
+                    if (rows_ok && !__any(odd)) {
+                        if (nv) {
+                            // tasks.cpp:268-283: position histogram rows 1..max_q.  All lanes are at the same 16 positions, so
+                            // each lane walks them in its own rotated order (word lj, byte lb): 16 different rows per
+                            // instruction instead of one, or the LDS atomics serialise on the popular quality values.
+                            const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        const uint32_t j = (k + lj) & 3;
-                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
-                        const uint32_t joff = rb + j * (4 * SR_HSTRIDE * 4);
-                        const uint32_t okw = okm >> (4 * j);
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t j = (k + lj) & 3;
+                                const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                                const uint32_t joff = rb + j * (4 * SR_HSTRIDE * 4);
 #pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
-                            const uint32_t a = ((okw >> (bsh[b] >> 3)) & 1u) ? joff + boff[b] + 4 * q : trash;
-                            atomicAdd(reinterpret_cast<uint32_t *>(hb + a), 1u);
-                        }
-                    }
-                }
-                if (__any(glm)) {
-#pragma unroll
-                    for (uint32_t u = 0; u < 16; ++u)
-                        if ((glm >> u) & 1u) atomicAdd(&qh[(size_t)(16 * ch + u + 1) * 256 + sr_byte(qw, u)], 1u);
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {   // only the dwords in which some lane holds an ambiguity code
-                    if (!__any((ambm >> (4 * k)) & 15u)) continue;
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        const uint32_t u = 4 * k + b;
-                        if ((ambm >> u) & 1u) {
-                            const uint32_t a = s_amb[sr_byte(sw, u)];
-                            if (a == 0) fl |= 2;
-                            else {
-                                const uint32_t q = sr_byte(qw, u);
-                                fl |= (q < 33 || q > 40) ? 2u : 1u;
-                                ++namb;
+                                for (uint32_t b = 0; b < 4; ++b) {
+                                    const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                                    atomicAdd(reinterpret_cast<uint32_t *>(hb + joff + boff[b] + 4 * q), 1u);
+                                }
                             }
-                            // remember where it was (up to four per record) for the pass below
-                            const uint32_t p16 = 16 * ch + u;
-                            if (nall < 2) apos0 |= p16 << (16 * nall);
-                            else if (nall < 4) apos1 |= p16 << (16 * (nall - 2));
-                            ++nall;
+                            t0 += c0; t1 += c1; t01 += c01; nok += 16;
+                        }
+                    } else if (16 * ch + nv_first + 1 <= lds_rows && !__any(dacc != 0 || qbad != 0) && !__any(nv != 0 && nv != nv_first)) {
+                        // the read tails of equally long reads: the same nv < 16 bytes in every lane, nothing odd about them
+                        if (nv) {
+                            const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
+                            for (uint32_t u = 0; u < nv_first; ++u) {
+                                const uint32_t w = u < 4 ? qw[0] : (u < 8 ? qw[1] : (u < 12 ? qw[2] : qw[3]));
+                                const uint32_t q = (w >> (8 * (u & 3))) & 0xffu;
+                                atomicAdd(reinterpret_cast<uint32_t *>(hb + rb + u * SR_HSTRIDE * 4 + 4 * q), 1u);
+                            }
+                            t0 += c0; t1 += c1; t01 += c01; nok += nv;
+                        }
+                    } else {
+                        uint32_t ambm = 0, qbm = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            if (!wany[k]) continue;
+                            ambm |= t_movemask(t_nonzero01(d[k])) << (4 * k);
+                            qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
+                        }
+                        const uint32_t validm = (1u << nv) - 1u;
+                        const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // rows 16ch+1.. inside LDS
+                        const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
+                        ambm &= validm;
+                        const uint32_t okm = validm & ~ambm & ~qbm & rowm;    // added to the LDS histogram now
+                        const uint32_t glm = validm & ~ambm & ~okm;           // unambiguous but outside the LDS histogram
+                        if (ambm) {   // recount the bases without the ambiguous ones
+                            c0 = c1 = c01 = 0;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t ok01 = t_nonzero01(d[k]) ^ 0x01010101u;
+                                const uint32_t p0 = idx[k] & ok01, p1 = (idx[k] >> 1) & ok01;
+                                c0 += __builtin_popcount(p0);
+                                c1 += __builtin_popcount(p1);
+                                c01 += __builtin_popcount(p0 & p1);
+                            }
+                        }
+                        t0 += c0; t1 += c1; t01 += c01; nok += nv - __builtin_popcount(ambm);
+                        const uint32_t rb = (16 * ch + 1) * SR_HSTRIDE * 4 - 33 * 4;
+                        if (__any(okm)) {   // branch-free: bytes that do not count go to the lane's own trash word
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t j = (k + lj) & 3;
+                                const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                                const uint32_t joff = rb + j * (4 * SR_HSTRIDE * 4);
+                                const uint32_t okw = okm >> (4 * j);
+#pragma unroll
+                                for (uint32_t b = 0; b < 4; ++b) {
+                                    const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                                    const uint32_t a = ((okw >> (bsh[b] >> 3)) & 1u) ? joff + boff[b] + 4 * q : trash;
+                                    atomicAdd(reinterpret_cast<uint32_t *>(hb + a), 1u);
+                                }
+                            }
+                        }
+                        if (__any(glm)) {
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; ++u)
+                                if ((glm >> u) & 1u) atomicAdd(&qh[(size_t)(16 * ch + u + 1) * 256 + sr_byte(qw, u)], 1u);
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {   // only the dwords in which some lane holds an ambiguity code
+                            if (!__any((ambm >> (4 * k)) & 15u)) continue;
+#pragma unroll
+                            for (uint32_t b = 0; b < 4; ++b) {
+                                const uint32_t u = 4 * k + b;
+                                if ((ambm >> u) & 1u) {
+                                    const uint32_t a = s_amb[sr_byte(sw, u)];
+                                    if (a == 0) fl |= 2;
+                                    else {
+                                        const uint32_t q = sr_byte(qw, u);
+                                        fl |= (q < 33 || q > 40) ? 2u : 1u;
+                                        ++namb;
+                                    }
+                                    // remember where it was (up to four per record) for the pass below
+                                    const uint32_t p16 = 16 * ch + u;
+                                    const uint32_t pv = p16 << (16 * (nall & 1u));   // (no choice between two variables: inside the
+                                    apos0 |= nall < 2 ? pv : 0u;                      //  lambda that would put both into scratch)
+                                    apos1 |= (nall >= 2 && nall < 4) ? pv : 0u;
+                                    ++nall;
+                                }
+                            }
                         }
                     }
                 }
@@ -388,6 +416,7 @@ __device__ __forceinline__ uint32_t sq_qentry_slow(const SqTabs &T, uint32_t row
 }
 
 // ---- measure: payload bits per record and per 256-record tile ----
+template <bool BURST>
 __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw)
 {
     if (*A.err) return;
@@ -438,19 +467,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         const bool xfer = xfer_d && !by_list;         // for the quality lengths inside the chunk loop
         const bool need_s = !plain || __any(xfer);   // bases matter for the Huffman DNA lengths and for the transferred positions
         uint32_t qb = 0, db = plain ? 2u * (sl & 0x0fffffffu) : 0u;
-        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
-        if (L) {
-            Qn = load16_unaligned(A.buf, q0, A.buf_len);
-            if (need_s) Sn = load16_unaligned(A.buf, s0, A.buf_len);
-        }
-        for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
+        // NB chunks are fetched back to back, see k_sq_stats_reg
+        auto chunk = [&](const uint32_t ch, const uint4 S, const uint4 Q) __attribute__((always_inline)) {
             const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            const uint4 S = Sn, Q = Qn;
-            Sn = Qn = make_uint4(0, 0, 0, 0);
-            if (L > 16 * ch + 16) {
-                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
-                if (need_s) Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
-            }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
             uint32_t qbad = 0, dacc = 0, idx[4];
 #pragma unroll
@@ -523,6 +542,38 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     }
                     db = __builtin_amdgcn_sad_u8(l4, 0u, db);
                 }
+            }
+        };
+        if constexpr (BURST) {
+            for (uint32_t c4 = 0; __any(16 * NB * c4 < L); ++c4) {
+                uint4 Sb[NB], Qb[NB];
+#pragma unroll
+                for (uint32_t k = 0; k < NB; ++k) {
+                    const uint32_t off = 16 * NB * c4 + 16 * k;
+                    Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
+                    if (L > off) {
+                        Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
+                        if (need_s) Sb[k] = load16_unaligned(A.buf, s0 + off, A.buf_len);
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < NB; ++k)
+                    if (k == 0 || __any(16 * NB * c4 + 16 * k < L)) chunk(NB * c4 + k, Sb[k], Qb[k]);
+            }
+        } else {
+            uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
+            if (L) {
+                if (need_s) Sn = load16_unaligned(A.buf, s0, A.buf_len);
+                Qn = load16_unaligned(A.buf, q0, A.buf_len);
+            }
+            for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
+                const uint4 S = Sn, Q = Qn;
+                Sn = Qn = make_uint4(0, 0, 0, 0);
+                if (L > 16 * ch + 16) {
+                    if (need_s) Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
+                    Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
+                }
+                chunk(ch, S, Q);
             }
         }
         if (__any(by_list && nall)) {
@@ -604,6 +655,7 @@ __device__ __forceinline__ uint32_t sq_scan_excl256(uint32_t v, uint32_t *s_part
     return basev + incl - v;
 }
 
+template <bool BURST>
 __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw)
 {
     if (*A.err) return;
@@ -679,124 +731,145 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
         wq_.init(q_lds ? st_q : outw, q_lds ? qw0 : 0, qb0 + qo);
         wd_.init(d_lds ? st_d : outw, d_lds ? dw0 : 0, db0 + dofs);
 
-        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
-        if (L) {
+        constexpr uint32_t NBX = BURST ? NB : 1u;   // chunks per trip, see k_sq_stats_reg
+        uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
+        if (!BURST && L) {
             Sn = load16_unaligned(A.buf, s0, A.buf_len);
             Qn = load16_unaligned(A.buf, q0, A.buf_len);
         }
-        for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
-            const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-            const uint4 S = Sn, Q = Qn;
-            Sn = Qn = make_uint4(0, 0, 0, 0);
-            if (L > 16 * ch + 16) {
-                Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
-                Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
-            }
-            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
-            uint32_t qbad = 0, dacc = 0, idx[4];
+        for (uint32_t grp = 0; __any(16 * NBX * grp < L); ++grp) {
+            uint4 Sb[NBX], Qb[NBX];
+            if constexpr (BURST) {
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                qbad |= sr_q_out(qw[k]) & vm;
-                const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
-                idx[k] = sr_idx(w);
-                dacc |= sr_not_acgt(w, idx[k]);
-            }
-            // Per-byte exceptions as 16-bit masks.  The common bytes go through the table / v_perm paths four at a time;
-            // a word (4 bytes) is patched byte by byte only if some lane of the wave has an exception in that word.
-            const uint32_t validm = (1u << nv) - 1u;
-            uint32_t ambm = 0, qbm = 0;
-            if (__any(dacc != 0 || qbad != 0)) {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                    const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
-                    ambm |= t_movemask(t_nonzero01(sr_not_acgt(w, idx[k]))) << (4 * k);
-                    qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
-                }
-                qbm &= validm;
-            }
-            const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // table rows for this chunk's positions
-            const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
-            // quality bytes whose entry is not in the LDS table: odd bytes, transferred ones, rows past the table
-            const uint32_t qpatch = (qbm | (xfer ? ambm : 0u) | (validm & ~rowm));
-
-            // ---- quality (tasks.cpp:609-619): four symbols per put when their codes fit 32 bits together ----
-            {
-                const uint32_t row0 = 16 * ch + 1;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!__any(nv > 4 * k)) continue;
-                    uint32_t e[4];
-#pragma unroll
-                    for (uint32_t b = 0; b < 4; ++b) {
-                        const uint32_t u = 4 * k + b;
-                        const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
-                        e[b] = s_qtab[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
+                for (uint32_t k = 0; k < NBX; ++k) {
+                    const uint32_t off = 16 * NBX * grp + 16 * k;
+                    Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
+                    if (L > off) {
+                        Sb[k] = load16_unaligned(A.buf, s0 + off, A.buf_len);
+                        Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
                     }
-                    if (__any((qpatch >> (4 * k)) & 15u)) {
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            const uint32_t u = 4 * k + b;
-                            if ((qpatch >> u) & 1u) {
-                                uint32_t q = sr_byte(qw, u);
-                                if (xfer && ((ambm >> u) & 1u)) q = transfer_quality(s_amb[sr_byte(sw, u)], (uint8_t)q);   // phyNGSC.cpp:579
-                                e[b] = sq_qentry_slow(T, row0 + u, q);
-                            }
-                        }
-                    }
-                    if (__any(nv < 4 * k + 4)) {   // read tails: bytes past the read contribute no bits
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) e[b] = ((validm >> (4 * k + b)) & 1u) ? e[b] : 0u;
-                    }
-                    const uint32_t l1 = e[1] & 31u, l2 = e[2] & 31u, l3 = e[3] & 31u;
-                    const uint32_t tl = (e[0] & 31u) + l1 + l2 + l3;
-                    if (__any(tl > 32)) {
-                        wq_.put(e[0] >> 5, e[0] & 31u); wq_.put(e[1] >> 5, l1); wq_.put(e[2] >> 5, l2); wq_.put(e[3] >> 5, l3);
-                    } else {
-                        wq_.put(((((((e[0] >> 5) << l1) | (e[1] >> 5)) << l2) | (e[2] >> 5)) << l3) | (e[3] >> 5), tl);
-                    }
-                }
-            }
-
-            // ---- DNA (tasks.cpp:544-557) ----
-            if (plain && !__any(ambm != 0)) {
-                if (nv) {
-                    // two bits per base: the four code bytes of a dword collapse with one multiply
-                    uint32_t x = 0;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                        x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
-                    wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
-                }
-            } else if (short_codes) {
-                // code and length bytes of the four bases of a dword from v_perm tables; ambiguity codes are patched in
-                // from the byte table (or dropped: transferred records carry them in the quality stream)
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!__any(nv > 4 * k)) continue;
-                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                    uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vm;
-                    if (__any((ambm >> (4 * k)) & 15u)) {
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            if ((ambm >> (4 * k + b)) & 1u) {
-                                const uint32_t ee = xfer ? 0u : s_dcode[sr_byte(sw, 4 * k + b)];
-                                l4 = (l4 & ~(0xffu << (8 * b))) | ((ee & 31u) << (8 * b));
-                                c4 = (c4 & ~(0xffu << (8 * b))) | ((ee >> 5) << (8 * b));
-                            }
-                        }
-                    }
-                    const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
-                    const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
-                    wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
                 }
             } else {
+                Sb[0] = Sn; Qb[0] = Qn;
+                Sn = Qn = make_uint4(0, 0, 0, 0);
+                if (L > 16 * grp + 16) {
+                    Sn = load16_unaligned(A.buf, s0 + 16 * grp + 16, A.buf_len);
+                    Qn = load16_unaligned(A.buf, q0 + 16 * grp + 16, A.buf_len);
+                }
+            }
 #pragma unroll
-                for (uint32_t u = 0; u < 16; ++u) {
-                    if (u < nv) {
-                        const uint32_t c = sr_byte(sw, u);
-                        if (!(xfer && s_amb[c] > 1)) { const uint32_t e = s_dcode[c]; wd_.put(e >> 5, e & 31u); }
+            for (uint32_t kb = 0; kb < NBX; ++kb) {
+                if (kb == 0 || __any(16 * (NBX * grp + kb) < L)) {
+                    const uint32_t ch = NBX * grp + kb;
+                    const uint4 S = Sb[kb], Q = Qb[kb];
+                    const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
+                    const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+                    uint32_t qbad = 0, dacc = 0, idx[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                        qbad |= sr_q_out(qw[k]) & vm;
+                        const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                        idx[k] = sr_idx(w);
+                        dacc |= sr_not_acgt(w, idx[k]);
+                    }
+                    // Per-byte exceptions as 16-bit masks.  The common bytes go through the table / v_perm paths four at a time;
+                    // a word (4 bytes) is patched byte by byte only if some lane of the wave has an exception in that word.
+                    const uint32_t validm = (1u << nv) - 1u;
+                    uint32_t ambm = 0, qbm = 0;
+                    if (__any(dacc != 0 || qbad != 0)) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                            const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                            ambm |= t_movemask(t_nonzero01(sr_not_acgt(w, idx[k]))) << (4 * k);
+                            qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
+                        }
+                        qbm &= validm;
+                    }
+                    const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // table rows for this chunk's positions
+                    const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
+                    // quality bytes whose entry is not in the LDS table: odd bytes, transferred ones, rows past the table
+                    const uint32_t qpatch = (qbm | (xfer ? ambm : 0u) | (validm & ~rowm));
+
+                    // ---- quality (tasks.cpp:609-619): four symbols per put when their codes fit 32 bits together ----
+                    {
+                        const uint32_t row0 = 16 * ch + 1;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            if (!__any(nv > 4 * k)) continue;
+                            uint32_t e[4];
+#pragma unroll
+                            for (uint32_t b = 0; b < 4; ++b) {
+                                const uint32_t u = 4 * k + b;
+                                const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
+                                e[b] = s_qtab[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
+                            }
+                            if (__any((qpatch >> (4 * k)) & 15u)) {
+#pragma unroll
+                                for (uint32_t b = 0; b < 4; ++b) {
+                                    const uint32_t u = 4 * k + b;
+                                    if ((qpatch >> u) & 1u) {
+                                        uint32_t q = sr_byte(qw, u);
+                                        if (xfer && ((ambm >> u) & 1u)) q = transfer_quality(s_amb[sr_byte(sw, u)], (uint8_t)q);   // phyNGSC.cpp:579
+                                        e[b] = sq_qentry_slow(T, row0 + u, q);
+                                    }
+                                }
+                            }
+                            if (__any(nv < 4 * k + 4)) {   // read tails: bytes past the read contribute no bits
+#pragma unroll
+                                for (uint32_t b = 0; b < 4; ++b) e[b] = ((validm >> (4 * k + b)) & 1u) ? e[b] : 0u;
+                            }
+                            const uint32_t l1 = e[1] & 31u, l2 = e[2] & 31u, l3 = e[3] & 31u;
+                            const uint32_t tl = (e[0] & 31u) + l1 + l2 + l3;
+                            if (__any(tl > 32)) {
+                                wq_.put(e[0] >> 5, e[0] & 31u); wq_.put(e[1] >> 5, l1); wq_.put(e[2] >> 5, l2); wq_.put(e[3] >> 5, l3);
+                            } else {
+                                wq_.put(((((((e[0] >> 5) << l1) | (e[1] >> 5)) << l2) | (e[2] >> 5)) << l3) | (e[3] >> 5), tl);
+                            }
+                        }
+                    }
+
+                    // ---- DNA (tasks.cpp:544-557) ----
+                    if (plain && !__any(ambm != 0)) {
+                        if (nv) {
+                            // two bits per base: the four code bytes of a dword collapse with one multiply
+                            uint32_t x = 0;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k)
+                                x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
+                            wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
+                        }
+                    } else if (short_codes) {
+                        // code and length bytes of the four bases of a dword from v_perm tables; ambiguity codes are patched in
+                        // from the byte table (or dropped: transferred records carry them in the quality stream)
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            if (!__any(nv > 4 * k)) continue;
+                            const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                            uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm, c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vm;
+                            if (__any((ambm >> (4 * k)) & 15u)) {
+#pragma unroll
+                                for (uint32_t b = 0; b < 4; ++b) {
+                                    if ((ambm >> (4 * k + b)) & 1u) {
+                                        const uint32_t ee = xfer ? 0u : s_dcode[sr_byte(sw, 4 * k + b)];
+                                        l4 = (l4 & ~(0xffu << (8 * b))) | ((ee & 31u) << (8 * b));
+                                        c4 = (c4 & ~(0xffu << (8 * b))) | ((ee >> 5) << (8 * b));
+                                    }
+                                }
+                            }
+                            const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
+                            const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
+                            wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t u = 0; u < 16; ++u) {
+                            if (u < nv) {
+                                const uint32_t c = sr_byte(sw, u);
+                                if (!(xfer && s_amb[c] > 1)) { const uint32_t e = s_dcode[c]; wd_.put(e >> 5, e & 31u); }
+                            }
+                        }
                     }
                 }
             }
@@ -836,6 +909,16 @@ static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec)
     return rpw;
 }
 
+// NB chunks fetched back to back (BURST) - measured per 400 MB: 150-base reads statistics 0.41 -> 0.25 ms and measure
+// 0.39 -> 0.27 ms, 36..300-base reads 0.34 -> 0.31 and 0.33 -> 0.31 ms, 36-base reads unchanged; the pack kernel gets
+// slower with it and keeps one chunk per trip.  Used when the longest read exceeds 64 bases; NGSC_SQ_BURST=0|1 forces.
+static bool sr_burst(const Arena &A)
+{
+    static const int forced = getenv("NGSC_SQ_BURST") ? atoi(getenv("NGSC_SQ_BURST")) : -1;
+    if (forced >= 0) return forced != 0;
+    return A.qrows - 1 > 16 * NB;   // reads that one trip of NB chunks does not cover anyway
+}
+
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     uint32_t rows = A.qrows;
@@ -844,8 +927,9 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t rpw = sr_records_per_wg(A, max_rec);
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
     const size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
-    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_stats_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
-    hipLaunchKernelGGL(k_sq_stats_reg, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
+    auto kern = sr_burst(A) ? k_sq_stats_reg<true> : k_sq_stats_reg<false>;
+    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
 }
 
 static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)
@@ -859,7 +943,8 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
-    hipLaunchKernelGGL(k_sq_measure_reg, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS + 64, st, A, rows, tpw);
+    auto kern = sr_burst(A) ? k_sq_measure_reg<true> : k_sq_measure_reg<false>;
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS + 64, st, A, rows, tpw);
 }
 
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
@@ -870,8 +955,11 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     const size_t lds = ((size_t)rows * SR_HCOLS + sw_q + sw_d) * 4;
-    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sq_pack_reg), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
-    hipLaunchKernelGGL(k_sq_pack_reg, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw);
+    // one chunk per trip: with NB chunks fetched back to back this kernel is 8-10 % slower on every configuration (it
+    // is bound by its bit writers, not by the loads), so only that variant is built
+    auto kern = k_sq_pack_reg<false>;
+    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw);
 }
 
 }  // namespace ngsc
