@@ -932,7 +932,10 @@ static void compress_rank(const uint8_t *fastq, uint64_t FS, uint32_t P, uint32_
         uint64_t av = (uint64_t)wr_start < FS ? FS - (uint64_t)wr_start : 0;
         if (av > (uint64_t)bsize) av = (uint64_t)bsize;
         cur = ngsc_o_first_record(fastq + wr_start, av);
-        if (cur < 0) { ro->rc = NGSC_O_EFORMAT; return; }
+        if (cur < 0) {
+            if (getenv("NGSC_O_VERBOSE")) fprintf(stderr, "oracle: rank %u finds no record start in its region\n", rank);
+            ro->rc = NGSC_O_EFORMAT; return;
+        }
     }
     ro->overlap_used = (int32_t)cur;
     uint64_t rec_start = (uint64_t)cur;
@@ -958,7 +961,12 @@ static void compress_rank(const uint8_t *fastq, uint64_t FS, uint32_t P, uint32_
         uint64_t sblen = 0;
         ngsc_o_sbinfo inf;
         int rc = ngsc_o_subblock(fastq + win_pos, avail, (uint64_t)bsize, rec_start, overlap, &sb, &sblen, &inf);
-        if (rc) { ro->rc = rc; free(payload); return; }
+        if (rc) {
+            if (getenv("NGSC_O_VERBOSE"))
+                fprintf(stderr, "oracle: rank %u window at %lld (size %lld, first record at +%llu): rc %d\n", rank, (long long)win_pos,
+                        (long long)bsize, (unsigned long long)rec_start, rc);
+            ro->rc = rc; free(payload); return;
+        }
         ro->n_subblocks++;
         bytes_read += (int64_t)inf.next_offset; /* :745 */
         win_pos = bytes_read + wr_start;        /* :746 */

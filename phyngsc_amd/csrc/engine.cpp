@@ -334,7 +334,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     {
         KScope k(c, st, "k_cuts_validate");
         launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
-                             max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err);
+                             max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr);
     }
     // ---- sync 2: cut list ----
     size_t plan_bytes = cs.off - o_plans;
@@ -346,10 +346,15 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (!n_rec_total || (size_t)n_rec_total + 2 > rec_bound) return NGSC_ERR_FORMAT;
     // per-record arrays
     const size_t rec_cap = (size_t)n_rec_total + 2;
+    // Arrays whose per-record values depend on the sub-block (title bits, cached fields, candidate values, payload bit
+    // counts) are indexed by record + sub-block ordinal: a sub-block takes its second record whatever its size
+    // (phyNGSC.cpp:295-300), so when a rank's last window holds a single record before the overlap, its second record is
+    // also the first record of the next rank - one record, two owners, two different sets of values.
+    const size_t slot_cap = rec_cap + (size_t)n_ranks * max_cuts;
     const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
     Carver cr2;
-    size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * rec_cap), o_doff = cr2.take(4 * rec_cap);
-    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * rec_cap);
+    size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * slot_cap), o_doff = cr2.take(4 * slot_cap);
+    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * slot_cap);
     size_t o_tsep = cr2.take(8 * rec_cap), o_apos = cr2.take(8 * rec_cap);
     rc = ensure(c, c->recs2, cr2.off);
     if (rc) return rc;
@@ -372,11 +377,6 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     const uint32_t S = (uint32_t)cuts.size();
     if (!S) return NGSC_ERR_FORMAT;
-    // A sub-block takes its second record whatever its size (phyNGSC.cpp:295-300), so with rank regions of a few
-    // records' size the last record of one rank can also be the first of the next.  The per-record arrays are indexed
-    // by record: such a job (file_size / P of the order of one record) is refused rather than given two owners.
-    for (uint32_t i = 0; i + 1 < S; ++i)
-        if (cuts[i].rec_lo + cuts[i].n_rec > cuts[i + 1].rec_lo) return NGSC_ERR_UNSUPPORTED;
     const uint32_t qrows = max_q + 1;
     uint32_t max_rec = 0;
     for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);
@@ -421,8 +421,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_tilelo = cp.take(4 * (size_t)S);
     size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
     size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
-    size_t p_tw = cp.take(4 * (size_t)NCF_CAP * rec_cap);
-    size_t p_tv = cp.take(4 * (size_t)NUM_CAND_CAP * rec_cap);
+    size_t p_tw = cp.take(4 * (size_t)NCF_CAP * slot_cap);
+    size_t p_tv = cp.take(4 * (size_t)NUM_CAND_CAP * slot_cap);
     size_t p_rec0 = cp.take(sizeof(Rec0Tab) * (size_t)S);
     rc = ensure(c, c->persb, cp.off);
     if (rc) return rc;
@@ -452,7 +452,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.ubits = (uint32_t *)(pb + p_ubits);
     A.tw = (uint32_t *)(pb + p_tw);
     A.tv = (uint32_t *)(pb + p_tv);
-    A.tw_stride = (uint32_t)rec_cap;
+    A.tw_stride = (uint32_t)slot_cap;
     A.rec0 = (Rec0Tab *)(pb + p_rec0);
     A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;

@@ -287,14 +287,27 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
                                                        uint64_t buf_off, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
                                                        const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                                                        uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
-                                                       uint32_t *max_title, int32_t *err)
+                                                       uint32_t *max_title, int32_t *err, const uint8_t *tail_buf)
 {
     const uint32_t n_rec_total = *total_lines / 4;
+    // tail_buf: the job buffer when it ends where the file ends.  Two real newlines behind the last complete record (the
+    // assumed one makes three lines) are a title and a read whose quality line is missing: the reference's record loop
+    // takes such a record as soon as both newlines lie behind the first leftover byte (phyNGSC.cpp:303-312) and then
+    // reads its quality past the end of the data.  Two bare blank lines do not qualify (the loop skips the first byte).
+    if (tail_buf && blockIdx.x == n_ranks && threadIdx.x == 0 && (*total_lines & 3u) == 3u && tail_buf[ls[n_rec_total]] != '\n')
+        atomicMin(err, (int32_t)ERR_FORMAT);
     if (blockIdx.x < n_ranks) {
         if (threadIdx.x >= 64) return;   // one wave per rank; all lanes run the (uniform) planner, the searches are wave-wide
         const uint32_t i = blockIdx.x;
         int rc = plan_rank_with(WaveSearch(), file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
                                 cuts + (size_t)i * max_cuts, max_cuts, &plans[i]);
+        // ... and behind the first record of a window the loop does not skip that byte (phyNGSC.cpp:295-300): there two
+        // blank lines qualify as well
+        if (!rc && tail_buf && (*total_lines & 3u) == 3u && n_rec_total) {
+            const uint32_t nc = plans[i].n_cuts;
+            for (uint32_t k = 0; k < nc && k < max_cuts; ++k)
+                if (cuts[(size_t)i * max_cuts + k].rec_lo + 1 == n_rec_total) rc = ERR_FORMAT;
+        }
         if (threadIdx.x == 0) {
             plans[i].err = rc;
             if (rc) atomicMin(err, (int32_t)rc);
@@ -339,7 +352,7 @@ void launch_nl_write(hipStream_t st, const uint32_t *nl_mask, uint32_t len, cons
 void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
-                          uint32_t *max_rec, uint32_t *max_title, int32_t *err)
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf)
 {
     // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
     // wave per 64 records
@@ -347,7 +360,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
     if (vblocks < 1) vblocks = 1;
     if (vblocks > 16384) vblocks = 16384;
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err);
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf);
 }
 
 }  // namespace ngsc

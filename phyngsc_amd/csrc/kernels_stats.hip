@@ -258,7 +258,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
         if (!walk) {
             // every needed field is numeric and k_title_stats_swar kept its values: no need to touch the titles
             for (uint32_t f = 0; f < nf; ++f)
-                if ((need >> f) & 1) s_val[s_k[f]][tid] = (valid && use_tv) ? A.tv[(size_t)fd[f].cand * A.tw_stride + g] : 0u;
+                if ((need >> f) & 1) s_val[s_k[f]][tid] = (valid && use_tv) ? A.tv[(size_t)fd[f].cand * A.tw_stride + g + s] : 0u;
         }
         if (walk || !use_tv) {
             const unsigned long long sepmask = (use_tv && valid) ? A.tsep[g] : 0ull;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
                 if ((need >> f) & 1) {
                     if (d.kind == KIND_NUM) {
                         uint32_t v = 0;
-                        if (use_tv) v = valid ? A.tv[(size_t)d.cand * A.tw_stride + g] : 0u;
+                        if (use_tv) v = valid ? A.tv[(size_t)d.cand * A.tw_stride + g + s] : 0u;
                         else { bool o; parse_num(buf, pc, ec, v, o); }
                         const uint32_t k = s_k[f];
                         if (k != 0xff) {

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
                 const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
                 const uint32_t kind = s_fd[f].kind;
                 if (kind == KIND_NUM) {   // parsed once, by k_title_stats_swar
-                    s_w[s_fd[f].kf][tid] = valid ? A.tv[(size_t)s_fd[f].cand * A.tw_stride + g] : 0u;
+                    s_w[s_fd[f].kf][tid] = valid ? A.tv[(size_t)s_fd[f].cand * A.tw_stride + g + s] : 0u;
                 } else if (kind == KIND_TEXT) {
                     s_w[s_fd[f].kf][tid] = pos | (len << 16);
                 }
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
             const uint32_t ff = s_kf_field[kf];
             const uint32_t wc = s_w[kf][tid];
             C.cur[kf] = wc;
-            A.tw[(size_t)kf * A.tw_stride + g] = wc;
+            A.tw[(size_t)kf * A.tw_stride + g + s] = wc;
             if (gi) {
                 const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
                 C.prev[kf] = wp;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
             bits = (uint32_t)bc.bits;
         }
     }
-    if (valid) A.tbits[g] = bits;
+    if (valid) A.tbits[g + s] = bits;
     const uint32_t gbits = t_g32_sum(bits);
     if (valid && gi == 0) {
         const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     const bool valid = (uint32_t)tid < nt;
     const uint32_t gi = tid & 31, gstart = tid - gi;
     const uint32_t g = valid ? i0 + tid : i0;
-    const uint32_t bits = valid ? A.tbits[g] : 0;
+    const uint32_t bits = valid ? A.tbits[g + s] : 0;
     uint32_t incl = bits;  // inclusive prefix inside the 32-record group
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
             for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
                 C.cur[kf] = C.prev[kf] = 0;
                 if (kf >= ncf) continue;
-                C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + g];
-                if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + g - 1];
+                C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + g + s];
+                if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + g + s - 1];
             }
             title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
         } else {
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             isn = true;
             v = s_r0.val0[f];
             ovf = s_r0.ovf0[f] != 0;
-            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g] = v;
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + s] = v;
             nummask |= 1u << f;
         } else if (kk != 0xff) {
             const uint64_t dm = pos < 64 ? digmask >> pos : 0, lm = t_lowbits(len);
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                     }
                 }
             }
-            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g] = v;   // k_title_measure_reg<true> and k_title_hist read it back
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + s] = v;   // k_title_measure_reg<true> and k_title_hist read it back
             nummask |= (uint32_t)isn << f;
         }
         if (kk < NUM_CAND_CAP) {   // (uniform) delta to the previous record, both numeric

@@ -18,7 +18,7 @@ void launch_nl_write(hipStream_t st, const uint32_t *nl_mask, uint32_t len, cons
 void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
-                          uint32_t *max_rec, uint32_t *max_title, int32_t *err);
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf);
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--reference", action="store_true",
                     help="build container only: compare the oracle with oracle/_ref/phyNGSC (mpiexec -np P) instead")
     ap.add_argument("--seeds", type=int, default=10 ** 9)
+    ap.add_argument("--driver", action="store_true",
+                    help="also push every accepted file through ngsc_compress_file_multi (two contexts, small jobs)")
     a = ap.parse_args()
 
     eng = None
@@ -52,6 +54,10 @@ def main():
         from phyngsc_amd import api
         assert torch.cuda.is_available(), "needs the MI355X (or --cpu-only)"
         eng = api.Engine(0)
+        if a.driver:
+            import tempfile
+            eng2 = api.Engine(0)
+            dtmp = tempfile.mkdtemp(prefix="ngsc_fuzz_drv_")
     t_end = time.time() + a.seconds
     seed = a.first_seed
     n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = 0
@@ -116,16 +122,26 @@ def main():
                 g_rc = 0
             except api.NgscError as e:
                 got, g_rc = None, e.code
-            if o_rc == 0 and g_rc == -8 and len(data) // d["P"] < 4 * max_rec:
-                # documented engine limit: rank regions of about one record's size (two ranks own the same record)
-                n_limit += 1
-                seed += 1
-                continue
             if (o_rc == 0) != (g_rc == 0):
                 verdict = f"oracle rc {o_rc}, engine rc {g_rc}"
             elif o_rc == 0 and got != ref:
                 k = next((x for x in range(min(len(got), len(ref))) if got[x] != ref[x]), min(len(got), len(ref)))
                 verdict = f"containers differ at byte {k} (sizes {len(got)} / {len(ref)})"
+            elif o_rc == 0 and a.driver:
+                # the file driver: jobs of a few ranks each, one or two contexts
+                fq, outp = os.path.join(dtmp, "in.fastq"), os.path.join(dtmp, "out.ngsc")
+                with open(fq, "wb") as f:
+                    f.write(data)
+                os.environ["NGSC_JOB_BYTES"] = str(rnd.choice([1, 300_000, 2_000_000, 9_000_000]))
+                engines = [eng, eng2] if d["P"] % 2 == 0 and rnd.random() < 0.5 else [eng]
+                try:
+                    api.compress_file_multi(engines, fq, outp, d["P"])
+                    with open(outp, "rb") as f:
+                        if f.read() != ref:
+                            verdict = f"file driver output differs (NGSC_JOB_BYTES={os.environ['NGSC_JOB_BYTES']}, {len(engines)} contexts)"
+                except api.NgscError as e:
+                    verdict = f"file driver rc {e.code} (NGSC_JOB_BYTES={os.environ['NGSC_JOB_BYTES']})"
+                del os.environ["NGSC_JOB_BYTES"]
         if verdict == "ok":
             if o_rc:
                 n_rej += 1
