@@ -168,3 +168,37 @@ def build_file(d, seed):
                 "cut_plus": nl[1] + 2, "cut_quality": (nl[2] + nl[3] + 1) // 2}[tail]
         data = data[: len(data) - len(last) + keep]
     return data
+
+
+def to_json(x):
+    """A dialect as JSON-able data (bytes -> {"__bytes__": latin-1 text}); from_json() is the inverse."""
+    if isinstance(x, (bytes, bytearray)):
+        return {"__bytes__": bytes(x).decode("latin-1")}
+    if isinstance(x, dict):
+        return {k: to_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [to_json(v) for v in x]
+    return x
+
+
+def from_json(x):
+    if isinstance(x, dict):
+        if set(x) == {"__bytes__"}:
+            return x["__bytes__"].encode("latin-1")
+        return {k: from_json(v) for k, v in x.items()}
+    if isinstance(x, list):
+        return [from_json(v) for v in x]
+    return x
+
+
+def manifest_input(man):
+    """The input a golden manifest (tests/golden/manifest_*.json) was made from: generator-made, or a stored dialect."""
+    import hashlib
+    from phyngsc_amd import fastq_gen
+    if "dialect" in man:
+        data = np.frombuffer(build_file(from_json(man["dialect"]), man["seed"]), dtype=np.uint8)
+        assert hashlib.sha256(data.tobytes()).hexdigest() == man["fastq_sha256"], "tests/dialects.py no longer rebuilds this input"
+    else:
+        data = fastq_gen.generate(fastq_gen.GenConfig(**man["generator"]), target_bytes=man["target_bytes"])
+    assert data.size == man["fastq_bytes"]
+    return data

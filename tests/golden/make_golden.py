@@ -213,6 +213,12 @@ GEN_CASES = [
 ]
 
 
+# inputs of the randomised runs kept as manifests: (name, seed of tests/dialects.py, max MB the dialect was drawn with)
+DIALECT_CASES = [
+    ("dialect_shared_record", 11040, 24.0),     # 17 MB, P = 2: rank 0's last window holds one record, the next is rank 1's first
+]
+
+
 def main():
     only = set(sys.argv[1:])
     os.makedirs(SMALL, exist_ok=True)
@@ -252,6 +258,28 @@ def main():
             with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
                 json.dump(man, f, indent=1, sort_keys=True)
             os.remove(path)
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        import hashlib
+        import random as _random
+        from tests import dialects
+        for name, seed, max_mb in DIALECT_CASES:
+            if only and name not in only and "dialects" not in only:
+                continue
+            d = dialects.draw_dialect(_random.Random(seed), max_mb)
+            data = dialects.build_file(d, seed)
+            path = os.path.join(tmp, name + ".fastq")
+            with open(path, "wb") as f:
+                f.write(data)
+            man = {"dialect": dialects.to_json(d), "seed": seed, "fastq_bytes": len(data),
+                   "fastq_sha256": hashlib.sha256(data).hexdigest(), "ranks": {}}
+            P = d["P"]
+            outp = os.path.join(tmp, f"{name}.p{P}.ngsc")
+            print(f"[dialect] {name} ({len(data)} B) P={P}")
+            if run_ref(path, P, outp):
+                with open(outp, "rb") as f:
+                    man["ranks"][str(P)] = ngsc_format.manifest(f.read())
+            with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
+                json.dump(man, f, indent=1, sort_keys=True)
     if not only or "small" in only:
         with open(os.path.join(HERE, "index.json"), "w") as f:
             json.dump(index["small"], f, indent=1, sort_keys=True)

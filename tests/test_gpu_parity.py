@@ -76,8 +76,8 @@ def test_reference_manifests(eng, man_path, P):
     """Generator-made inputs (10 MiB .. 1 GB): per-(WRID,k) block hashes + footer of the reference."""
     with open(man_path) as f:
         man = json.load(f)
-    data = fastq_gen.generate(fastq_gen.GenConfig(**man["generator"]), target_bytes=man["target_bytes"])
-    assert data.size == man["fastq_bytes"]
+    from tests.dialects import manifest_input
+    data = manifest_input(man)
     _, out = _gpu(eng, data, P)
     got = nf.manifest(out)
     assert got["footer"] == man["ranks"][str(P)]["footer"]

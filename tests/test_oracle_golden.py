@@ -54,9 +54,8 @@ def test_oracle_matches_reference_manifest(man_path, P):
     """Generator-made inputs (<= 64 MB here; the bigger manifests are used by the -m gpu suite)."""
     with open(man_path) as f:
         man = json.load(f)
-    cfg = fastq_gen.GenConfig(**man["generator"])
-    data = fastq_gen.generate(cfg, target_bytes=man["target_bytes"])
-    assert data.size == man["fastq_bytes"]
+    from tests.dialects import manifest_input
+    data = manifest_input(man)
     out, _ = orc.compress_file(data, P, threads=4)
     assert nf.manifest(out) == man["ranks"][str(P)]
 
