@@ -98,7 +98,11 @@ def main():
                 verdict = f"reference ok={r_ok} (rc {r.returncode}: {r.stdout[-200:]!r}), oracle rc {o_rc}"
             elif r_ok:
                 with open(outp, "rb") as f:
-                    same, msg = nf.equivalent(f.read(), ref)
+                    rbytes = f.read()
+                try:
+                    same, msg = nf.equivalent(rbytes, ref)
+                except AssertionError as e:
+                    same, msg = False, f"the reference's output does not parse ({e}); oracle {len(ref)} B, reference {len(rbytes)} B"
                 if not same:
                     verdict = "reference and oracle differ: " + msg
         elif eng is None:
