@@ -305,7 +305,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemsetAsync(sm, 0, o_first, st));
 
     const uint32_t ntiles = index_num_tiles(len);
-    // The record table is sized for the smallest possible record (8 bytes), so the line count never has to come back
+    // The record table is sized for the smallest possible record (5 bytes), so the line count never has to come back
     // to the host before the table is written.
     const size_t mask_words = index_mask_words(len);
     rc = ensure(c, c->tiles, 4 * (size_t)ntiles + 64 + 4 * mask_words);
@@ -315,7 +315,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     rc = ensure_pinned(c, cs.off);
     if (rc) return rc;
     uint8_t *hp = (uint8_t *)c->h_pin;
-    const size_t rec_bound = (size_t)len / 8 + 2;
+    const size_t rec_bound = (size_t)len / 5 + 2;   // a record is four newlines and a '+' at the very least
     Carver cr;
     size_t o_te = cr.take(4 * rec_bound), o_se = cr.take(4 * rec_bound), o_ls = cr.take(4 * (rec_bound + 1));
     rc = ensure(c, c->recs, cr.off);
@@ -344,24 +344,6 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
     const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
     if (!n_rec_total || (size_t)n_rec_total + 2 > rec_bound) return NGSC_ERR_FORMAT;
-    // per-record arrays
-    const size_t rec_cap = (size_t)n_rec_total + 2;
-    // Arrays whose per-record values depend on the sub-block (title bits, cached fields, candidate values, payload bit
-    // counts) are indexed by record + sub-block ordinal: a sub-block takes its second record whatever its size
-    // (phyNGSC.cpp:295-300), so when a rank's last window holds a single record before the overlap, its second record is
-    // also the first record of the next rank - one record, two owners, two different sets of values.
-    const size_t slot_cap = rec_cap + (size_t)n_ranks * max_cuts;
-    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
-    Carver cr2;
-    size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * slot_cap), o_doff = cr2.take(4 * slot_cap);
-    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * slot_cap);
-    size_t o_tsep = cr2.take(8 * rec_cap), o_apos = cr2.take(8 * rec_cap);
-    rc = ensure(c, c->recs2, cr2.off);
-    if (rc) return rc;
-    uint8_t *rb2 = (uint8_t *)c->recs2.p;
-    const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
-    const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
-    const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
     const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
     const Cut *h_cuts = (const Cut *)(hp + o_cuts);
     std::vector<Cut> cuts;
@@ -377,6 +359,27 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     const uint32_t S = (uint32_t)cuts.size();
     if (!S) return NGSC_ERR_FORMAT;
+    // per-record arrays
+    const size_t rec_cap = (size_t)n_rec_total + 2;
+    // Arrays whose per-record values depend on the sub-block (title bits, cached fields, candidate values, payload bit
+    // counts) have one slot per (sub-block, record): a sub-block takes its second record whatever its size
+    // (phyNGSC.cpp:295-300), so a rank whose last window holds a single record before the overlap also encodes the first
+    // record of the next rank, and with rank regions smaller than a record consecutive ranks can even start on the same
+    // record.  Slots are dealt out sub-block after sub-block (SbState::slot_bias).
+    size_t slot_cap = 2;
+    for (auto &ct : cuts) slot_cap += ct.n_rec;
+    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
+    Carver cr2;
+    size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * slot_cap), o_doff = cr2.take(4 * slot_cap);
+    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * slot_cap);
+    const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
+    const uint32_t tsep_words = max_title <= 64 ? 1u : 2u;
+    size_t o_tsep = cr2.take(8 * tsep_words * rec_cap), o_apos = cr2.take(8 * rec_cap);
+    rc = ensure(c, c->recs2, cr2.off);
+    if (rc) return rc;
+    uint8_t *rb2 = (uint8_t *)c->recs2.p;
+    const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
+    const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
     const uint32_t qrows = max_q + 1;
     uint32_t max_rec = 0;
     for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);
@@ -445,6 +448,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.grp_lo = (uint32_t *)(pb + p_grplo);
     A.tbits = (uint32_t *)(rb2 + o_tbits);
     A.tsep = (uint64_t *)(rb2 + o_tsep);
+    A.tsep_words = tsep_words;
     A.apos = (AmbPos *)(rb2 + o_apos);
     A.gflags = (uint32_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
@@ -491,9 +495,11 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     SbState *h_sb = (SbState *)hp;
     uint32_t *h_grp = (uint32_t *)(hp + sb_bytes);
     memset(h_sb, 0, sb_bytes);
-    uint32_t gacc = 0;
+    uint32_t gacc = 0, slot_next = 0;
     for (uint32_t s = 0; s < S; ++s) {
         h_sb[s].rec_lo = cuts[s].rec_lo;
+        h_sb[s].slot_bias = slot_next - cuts[s].rec_lo;   // (mod 2^32)
+        slot_next += cuts[s].n_rec;
         h_sb[s].n_rec = cuts[s].n_rec;
         h_sb[s].rank = cuts[s].rank;
         h_grp[s] = gacc;
@@ -527,7 +533,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     };
     // titles of at most 64 bytes take the word-parallel kernels (NGSC_TITLE_PATH=reg forces the byte-serial ones)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
-    const bool t_swar = max_title <= 64 && !(tp_env && !strcmp(tp_env, "reg"));
+    const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_rec0_fields"); launch_rec0_fields(st2, A); }
     if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec); }

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t 
     }
     if (lane == 0) {
         if (at < 0 || nl < 0) { atomicMin(err, (int32_t)ERR_FORMAT); first_abs[blockIdx.x] = 0; return; }
-        uint64_t res = (nl + 1 < (int64_t)len && buf[nl + 1] == '@') ? (uint64_t)(nl + 1) : (uint64_t)at;
+        // (the look at the byte behind the newline stays inside the rank's first window, like the two scans: phyNGSC.cpp:131-156)
+        uint64_t res = (nl + 1 < (int64_t)limit && buf[nl + 1] == '@') ? (uint64_t)(nl + 1) : (uint64_t)at;
         first_abs[blockIdx.x] = res + buf_off;
         if (blockIdx.x == 0) *start_rel = (uint32_t)res;
     }

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_measure_sq(Arena A, uint32_t lds
     __shared__ uint8_t s_qcode[256];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     const uint32_t r_begin = blockIdx.x * PK_REC_PER_WG;
     if (r_begin >= n) return;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_measure_sq(Arena A, uint32_t lds
         }
         qb = wave_sum(qb);
         db = wave_sum(db);
-        if (lane == 0) { A.qoff[g + s] = qb; A.doff[g + s] = db; }
+        if (lane == 0) { A.qoff[g + slot_bias] = qb; A.doff[g + slot_bias] = db; }
     }
 }
 
@@ -137,8 +138,9 @@ __global__ __launch_bounds__(1024) void k_scan_sb(Arena A)
     __shared__ uint32_t s_wave[17];
     const uint32_t s = blockIdx.x;
     SbState &sb = A.sb[s];
-    uint32_t tq = wg_scan_excl(A.qoff + sb.rec_lo + s, sb.n_rec, s_wave);
-    uint32_t td = wg_scan_excl(A.doff + sb.rec_lo + s, sb.n_rec, s_wave);
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
+    uint32_t tq = wg_scan_excl(A.qoff + sb.rec_lo + slot_bias, sb.n_rec, s_wave);
+    uint32_t td = wg_scan_excl(A.doff + sb.rec_lo + slot_bias, sb.n_rec, s_wave);
     uint32_t tg = wg_scan_excl(A.goff + A.grp_lo[s], (sb.n_rec + GROUP - 1) / GROUP, s_wave);
     if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
 }
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_sq(Arena A, uint32_t lds_en
     __shared__ uint8_t s_qcode[256];
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     const uint32_t r_begin = blockIdx.x * PK_REC_PER_WG;
     if (r_begin >= n) return;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_sq(Arena A, uint32_t lds_en
         const uint32_t t = A.te[g], e = A.se[g];
         const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
         const bool xfer = A.slen[g] >> 31;
-        uint64_t qpos = qbase + A.qoff[g + s], dpos = dbase + A.doff[g + s];
+        uint64_t qpos = qbase + A.qoff[g + slot_bias], dpos = dbase + A.doff[g + slot_bias];
         for (uint32_t base = 0; base < L; base += 64) {
             uint32_t j = base + lane;
             uint32_t qe = 0, de = 0;

@@ -11,6 +11,7 @@
 //
 // All of it is integer, branchy, HBM/LDS-bound work: no MFMA.
 #include "ngsc_kernels.h"
+#include "ngsc_swar.h"
 
 namespace ngsc {
 
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
     const uint32_t wg_first = blockIdx.x * TS_OWNED * TH_BATCHES;
     if (wg_first >= n) return;
@@ -258,18 +260,21 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
         if (!walk) {
             // every needed field is numeric and k_title_stats_swar kept its values: no need to touch the titles
             for (uint32_t f = 0; f < nf; ++f)
-                if ((need >> f) & 1) s_val[s_k[f]][tid] = (valid && use_tv) ? A.tv[(size_t)fd[f].cand * A.tw_stride + g + s] : 0u;
+                if ((need >> f) & 1) s_val[s_k[f]][tid] = (valid && use_tv) ? A.tv[(size_t)fd[f].cand * A.tw_stride + g + slot_bias] : 0u;
         }
         if (walk || !use_tv) {
-            const unsigned long long sepmask = (use_tv && valid) ? A.tsep[g] : 0ull;
+            uint64_t sepmask[2] = {0, 0};   // (two-word form for both title widths: this kernel is not the bottleneck)
+            if (use_tv && valid) {
+                sepmask[0] = A.tsep[(size_t)g * A.tsep_words];
+                if (A.tsep_words == 2) sepmask[1] = A.tsep[(size_t)g * 2 + 1];
+            }
             uint32_t pc = ls;
             // lockstep over fields so that the lanes of a wave look at the same field together
             for (uint32_t f = 0; f < nf; ++f) {
                 uint32_t ec;
                 if (use_tv) {   // field boundaries from the separator mask of k_title_stats_swar
                     const uint32_t rel = pc - ls;
-                    const unsigned long long rem = rel < 64 ? sepmask >> rel : 0ull;
-                    ec = pc + (rem ? (uint32_t)__builtin_ctzll(rem) : 0u);
+                    ec = pc + t_next_set<2>(sepmask, rel);
                 } else {
                     ec = field_end(buf, pc);
                 }
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
                 if ((need >> f) & 1) {
                     if (d.kind == KIND_NUM) {
                         uint32_t v = 0;
-                        if (use_tv) v = valid ? A.tv[(size_t)d.cand * A.tw_stride + g + s] : 0u;
+                        if (use_tv) v = valid ? A.tv[(size_t)d.cand * A.tw_stride + g + slot_bias] : 0u;
                         else { bool o; parse_num(buf, pc, ec, v, o); }
                         const uint32_t k = s_k[f];
                         if (k != 0xff) {

@@ -84,7 +84,7 @@ __device__ __forceinline__ void for_each_title_byte(const uint8_t *buf, uint32_t
 }
 
 // =========================================================================================================
-// Word-parallel title path for jobs whose titles are all <= 64 bytes (TS_MAX_TITLE).
+// Word-parallel title path for jobs whose titles are all <= 128 bytes (W = 1 or 2 mask words of 64 title bytes).
 //
 // The byte-serial parsers above cost ~100 VALU instructions per title byte and wave (PMC: 6.4 k VALU per
 // wave, VALU-bound).  Here a lane holds its whole title in 16 dwords, classifies four bytes per step with
@@ -93,7 +93,7 @@ __device__ __forceinline__ void for_each_title_byte(const uint8_t *buf, uint32_t
 // zeros of the shifted separator mask, field bytes = funnel-shifted dwords of the lane's own LDS column,
 // equality / Hamming mask = XOR against record 0's field words, numeric value = SWAR 8-digit parse.
 // Same statistics, same s_stat layout and same results as k_title_stats_reg.
-constexpr uint32_t TS_ROWS = 17;   // 16 title dwords + one zero row for reads past the title
+template <uint32_t W> constexpr uint32_t TS_ROWS = 16 * W + 1;   // title dwords + one zero row for reads past the title
 
 // Four bytes at once: per byte, bits 0-3 = separator class (non-zero <=> one of " ._,=:/-#\n"), bit 4 = digit.
 // class(byte) = LUT_lo[low nibble] & LUT_hi[high nibble]; each LUT is a v_perm_b32 byte table (8 entries per
@@ -345,12 +345,13 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
 // 256 records (8 groups of 32) per workgroup.  SWAR: titles <= 64 bytes whose separator masks k_title_stats_swar
 // left in A.tsep - the fields are found with count-trailing-zeros steps and only the non-constant numeric ones
 // are read (eight bytes, unaligned) and parsed; otherwise the title is parsed byte by byte.
-template <bool SWAR>
+template <bool SWAR, uint32_t W>
 __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
     const uint32_t t0 = blockIdx.x * TT_THREADS;
     if (t0 >= n) return;
@@ -377,14 +378,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     if (ncf <= NCF_CAP) {
         // one pass over the title: cache the non-constant fields of this record
         if constexpr (SWAR) {
-            const uint64_t sepmask = valid ? A.tsep[g] : 0;
+            uint64_t sepmask[W];
+#pragma unroll
+            for (uint32_t k = 0; k < W; ++k) sepmask[k] = valid ? A.tsep[(size_t)g * W + k] : 0;
             uint32_t pos = 0;
             for (uint32_t f = 0; f < nf; ++f) {
-                const uint64_t rem = pos < 64 ? sepmask >> pos : 0;
-                const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
+                const uint32_t len = t_next_set<W>(sepmask, pos);
                 const uint32_t kind = s_fd[f].kind;
                 if (kind == KIND_NUM) {   // parsed once, by k_title_stats_swar
-                    s_w[s_fd[f].kf][tid] = valid ? A.tv[(size_t)s_fd[f].cand * A.tw_stride + g + s] : 0u;
+                    s_w[s_fd[f].kf][tid] = valid ? A.tv[(size_t)s_fd[f].cand * A.tw_stride + g + slot_bias] : 0u;
                 } else if (kind == KIND_TEXT) {
                     s_w[s_fd[f].kf][tid] = pos | (len << 16);
                 }
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
             const uint32_t ff = s_kf_field[kf];
             const uint32_t wc = s_w[kf][tid];
             C.cur[kf] = wc;
-            A.tw[(size_t)kf * A.tw_stride + g + s] = wc;
+            A.tw[(size_t)kf * A.tw_stride + g + slot_bias] = wc;
             if (gi) {
                 const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
                 C.prev[kf] = wp;
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
             bits = (uint32_t)bc.bits;
         }
     }
-    if (valid) A.tbits[g + s] = bits;
+    if (valid) A.tbits[g + slot_bias] = bits;
     const uint32_t gbits = t_g32_sum(bits);
     if (valid && gi == 0) {
         const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf, ncf = sb.ncf;
     const uint32_t t0 = blockIdx.x * TT_THREADS;
     if (t0 >= n) return;
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     const bool valid = (uint32_t)tid < nt;
     const uint32_t gi = tid & 31, gstart = tid - gi;
     const uint32_t g = valid ? i0 + tid : i0;
-    const uint32_t bits = valid ? A.tbits[g + s] : 0;
+    const uint32_t bits = valid ? A.tbits[g + slot_bias] : 0;
     uint32_t incl = bits;  // inclusive prefix inside the 32-record group
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {
@@ -560,8 +563,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
             for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
                 C.cur[kf] = C.prev[kf] = 0;
                 if (kf >= ncf) continue;
-                C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + g + s];
-                if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + g + s - 1];
+                C.cur[kf] = A.tw[(size_t)kf * A.tw_stride + g + slot_bias];
+                if (gi) C.prev[kf] = A.tw[(size_t)kf * A.tw_stride + g + slot_bias - 1];
             }
             title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
         } else {
@@ -580,14 +583,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     }
 }
 
-// Title of one record as 16 dwords (bytes past the title are other lines' bytes: every use masks by length),
+// Title of one record as 16 * W dwords (bytes past the title are other lines' bytes: every use masks by length),
 // written to the lane's LDS column, plus its separator / digit masks.
+template <uint32_t W>
 __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
-                                             uint64_t &sepmask, uint64_t &digmask)
+                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W])
 {
-    uint32_t seplo = 0, sephi = 0, diglo = 0, dighi = 0;
+    uint32_t sp32[2 * W], dg32[2 * W];
 #pragma unroll
-    for (uint32_t m = 0; m < 4; ++m) {
+    for (uint32_t k = 0; k < 2 * W; ++k) sp32[k] = dg32[k] = 0;
+#pragma unroll
+    for (uint32_t m = 0; m < 4 * W; ++m) {
         uint4 q = make_uint4(0, 0, 0, 0);
         if (__any(16 * m < tlen)) {
             if (16 * m < tlen) q = load16_unaligned(A.buf, ls + 16 * m, A.buf_len);
@@ -598,8 +604,8 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
                 const uint32_t sp = t_movemask((((cls & 0x0F0F0F0Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u);
                 const uint32_t dg = t_movemask((cls >> 4) & 0x01010101u);
                 const uint32_t sh = 4 * ((4 * m + j) & 7);
-                if (m < 2) { seplo |= sp << sh; diglo |= dg << sh; }
-                else { sephi |= sp << sh; dighi |= dg << sh; }
+                sp32[m >> 1] |= sp << sh;
+                dg32[m >> 1] |= dg << sh;
             }
         }
         s_w[4 * m + 0][tid] = q.x;
@@ -607,26 +613,33 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
         s_w[4 * m + 2][tid] = q.z;
         s_w[4 * m + 3][tid] = q.w;
     }
-    s_w[16][tid] = 0;
-    const uint64_t keep = t_lowbits(tlen);
-    sepmask = (((uint64_t)sephi << 32) | seplo) & keep;
-    digmask = (((uint64_t)dighi << 32) | diglo) & keep;
+    s_w[16 * W][tid] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < W; ++k) {
+        const uint64_t keep = t_lowbits(tlen > 64 * k ? tlen - 64 * k : 0);
+        sepmask[k] = (((uint64_t)sp32[2 * k + 1] << 32) | sp32[2 * k]) & keep;
+        digmask[k] = (((uint64_t)dg32[2 * k + 1] << 32) | dg32[2 * k]) & keep;
+    }
 }
 
 // eight bytes of the lane's title starting at byte position pos (rows past the title read the zero row)
+template <uint32_t W>
 __device__ __forceinline__ void t_field8(uint32_t (*s_w)[TT_THREADS], int tid, uint32_t pos, uint32_t &w0, uint32_t &w1)
 {
+    constexpr uint32_t Z = 16 * W;   // the zero row
     const uint32_t r = pos >> 2, sh = (pos & 3) * 8;
-    const uint32_t x0 = s_w[r < 16 ? r : 16][tid], x1 = s_w[r + 1 < 16 ? r + 1 : 16][tid], x2 = s_w[r + 2 < 16 ? r + 2 : 16][tid];
+    const uint32_t x0 = s_w[r < Z ? r : Z][tid], x1 = s_w[r + 1 < Z ? r + 1 : Z][tid], x2 = s_w[r + 2 < Z ? r + 2 : Z][tid];
     w0 = __builtin_amdgcn_alignbit(x1, x0, sh);
     w1 = __builtin_amdgcn_alignbit(x2, x1, sh);
 }
 
+template <uint32_t W>
 __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
+    const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
     constexpr uint32_t OWNED = TT_THREADS - 1;
     if (blockIdx.x * OWNED >= n) return;
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     // boundaries of the workgroup through these (last lane's value / first lane's value, per numeric candidate)
     __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
     __shared__ uint32_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
-    __shared__ uint32_t s_w[TS_ROWS][TT_THREADS];
+    __shared__ uint32_t s_w[TS_ROWS<W>][TT_THREADS];
     __shared__ Rec0Tab s_r0;
 
     for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
@@ -654,23 +667,27 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     const uint32_t ls = A.ls[g], te = A.te[g];
     const uint32_t tlen = valid ? te - ls + 1 : 0;            // title bytes including the closing newline
 
-    uint64_t sepmask, digmask;
-    t_load_title(A, ls, tlen, s_w, tid, sepmask, digmask);
-    if (owned) A.tsep[g] = sepmask;
-    if (valid && (uint32_t)__popcll(sepmask) != s_r0.nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    uint64_t sepmask[W], digmask[W];
+    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask);
+    uint32_t nsep = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < W; ++k) {
+        if (owned) A.tsep[(size_t)g * W + k] = sepmask[k];
+        nsep += (uint32_t)__popcll(sepmask[k]);
+    }
+    if (valid && nsep != s_r0.nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
 
     uint32_t pos = 0, nummask = 0;
     for (uint32_t f = 0; f < nf0; ++f) {
         const uint32_t len0 = s_r0.len[f], kk = s_r0.kmap[f], wo = s_r0.woff[f];
-        const uint64_t rem = pos < 64 ? sepmask >> pos : 0;
-        const uint32_t len = rem ? (uint32_t)__builtin_ctzll(rem) : 0;
+        const uint32_t len = t_next_set<W>(sepmask, pos);
         const uint32_t minlen = len < len0 ? len : len0;
 
         // compare with record 0's field, eight bytes per step
         uint32_t w0 = 0, w1 = 0, diff = 0, c8 = 0;
         do {
             uint32_t x0, x1;
-            t_field8(s_w, tid, pos + 8 * c8, x0, x1);
+            t_field8<W>(s_w, tid, pos + 8 * c8, x0, x1);
             const uint32_t left = len > 8 * c8 ? len - 8 * c8 : 0;
             const uint64_t km = t_lowbytes(left);
             x0 &= (uint32_t)km;
@@ -698,11 +715,10 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             isn = true;
             v = s_r0.val0[f];
             ovf = s_r0.ovf0[f] != 0;
-            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + s] = v;
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;
             nummask |= 1u << f;
         } else if (kk != 0xff) {
-            const uint64_t dm = pos < 64 ? digmask >> pos : 0, lm = t_lowbits(len);
-            isn = (dm & lm) == lm && len > 0 && !(len > 1 && (w0 & 0xffu) == '0');
+            isn = len > 0 && t_all_set<W>(digmask, pos, len) && !(len > 1 && (w0 & 0xffu) == '0');
             v = t_parse8(w0, w1, len);
             if (__any(isn && len > 8)) {
                 if (isn && len > 8) {   // nine digits and more: digit by digit with the overflow test
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                     }
                 }
             }
-            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + s] = v;   // k_title_measure_reg<true> and k_title_hist read it back
+            if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;   // k_title_measure_reg<true> and k_title_hist read it back
             nummask |= (uint32_t)isn << f;
         }
         if (kk < NUM_CAND_CAP) {   // (uniform) delta to the previous record, both numeric
@@ -795,14 +811,16 @@ void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     dim3 grid((max_rec + TT_THREADS - 2) / (TT_THREADS - 1), A.n_sb);
-    hipLaunchKernelGGL(k_title_stats_swar, grid, dim3(TT_THREADS), 0, st, A);
+    if (A.tsep_words == 2) hipLaunchKernelGGL(k_title_stats_swar<2>, grid, dim3(TT_THREADS), 0, st, A);
+    else hipLaunchKernelGGL(k_title_stats_swar<1>, grid, dim3(TT_THREADS), 0, st, A);
 }
 
 void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar)
 {
     dim3 grid((max_rec + TT_THREADS - 1) / TT_THREADS, A.n_sb);
-    if (swar) hipLaunchKernelGGL(k_title_measure_reg<true>, grid, dim3(TT_THREADS), 0, st, A);
-    else hipLaunchKernelGGL(k_title_measure_reg<false>, grid, dim3(TT_THREADS), 0, st, A);
+    if (swar && A.tsep_words == 2) hipLaunchKernelGGL((k_title_measure_reg<true, 2>), grid, dim3(TT_THREADS), 0, st, A);
+    else if (swar) hipLaunchKernelGGL((k_title_measure_reg<true, 1>), grid, dim3(TT_THREADS), 0, st, A);
+    else hipLaunchKernelGGL((k_title_measure_reg<false, 1>), grid, dim3(TT_THREADS), 0, st, A);
 }
 
 void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec)

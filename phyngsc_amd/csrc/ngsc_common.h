@@ -210,7 +210,9 @@ struct SbState {        // per sub-block scalars
     uint32_t info_len, title_len, qual_len, dna_len;
     uint32_t total;
     uint32_t n_bases;               // sum of sequence lengths (= quality bytes) of the sub-block
-    uint32_t ncf, pad1;             // number of non-constant title fields
+    uint32_t ncf;                   // number of non-constant title fields
+    uint32_t slot_bias;             // record index + slot_bias = the record's slot in the arrays that depend on the sub-block
+                                    // (slot of the sub-block's first record = records of all earlier sub-blocks; mod 2^32)
     uint64_t out_off;               // byte offset of the sub-block in the output buffer
     uint8_t symbols[256];
     uint8_t qualities[256];
@@ -250,7 +252,8 @@ struct Arena {
     uint32_t *gflags;       // per title group: flag bits (tiled path)
     uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
     uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
-    uint64_t *tsep;         // per record: separator mask of the title (word-parallel path, titles <= 64 B)
+    uint64_t *tsep;         // per record: separator mask of the title, tsep_words words of 64 title bytes (word-parallel path)
+    uint32_t tsep_words;    // 1: titles <= 64 B, 2: titles <= 128 B
     uint32_t *tv;           // [NUM_CAND_CAP][tw_stride]: value of every numeric candidate field per record (word-parallel path)
     uint32_t *tw;           // [NCF_CAP][tw_stride]: cached non-constant title fields per record (tiled path)
     uint32_t tw_stride;

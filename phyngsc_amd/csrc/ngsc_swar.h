@@ -47,6 +47,46 @@ __device__ __forceinline__ uint64_t t_lowbits(uint32_t n)    // n lowest bits, n
     return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
 
+// ---- masks with one bit per title byte, W 64-bit words (titles of up to 64 * W bytes) ----
+// the 64 mask bits that start at bit pos
+template <uint32_t W>
+__device__ __forceinline__ uint64_t t_window(const uint64_t (&m)[W], uint32_t pos)
+{
+    if constexpr (W == 1) {
+        return pos < 64 ? m[0] >> pos : 0ull;
+    } else {
+        if (pos >= 128) return 0ull;
+        if (pos >= 64) return m[1] >> (pos - 64);
+        return (m[0] >> pos) | (pos ? m[1] << (64 - pos) : 0ull);
+    }
+}
+// distance from bit pos to the next set bit at or behind it (0 if there is none: a title always ends in one)
+template <uint32_t W>
+__device__ __forceinline__ uint32_t t_next_set(const uint64_t (&m)[W], uint32_t pos)
+{
+    const uint64_t lo = t_window<W>(m, pos);
+    if (lo) return (uint32_t)__builtin_ctzll(lo);
+    if constexpr (W > 1) {
+        const uint64_t hi = t_window<W>(m, pos + 64);
+        if (hi) return 64u + (uint32_t)__builtin_ctzll(hi);
+    }
+    return 0u;
+}
+// are the len bits from bit pos all set?
+template <uint32_t W>
+__device__ __forceinline__ bool t_all_set(const uint64_t (&m)[W], uint32_t pos, uint32_t len)
+{
+    const uint64_t l0 = t_lowbits(len < 64 ? len : 64);
+    bool ok = (t_window<W>(m, pos) & l0) == l0;
+    if constexpr (W > 1) {
+        if (len > 64) {
+            const uint64_t l1 = t_lowbits(len - 64);
+            ok = ok && (t_window<W>(m, pos + 64) & l1) == l1;
+        }
+    }
+    return ok;
+}
+
 // 0xFF in the n lowest bytes of a dword, n clamped to 0..4
 __device__ __forceinline__ uint32_t t_lowbytes32(int32_t n)
 {

@@ -10,8 +10,8 @@ def _fq(recs):
 def build():
     rnd = random.Random(7)
     cases = {}
-    # title lines of 63..66 bytes: the word-parallel title kernels take titles of up to 64 bytes
-    for tl in (63, 64, 65, 66):
+    # title lines around 64 and 128 bytes: the word-parallel title kernels take titles of up to 64 / 128 bytes
+    for tl in (63, 64, 65, 66, 127, 128, 129, 130):      # 64 / 128: one / two mask words, beyond: the byte-serial kernels
         recs = []
         for i in range(4000):
             t = b"r%d " % (i * 7919 % 100000)
@@ -84,4 +84,19 @@ def build():
     recs = [(b"long.%d" % i, bytes(rnd.choice(b"ACGTN") for _ in range(3000 + i % 11)),
              bytes(rnd.choice(b"#5?IJ") for _ in range(3000 + i % 11))) for i in range(300)]
     cases["reads_3000bp"] = (_fq(recs), 2)
+    # titles between 65 and 128 bytes with a field longer than 64 bytes, digits across the word boundary of the masks,
+    # and numeric fields that start in the second mask word
+    recs = []
+    for i in range(4000):
+        t = b"X" * (60 + i % 9) + b" " + b"%d" % (10 ** 8 + i * 7919) + b":" + b"y" * (3 + i % 3) + b"_" + b"%d" % (i % 1000)
+        recs.append((t, b"ACGT" * 9, bytes(rnd.choice(b"ABCDEFGHI") for _ in range(36))))
+    cases["title_two_mask_words"] = (_fq(recs), 2)
+    recs = []
+    for i in range(3000):
+        t = b"run" + b"Z" * (70 + i % 5) + b"/" + b"%d" % i        # one text field longer than 64 bytes
+        recs.append((t, b"ACGT" * 9, bytes(rnd.choice(b"ABCDEFGHI") for _ in range(36))))
+    cases["title_field_longer_than_64"] = (_fq(recs), 3)
+    # the smallest records there are: '@' alone as the title and an empty read (6 bytes), next to one-base reads
+    recs = [(b"", b"", b"") if i % 3 else (b"", b"A", b"I") for i in range(9000)]
+    cases["six_byte_records"] = (_fq(recs), 2)
     return cases

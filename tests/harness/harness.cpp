@@ -233,11 +233,12 @@ int64_t h_plan_file(const uint8_t *buf, uint64_t file_size, uint32_t P, uint32_t
         if (r) {
             // phyNGSC.cpp:131-156
             uint64_t i = (uint64_t)g.wr_start;
-            while (i < file_size && buf[i] != '@') ++i;
+            const uint64_t lim = std::min<uint64_t>(file_size, (uint64_t)g.wr_start + (uint64_t)g.bsize);   // the rank's first window
+            while (i < lim && buf[i] != '@') ++i;
             uint64_t at = i;
-            while (i < file_size && buf[i] != '\n') ++i;
-            if (i >= file_size) return ERR_FORMAT;
-            first = (i + 1 < file_size && buf[i + 1] == '@') ? i + 1 : at;
+            while (i < lim && buf[i] != '\n') ++i;
+            if (i >= lim) return ERR_FORMAT;
+            first = (i + 1 < lim && buf[i + 1] == '@') ? i + 1 : at;
         }
         std::vector<Cut> cuts(4096);
         RankPlan pl;

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--reference", action="store_true",
                     help="build container only: compare the oracle with oracle/_ref/phyNGSC (mpiexec -np P) instead")
     ap.add_argument("--seeds", type=int, default=10 ** 9)
+    ap.add_argument("--tiny", action="store_true",
+                    help="files of 20..200 KB split over 8..24 ranks: rank regions of a record's size, records owned by two ranks")
     ap.add_argument("--driver", action="store_true",
                     help="also push every accepted file through ngsc_compress_file_multi (two contexts, small jobs)")
     a = ap.parse_args()
@@ -66,6 +68,9 @@ def main():
     while time.time() < t_end and seed < a.first_seed + a.seeds:
         rnd = random.Random(seed)
         d = draw_dialect(rnd, a.max_mb)
+        if a.tiny:
+            d["bytes"] = rnd.choice([20_000, 60_000, 200_000])
+            d["P"] = rnd.choice([8, 12, 16, 20, 24])
         data = build_file(d, seed)
         total += len(data)
         max_rec = max(len(x) for x in data.split(b"\n@")) + 2
@@ -106,6 +111,7 @@ def main():
                 if not same:
                     verdict = "reference and oracle differ: " + msg
         elif eng is None:
+            n_file = data.count(b"\n+\n") if o_rc == 0 else 0       # (an upper bound is enough to spot duplicates)
             if o_rc == 0 and not d["vary_sep"]:
                 try:
                     back = orc.decompress(ref)
@@ -113,7 +119,9 @@ def main():
                     back = None
                     verdict = f"oracle decoder rc {e.rc}"
                 whole = data if d["tail"] != "ok" or d["final_newline"] else data + b"\n"
-                if back is not None and d["tail"] == "ok" and back != data:
+                if back is not None and back.count(b"\n+\n") > n_file:
+                    pass      # a record owned by two ranks is stored twice (phyNGSC.cpp:295-300): no round trip to expect
+                elif back is not None and d["tail"] == "ok" and back != data:
                     verdict = "oracle round trip differs"
                 elif back is not None and not whole.startswith(back[:-1]):    # damaged tail: the records before it
                     verdict = "oracle round trip is not a prefix of the input"

@@ -21,7 +21,7 @@ res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per l
                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads) - an upper estimate for byte-granular access"}
 for k in f:
     fk = f[k].get("FETCH_SIZE", 0.0); wk = w.get(k, {}).get("WRITE_SIZE", 0.0)
-    res[k.replace("k_title_measure_reg<true>", "k_title_measure_swar").replace("<false>", "")] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+    res[k.replace("k_title_measure_reg<true, 1>", "k_title_measure_swar").replace("k_title_measure_reg<true, 2>", "k_title_measure_swar").replace("<false, 1>", "").replace("<false>", "").replace("<true>", "").replace("<1>", "").replace("<2>", "")] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
               "launches_sampled": f[k].get("launches")}
 json.dump(res, open(f"{out}/traffic_{tag}.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] if isinstance(kv[1], dict) else 0)):
