@@ -145,18 +145,24 @@ __global__ __launch_bounds__(1024) void k_scan_sb(Arena A)
     if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
 }
 
-// One thread per sub-block: stream sizes.  qrow_off[s][row] = byte offset of tree `row` inside the quality header.
+// One wave per sub-block: stream sizes.  qrow_off[s][row] = byte offset of tree `row` inside the quality header (a
+// prefix sum over up to max_q + 1 tree blobs: as a serial loop of one thread it was 150 dependent loads for 150-base reads).
 __global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
 {
     if (*A.err) return;
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
     if (s >= A.n_sb) return;
     SbState &sb = A.sb[s];
+    const uint32_t rows = sb.max_q + 1;
     uint32_t off = sb.nqual;  // alphabet bytes (tasks.cpp:577-581)
-    for (uint32_t row = 0; row <= sb.max_q; ++row) {
-        qrow_off[(size_t)s * A.qrows + row] = off;
-        off += 4 + A.qblob_len[(size_t)s * A.qrows + row];
+    for (uint32_t base = 0; base < rows; base += 64) {
+        const uint32_t row = base + lane;
+        const uint32_t v = row < rows ? 4 + A.qblob_len[(size_t)s * A.qrows + row] : 0u;
+        const uint32_t incl = wave_scan_incl_u32(v);
+        if (row < rows) qrow_off[(size_t)s * A.qrows + row] = off + incl - v;
+        off += (uint32_t)__shfl((int)incl, 63);
     }
+    if (lane) return;
     sb.qual_hdr = off;
     sb.qual_len = off + (sb.qbits + 7) / 8;
     uint32_t dh = sb.nsym;
@@ -171,17 +177,29 @@ __global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
     sb.total = sb.info_len + sb.title_len + sb.qual_len + sb.dna_len;
 }
 
-__global__ void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
+// One wave: exclusive prefix sum of the sub-block sizes = their offsets in the output.
+__global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
 {
     if (*A.err) return;
-    if (blockIdx.x || threadIdx.x) return;
+    if (blockIdx.x) return;
+    const uint32_t lane = threadIdx.x;
     uint64_t off = 0;
-    for (uint32_t s = 0; s < A.n_sb; ++s) {
-        A.sb[s].out_off = off;
-        off += A.sb[s].total;
+    for (uint32_t base = 0; base < A.n_sb; base += 64) {
+        const uint32_t s = base + lane;
+        const uint64_t v = s < A.n_sb ? A.sb[s].total : 0ull;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t o = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += o;
+        }
+        if (s < A.n_sb) A.sb[s].out_off = off + incl - v;
+        off += __shfl(incl, 63);
     }
-    *total_out = off;
-    if (off > out_cap) atomicMin(A.err, (int32_t)ERR_CAPACITY);
+    if (lane == 0) {
+        *total_out = off;
+        if (off > out_cap) atomicMin(A.err, (int32_t)ERR_CAPACITY);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -363,7 +381,7 @@ void launch_scan_sb(hipStream_t st, const Arena &A)
 
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out)
 {
-    hipLaunchKernelGGL(k_sizes, dim3((A.n_sb + 63) / 64), dim3(64), 0, st, A, qrow_off);
+    hipLaunchKernelGGL(k_sizes, dim3(A.n_sb), dim3(64), 0, st, A, qrow_off);
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, st, A, out_cap, total_out);
 }
 
