@@ -14,14 +14,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
     find $out/pmc_${tag}_$c -name "*.csv" -size +8M -delete
 done
 python3 - "$out" "$tag" <<'PY'
-import json, sys
+import json, re, sys
+def norm(k):   # template arguments off; the word-parallel instance of the title measure kernel has its own name
+    k = re.sub(r'k_title_measure_reg<true, \d+u?>', 'k_title_measure_swar', k)
+    return re.sub(r'<[^>]*>', '', k)
 out, tag = sys.argv[1], sys.argv[2]
 f = json.load(open(f"{out}/pmc_{tag}_FETCH_SIZE.json")); w = json.load(open(f"{out}/pmc_{tag}_WRITE_SIZE.json"))
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, bench.py 1 GB cfg2 workload; FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads) - an upper estimate for byte-granular access"}
 for k in f:
     fk = f[k].get("FETCH_SIZE", 0.0); wk = w.get(k, {}).get("WRITE_SIZE", 0.0)
-    res[k.replace("k_title_measure_reg<true, 1>", "k_title_measure_swar").replace("k_title_measure_reg<true, 2>", "k_title_measure_swar").replace("<false, 1>", "").replace("<false>", "").replace("<true>", "").replace("<1>", "").replace("<2>", "")] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+    res[norm(k)] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
               "launches_sampled": f[k].get("launches")}
 json.dump(res, open(f"{out}/traffic_{tag}.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["hbm_bytes_per_launch"] if isinstance(kv[1], dict) else 0)):
