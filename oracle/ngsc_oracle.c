@@ -377,11 +377,9 @@ static int title_stream(const titles_t *t, bw_t *w)
                 uint32_t s, e;
                 field_span(t, r, f, &s, &e);
                 uint64_t v = 0;
-                int big = 0;
-                for (uint32_t p = s; p < e; ++p) {
+                for (uint32_t p = s; p < e; ++p)
                     v = (v * 10 + (uint64_t)(buf[p] - '0')) & 0xffffffffull; /* uint32 arithmetic, utils.h:117-125 */
-                    if (v > 0x7fffffffull) big = 1;
-                }
+                const int big = v > 0x7fffffffull; /* the value the reference goes on with is a negative int32 */
                 /* a constant field is stored once as text and its (wrapped) value is never used; a varying
                    one with a value the int32 cannot hold sends the reference into negative ranges */
                 if (big && !fd->is_const) { rc = NGSC_O_ERANGE; break; }

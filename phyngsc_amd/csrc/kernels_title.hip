@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
     const uint32_t g = valid ? rec_lo + (uint32_t)i : rec_lo;
     const uint32_t ls = A.ls[g], te = A.te[g];
 
-    // parser state in integer registers; st bit0: non-digit seen, bit1: leading zero, bit2: value > INT32_MAX,
+    // parser state in integer registers; st bit0: non-digit seen, bit1: leading zero,
     // bit3: differs from record 0
     uint32_t f = 0, k = 0, nummask = 0, v = 0, stf = 0;
     uint32_t f0len = nf0 ? s_r0.len[0] : 0, f0start = nf0 ? s_r0.start[0] : 0;
@@ -218,12 +218,11 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
         const uint32_t body = act & (sepb ^ 1u);
         const uint32_t d = c - '0';
         const uint32_t dig = d <= 9 ? 1u : 0u;
-        const uint32_t ovn = (v > 214748364u || (v == 214748364u && d > 7)) ? 1u : 0u;
         const uint32_t ld0 = (k == 0 && d == 0) ? 1u : 0u;
         const uint32_t inr = body & (k < f0len ? 1u : 0u);          // f0len == 0 once f >= nf0
         const uint32_t c0 = s_r0.title[f0start + (inr ? k : 0)];
         const uint32_t nd = inr & (c != c0 ? 1u : 0u);
-        stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | ((body & dig & ovn) << 2) | (nd << 3);
+        stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | (nd << 3);
         v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num (utils.h:117-125)
         if (__any(nd)) {
             if (nd && owned && k < 256) t_lds_or(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
                                        a7 = st[7];
                         const uint32_t bv = bias((int32_t)v);
                         const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3,
-                                   n4 = !isn && !a4, n5 = isn && (stf & 4) && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
+                                   n4 = !isn && !a4, n5 = isn && (v >> 31) && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
                         if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
                             if (n0) atomicMax(st + 0, len);
                             if (n1) atomicMax(st + 1, ~len);
@@ -721,14 +720,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             isn = len > 0 && t_all_set<W>(digmask, pos, len) && !(len > 1 && (w0 & 0xffu) == '0');
             v = t_parse8(w0, w1, len);
             if (__any(isn && len > 8)) {
-                if (isn && len > 8) {   // nine digits and more: digit by digit with the overflow test
+                if (isn && len > 8) {   // nine digits and more: digit by digit, wrapping like utils::to_num (utils.h:117-125)
                     v = 0;
                     for (uint32_t j = 0; j < len; ++j) {
                         const uint32_t p = pos + j;
                         const uint32_t d = ((s_w[p >> 2][tid] >> (8 * (p & 3))) & 0xffu) - '0';
-                        if (v > 214748364u || (v == 214748364u && d > 7)) ovf = true;
                         v = v * 10 + d;
                     }
+                    ovf = (v >> 31) != 0;   // what the reference ends up with as a negative int32
                 }
             }
             if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;   // k_title_measure_reg<true> and k_title_hist read it back

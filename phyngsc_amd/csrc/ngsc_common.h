@@ -53,7 +53,7 @@ enum : int {
     ERR_FIELDS = -2,       // title with a different separator count than the sub-block's first record
     ERR_TOOMANY = -3,      // > 100000 records in one sub-block
     ERR_COLORSPACE = -4,   // SOLiD colour-space reads (phyNGSC.cpp:473-547): out of scope
-    ERR_RANGE = -5,        // numeric title value >= 2^31 or delta range >= 2^31
+    ERR_RANGE = -5,        // numeric title value that the reference's uint32 parse leaves >= 2^31, or delta range >= 2^31
     ERR_NOMEM = -6,
     ERR_ARG = -7,
     ERR_UNSUPPORTED = -8,  // engine limit exceeded (MAX_FIELDS, MAX_TEXT_LEN0, MAX_CODE_LEN, text slots)
@@ -109,17 +109,15 @@ NGSC_HD bool parse_num(const uint8_t *b, uint32_t s, uint32_t e, uint32_t &v, bo
 {
     uint32_t len = e - s;
     if (len == 0) return false;
-    uint64_t acc = 0;
-    bool big = false;
+    uint32_t acc = 0;   // wraps like utils::to_num (utils.h:117-125)
     for (uint32_t i = s; i < e; ++i) {
         uint32_t d = (uint32_t)b[i] - '0';
         if (d > 9) return false;
         acc = acc * 10 + d;
-        if (acc > 0x7fffffffull) { big = true; acc &= 0xffffffffull; }
     }
     if (len > 1 && b[s] == '0') return false;
-    v = (uint32_t)acc;
-    ovf = big;
+    v = acc;
+    ovf = (acc >> 31) != 0;   // the reference holds the value in an int32: negative from here on
     return true;
 }
 

@@ -433,3 +433,21 @@ def test_record_shared_by_two_ranks(eng):
         assert out == want, P
         shared += sum(sb.n_records for sb in res.subblocks) - len(recs) > 0
     assert shared, "no rank split of this input shares a record: the test input lost its point"
+
+
+def test_numeric_title_values_wrap_like_the_reference(eng):
+    """utils::to_num is uint32 arithmetic (utils.h:117-125): 8888888888 becomes 298954296, 21474836480 becomes 0, and the
+    reference goes on with those (the stream is lossy there, but defined - checked against the reference binary).  Only a
+    value that ends up >= 2^31, a negative int32 for the reference, is refused."""
+    import random
+    rnd = random.Random(4)
+    vals = [b"8888888888", b"888888", b"21474836480", b"12", b"88888888888888"]
+    data = b"".join(b"@r.%d x %s y\n%s\n+\n%s\n" % (i, vals[i % len(vals)], bytes(rnd.choice(b"ACGT") for _ in range(36)),
+                                                     bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(3000))
+    _, out = _gpu(eng, data, 2)
+    want, _ = orc.compress_file(data, 2)
+    assert out == want
+    bad = data.replace(b"21474836480", b"3000000000")
+    with pytest.raises(orc.OracleError):
+        orc.compress_file(bad, 2)
+    _expect_error(eng, bad, 2, -5)
