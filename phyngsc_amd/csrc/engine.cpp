@@ -531,7 +531,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         return NGSC_OK;
     };
-    // titles of at most 64 bytes take the word-parallel kernels (NGSC_TITLE_PATH=reg forces the byte-serial ones)
+    // titles of at most 128 bytes take the word-parallel kernels, with one or two 64-bit mask words (NGSC_TITLE_PATH=reg forces the byte-serial ones)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
     const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
     if ((rc = fork())) return rc;

@@ -341,7 +341,7 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
     }
 }
 
-// 256 records (8 groups of 32) per workgroup.  SWAR: titles <= 64 bytes whose separator masks k_title_stats_swar
+// 256 records (8 groups of 32) per workgroup.  SWAR: titles <= 64 * W bytes whose separator masks k_title_stats_swar
 // left in A.tsep - the fields are found with count-trailing-zeros steps and only the non-constant numeric ones
 // are read (eight bytes, unaligned) and parsed; otherwise the title is parsed byte by byte.
 template <bool SWAR, uint32_t W>
