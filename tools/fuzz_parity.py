@@ -73,7 +73,8 @@ def main():
             d["P"] = rnd.choice([8, 12, 16, 20, 24])
         data = build_file(d, seed)
         total += len(data)
-        max_rec = max(len(x) for x in data.split(b"\n@")) + 2
+        _ln = data.split(b"\n")          # (quality lines may start with '@': count lines, do not look for "\n@")
+        max_rec = max((sum(len(x) + 1 for x in _ln[k:k + 4]) for k in range(0, len(_ln) - 3, 4)), default=0)
         try:
             ref, _ = orc.compress_file(data, d["P"], threads=8)
             o_rc = 0
