@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """bench.py - GB/s of raw FASTQ compressed on MI355X (BASELINE.json metric), inputs resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (no launcher needed, any N)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the whole hot path (record index, sub-block cuts, statistics, Huffman build, packed
-emit) over this process' share of the workload, with the FASTQ bytes already in HBM and the .ngsc
+emit) over one GPU's share of the workload, with the FASTQ bytes already in HBM and the .ngsc
 sub-block bytes left in HBM.  N=1: BASELINE configs[1], 1 GB synthetic 36 bp ERR005195-style FASTQ,
 8 virtual ranks.  N>1 (weak scaling): a logical file of N x 1 GB (fixed-width variant of the same
-generator so that every process can produce its own byte range), 8 virtual ranks per GPU; the only
-collective is the block-size all-gather that assigns file offsets (RCCL).
-Prints ONE JSON line on rank 0.
+generator so that every GPU's share can be produced on its own), 8 virtual ranks per GPU.
+
+Two ways to run N > 1, same work per GPU, same JSON line:
+  * under torch.distributed.run (WORLD_SIZE set): one process per GPU; the only collective is the all-gather of
+    block sizes that assigns file offsets (RCCL over xGMI; replaces MPI_Gather/Gatherv, phyNGSC.cpp:964, 994);
+  * plain `python bench.py --gpus N`: ONE process, N contexts, one host thread per GPU calling
+    ngsc_compress_device on its own device (ctypes releases the GIL) - the north-star's "single-process host that
+    partitions sub-blocks across the GPUs of one node"; the block sizes meet in host memory.
+Prints ONE JSON line (rank 0 / the main thread).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import shutil
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,50 +41,70 @@ import torch.distributed as dist  # noqa: E402
 from phyngsc_amd import api, fastq_gen, ngsc_format as nf  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+RANKS_PER_GPU = 8
+METRIC = "GB/s raw FASTQ compressed at 1/2/4/8 MI355X; bit-exact .ngsc vs ref"
+
+
+def kernel_source_hash() -> str:
+    """Identifies the kernel sources a profile was taken with (profiles/traffic_latest.json carries the same hash)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "phyngsc_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
-    """Algorithmic HBM bytes of one launch of each kernel on this workload (kernel table)."""
+    """Algorithmic HBM bytes of one launch of each kernel on this workload: what the kernel must
+    read of the FASTQ (or of the dense streams made from it) once, plus the stream bytes it writes.  Record tables,
+    scan temporaries and code tables are NOT credited."""
     n_rec = sum(sb.n_records for sb in res.subblocks)
     bases = sum(sb.n_bases for sb in res.subblocks)
     title_in = raw - 2 * bases - 4 * n_rec   # title lines incl. their newline
     title_out = sum(sb.title_len for sb in res.subblocks)
-    sq_out = sum(sb.qual_len + sb.dna_len for sb in res.subblocks)
-    ncf_words = 4 * n_rec * 2   # cached non-constant title fields (about two per record on this workload)
+    q_out = sum(sb.qual_len for sb in res.subblocks)
+    d_out = sum(sb.dna_len for sb in res.subblocks)
     return {
         "k_nl_count": raw,
-        "k_nl_write": raw + 12 * n_rec,
-        "k_validate": 12 * n_rec,
-        "k_cuts_validate": 16 * n_rec,
-        # register-streaming kernels (one lane per record): record table entries + the bytes they parse
-        "k_title_stats_swar": title_in + 8 * n_rec + 8 * n_rec,           # ls/te in, separator mask out
-        "k_title_measure_swar": 8 * n_rec + 8 * n_rec + ncf_words + 4 * n_rec + title_in // 4,  # masks + numeric fields only
-        "k_sq_stats_reg": 2 * bases + 8 * n_rec + 4 * n_rec,              # te/se in, slen out
-        "k_sq_measure_reg": bases + 12 * n_rec + 4 * n_rec,               # qualities only (2-bit DNA needs no bases)
-        "k_sq_pack_reg": 2 * bases + 16 * n_rec + sq_out,
-        # byte-serial / LDS-tiled fallbacks
+        "k_nl_write": raw // 8,
+        "k_title_stats_swar": title_in,
         "k_title_stats_reg": title_in,
-        "k_title_measure_reg": title_in + ncf_words + 4 * n_rec,
-        "k_title_pack_reg": ncf_words + 4 * n_rec + title_out,
+        "k_title_measure_swar": 0,
+        "k_title_measure_reg": title_in,
+        "k_title_pack_reg": title_out,
         "k_title_hist": title_in,
+        "k_sq_stats_reg": 2 * bases,
+        "k_sq_measure_reg": bases,
+        "k_sq_pack_reg": 2 * bases + q_out + d_out,
         "k_seq_qual_stats_tile": 2 * bases,
-        "k_measure_sq_tile": 2 * bases + 4 * n_rec,
-        "k_pack_sq_tile": 2 * bases + 4 * n_rec + sq_out,
-        # untiled fallbacks (records longer than the LDS tile budget)
+        "k_measure_sq_tile": 2 * bases,
+        "k_pack_sq_tile": 2 * bases + q_out + d_out,
         "k_seq_qual_stats": 2 * bases,
-        "k_measure_sq": 2 * bases + 8 * n_rec,
-        "k_pack_sq": 2 * bases + sq_out,
+        "k_measure_sq": 2 * bases,
+        "k_pack_sq": 2 * bases + q_out + d_out,
+        # dense-stream path (kernels_dense.hip)
+        "k_split": raw + 2 * bases,
+        "k_dq_stats": 2 * bases,
+        "k_dq_measure": bases,
+        "k_dq_pack": 2 * bases + q_out + d_out,
     }
 
 
 def cpu_baseline(data: np.ndarray, P: int) -> dict:
     """Reported-only CPU baseline on the host cores of the GPU box: the unmodified reference binary
-    (oracle/_ref, built in the build container) if it runs here, else the oracle port."""
+    (oracle/_ref, built in the build container) if it runs here, else the oracle port (with the reason)."""
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "phyNGSC")
     mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
     sample = f"whole workload ({data.size} B), page-cached file"
-    if os.path.exists(ref) and os.path.exists(mpiexec):
+    why = None
+    if not os.path.exists(ref):
+        why = "oracle/_ref/phyNGSC not present"
+    elif not os.path.exists(mpiexec):
+        why = "no mpiexec on this box"
+    else:
         try:
             with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
                 fq, out = os.path.join(tmp, "in.fastq"), os.path.join(tmp, "out.ngsc")
@@ -88,33 +116,153 @@ def cpu_baseline(data: np.ndarray, P: int) -> dict:
                 if r.returncode == 0 and os.path.getsize(out) > 0:
                     times = [float(l.split()[1]) for l in r.stdout.splitlines() if l[:1].isdigit() and len(l.split()) >= 4]
                     comp = max(times) if times else dt
-                    return {"value": data.size / comp / 1e9, "unit": "GB/s", "cores": npn, "kind": "reference",
+                    return {"value": data.size / comp / 1e9, "unit": "GB/s", "cores": npn, "host_cores": cores,
+                            "kind": "reference",
                             "sample": sample + f"; mpiexec -np {npn} x 1 thread, slowest-rank COMP_TIME {comp:.2f} s "
                                                f"(wall {dt:.2f} s)"}
-        except Exception:  # noqa: BLE001
-            pass
+                why = f"reference run failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]!r}"
+        except Exception as e:  # noqa: BLE001
+            why = f"reference run raised {type(e).__name__}: {e}"
     from oracle import binding as orc
     thr = min(P, cores)
     _, st = orc.compress_file(data, P, threads=thr)
-    return {"value": data.size / st.seconds / 1e9, "unit": "GB/s", "cores": thr, "kind": "port",
+    return {"value": data.size / st.seconds / 1e9, "unit": "GB/s", "cores": thr, "host_cores": cores, "kind": "port",
+            "fallback_reason": why,
             "sample": sample + f"; oracle/ngsc_oracle.c, {thr} OpenMP threads over {P} virtual ranks"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size-mb", type=int, default=1000, help="raw FASTQ MB per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    args = ap.parse_args()
+class Share:
+    """One GPU's share of the workload: its byte range of the (logical) file in HBM, its virtual ranks, its context."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    def __init__(self, world: int, rank: int, device: int, per_gpu: int):
+        self.world, self.rank, self.device = world, rank, device
+        self.P = RANKS_PER_GPU * world
+        P = self.P
+        if world == 1:
+            cfg = fastq_gen.CFG2
+            host = fastq_gen.generate(cfg, target_bytes=per_gpu)
+            self.file_size, self.buf_off = int(host.size), 0
+            self.workload = f"cfg2: {host.size} B synthetic FASTQ, 36 bp ERR005195-style (seed 2), {P} virtual ranks, 1 GPU"
+        else:
+            cfg = fastq_gen.CFG2_FIXED
+            rs = fastq_gen.record_size(cfg)
+            n_per = per_gpu // rs
+            self.file_size = world * n_per * rs
+            lo, hi = api.job_byte_range(self.file_size, P, rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU)
+            self.buf_off = lo & ~15
+            host = fastq_gen.generate_range(cfg, self.buf_off, hi - self.buf_off)
+            self.workload = (f"cfg2-fixed: {self.file_size} B logical FASTQ ({world} x {n_per * rs} B), 36 bp, {P} virtual "
+                             f"ranks, {RANKS_PER_GPU} per GPU")
+        self.host = host
+        self.lo_rank, self.hi_rank = rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU
+        fs = self.file_size
+        self.my_raw = (api.region_bounds(fs, P, self.hi_rank - 1)[1] + 1 if self.hi_rank < P else fs) - \
+            api.region_bounds(fs, P, self.lo_rank)[0]
+        if self.hi_rank < P:
+            self.my_raw -= api.OVERLAP  # count each byte once: regions, not regions + overlap
+        torch.cuda.set_device(device)
+        dev = torch.device("cuda", device)
+        self.d_in = torch.from_numpy(host).to(dev)
+        self.d_out = torch.empty(int(host.size * 0.45) + (32 << 20), dtype=torch.uint8, device=dev)
+        self.eng = api.Engine(device)
+        self.res = None
+
+    def step(self):
+        self.res = self.eng.compress_device(self.d_in, self.file_size, self.P, rank_lo=self.lo_rank, rank_hi=self.hi_rank,
+                                            buf_off=self.buf_off, out=self.d_out)
+        return self.res
+
+    def block_sizes(self):
+        res = self.res
+        sizes = [[b.size for b in api.plan_blocks(self.P, rk.rank, [res.subblocks[rk.first_subblock + k].size
+                                                                    for k in range(rk.n_subblocks)])] for rk in res.ranks]
+        meta = [(rk.n_subblocks, rk.overlap_used) for rk in res.ranks]
+        return sizes, meta
+
+
+def profile_pass(sh: Share):
+    """Untimed: an event pair around EVERY kernel -> the per-kernel table and which kernel dominates; then only that
+    kernel keeps its events for the timed region (an event pair around each launch costs launch gaps)."""
+    eng = sh.eng
+    eng.set_profiling(True)
+    eng.reset_kernel_times()
+    for _ in range(2):
+        sh.step()
+    torch.cuda.synchronize(sh.device)
+    ktimes_all = eng.kernel_times()
+    dom = max(ktimes_all, key=lambda k: ktimes_all[k][0] / max(ktimes_all[k][1], 1))
+    eng.profile_only(dom)
+    eng.reset_kernel_times()
+    return ktimes_all, dom
+
+
+def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, launch_mode):
+    res, eng = sh.res, sh.eng
+    ktimes = eng.kernel_times()
+    alg = algorithmic_bytes(res, sh.my_raw)
+    per_kernel = {k: {"ms_avg": ms / max(n, 1), "launches": n} for k, (ms, n) in ktimes_all.items() if n}
+    dom_ms = ktimes[dom][0] / max(ktimes[dom][1], 1)   # measured inside the timed region
+    per_kernel[dom]["ms_avg"] = dom_ms
+    achieved = alg.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel: NOT measured in this run (PMC counters need their own rocprofv3 passes):
+    # taken from the committed profile, with its provenance, and marked stale when the kernel sources changed since
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if world == 1 and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+        prof_hash = tj.get("kernel_source_hash")
+        traffic_src = {"file": "profiles/traffic_latest.json", "tool": "tools/pmc_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                       "separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)", "build": tj.get("build"),
+                       "measured_in_this_run": False, "stale": prof_hash != kernel_source_hash()}
+    kernel_sum_ms = sum(v["ms_avg"] for v in per_kernel.values())
+    step_ms = dt / args.steps * 1e3
+    line = {
+        "metric": METRIC,
+        "value": total_raw * args.steps / dt / 1e9,
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_ms,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": sh.workload, "virtual_ranks": sh.P, "raw_bytes": total_raw, "ngsc_bytes": total_out,
+                   "ratio": total_out / total_raw, "subblocks_rank0": len(res.subblocks), "launch": launch_mode},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_ms": dom_ms},
+        "pipeline": {"kernel_ms_sum": kernel_sum_ms, "host_gap_ms": step_ms - kernel_sum_ms,
+                     "raw_GBps_over_kernel_time": sh.my_raw / (kernel_sum_ms * 1e-3) / 1e9 if kernel_sum_ms else None,
+                     "frac_of_hbm_read_roofline": sh.my_raw / (kernel_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                     if kernel_sum_ms else None},
+        "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])},
+    }
+    if world == 1 and not args.no_verify:
+        out = api.assemble_container(res, sh.P, sh.file_size)
+        man_path = os.path.join(ROOT, "tests", "golden", "manifest_cfg2_1GB.json")
+        verdict = None
+        if os.path.exists(man_path):
+            with open(man_path) as f:
+                man = json.load(f)
+            if man["fastq_bytes"] == sh.file_size and str(sh.P) in man["ranks"]:
+                verdict = nf.manifest(out) == man["ranks"][str(sh.P)]
+        line["bit_exact_vs_reference_manifest"] = verdict
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sh.host, sh.P)
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+
+
+# ---- one process per GPU (torch.distributed.run) ----------------------------------------------------------------
+def run_distributed(args, world: int):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     # NGSC_BENCH_REHEARSE=1: every rank on cuda:0 with gloo collectives - a dry run of the N > 1 path on a one-GPU box
     # (RCCL refuses two ranks on one device); never used by the driver
     rehearse = os.environ.get("NGSC_BENCH_REHEARSE") == "1"
@@ -128,36 +276,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-
-    per_gpu = args.size_mb * 1_000_000
-    RANKS_PER_GPU = 8
-    P = RANKS_PER_GPU * world
-    if world == 1:
-        cfg = fastq_gen.CFG2
-        host = fastq_gen.generate(cfg, target_bytes=per_gpu)
-        file_size, buf_off = int(host.size), 0
-        workload = f"cfg2: {host.size} B synthetic FASTQ, 36 bp ERR005195-style (seed 2), {P} virtual ranks, 1 GPU"
-    else:
-        cfg = fastq_gen.CFG2_FIXED
-        rs = fastq_gen.record_size(cfg)
-        n_per = per_gpu // rs
-        file_size = world * n_per * rs
-        lo, hi = api.job_byte_range(file_size, P, rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU)
-        buf_off = lo & ~15
-        host = fastq_gen.generate_range(cfg, buf_off, hi - buf_off)
-        workload = (f"cfg2-fixed: {file_size} B logical FASTQ ({world} x {n_per * rs} B), 36 bp, {P} virtual ranks, "
-                    f"{RANKS_PER_GPU} per GPU")
-    lo_rank, hi_rank = rank * RANKS_PER_GPU, (rank + 1) * RANKS_PER_GPU
-    my_raw = (api.region_bounds(file_size, P, hi_rank - 1)[1] + 1 if hi_rank < P else file_size) - \
-        api.region_bounds(file_size, P, lo_rank)[0]
-    if hi_rank < P:
-        my_raw -= api.OVERLAP  # count each byte once: regions, not regions + overlap
-    d_in = torch.from_numpy(host).to(dev)
-    d_out = torch.empty(int(host.size * 0.45) + (32 << 20), dtype=torch.uint8, device=dev)
-    eng = api.Engine(local_rank)
-
-    def step():
-        return eng.compress_device(d_in, file_size, P, rank_lo=lo_rank, rank_hi=hi_rank, buf_off=buf_off, out=d_out)
+    sh = Share(world, rank, local_rank, args.size_mb * 1_000_000)
 
     def barrier():
         if world > 1:
@@ -165,97 +284,122 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res = step()
-    # untimed pass with an event pair around EVERY kernel: the per-kernel table, and which kernel dominates
-    eng.set_profiling(True)
-    eng.reset_kernel_times()
-    for _ in range(2):
-        res = step()
-    torch.cuda.synchronize()
-    ktimes_all = eng.kernel_times()
-    dom = max(ktimes_all, key=lambda k: ktimes_all[k][0] / max(ktimes_all[k][1], 1))
-    # timed region: only the dominant kernel carries HIP events (two records per step; an event pair around each
-    # of the ~30 launches costs ~0.3 ms per step in launch gaps)
-    eng.profile_only(dom)
-    eng.reset_kernel_times()
+        sh.step()
+    ktimes_all, dom = profile_pass(sh)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        sh.step()
     barrier()
     dt = time.perf_counter() - t0
-    eng.set_profiling(False)
-    eng.profile_only(None)
+    sh.eng.set_profiling(False)
+    sh.eng.profile_only(None)
     if world > 1:
-        # the one data-path-free collective: block sizes -> file offsets (RCCL all-gather over xGMI)
-        sizes_local = [[b.size for b in api.plan_blocks(P, rk.rank, [res.subblocks[rk.first_subblock + k].size
-                                                                     for k in range(rk.n_subblocks)])] for rk in res.ranks]
-        meta_local = [(rk.n_subblocks, rk.overlap_used) for rk in res.ranks]
+        # the one (data-path-free) collective: block sizes -> file offsets (RCCL all-gather over xGMI)
+        sizes_local, meta_local = sh.block_sizes()
         sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=cdev)
         api.file_offsets(sizes_all)
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([my_raw, res.total_bytes], dtype=torch.int64, device=cdev)
+        tot = torch.tensor([sh.my_raw, sh.res.total_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_raw, total_out = int(tot[0].item()), int(tot[1].item())
     else:
-        total_raw, total_out = file_size, res.total_bytes
-
-    ktimes = eng.kernel_times()
+        total_raw, total_out = sh.file_size, sh.res.total_bytes
     if rank == 0:
-        alg = algorithmic_bytes(res, my_raw)
-        per_kernel = {k: {"ms_avg": ms / max(n, 1), "launches": n} for k, (ms, n) in ktimes_all.items() if n}
-        dom_ms = ktimes[dom][0] / max(ktimes[dom][1], 1)   # measured inside the timed region
-        per_kernel[dom]["ms_avg"] = dom_ms
-        achieved = alg.get(dom, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if world == 1 and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-        kernel_sum_ms = sum(v["ms_avg"] for v in per_kernel.values())
-        line = {
-            "metric": "GB/s raw FASTQ compressed at 1/2/4/8 MI355X; bit-exact .ngsc vs ref",
-            "value": total_raw * args.steps / dt / 1e9,
-            "unit": "GB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": workload, "virtual_ranks": P, "raw_bytes": total_raw, "ngsc_bytes": total_out,
-                       "ratio": total_out / total_raw, "subblocks_rank0": len(res.subblocks)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_ms": dom_ms},
-            "pipeline": {"kernel_ms_sum": kernel_sum_ms, "raw_GBps_over_kernel_time": my_raw / (kernel_sum_ms * 1e-3) / 1e9
-                         if kernel_sum_ms else None, "frac_of_hbm_read_roofline": my_raw / (kernel_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                         if kernel_sum_ms else None},
-            "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])},
-        }
-        if world == 1 and not args.no_verify:
-            out = api.assemble_container(res, P, file_size)
-            man_path = os.path.join(ROOT, "tests", "golden", "manifest_cfg2_1GB.json")
-            verdict = None
-            if os.path.exists(man_path):
-                with open(man_path) as f:
-                    man = json.load(f)
-                if man["fastq_bytes"] == file_size and str(P) in man["ranks"]:
-                    verdict = nf.manifest(out) == man["ranks"][str(P)]
-            line["bit_exact_vs_reference_manifest"] = verdict
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host, P)
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        mode = ("one process per GPU (torch.distributed.run), " + ("gloo rehearsal on one device" if rehearse else
+                "RCCL all-gather of block sizes")) if world > 1 else "one process, one context"
+        report(sh, args, world, dt, total_raw, total_out, ktimes_all, dom, mode)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- one process, N contexts, one host thread per GPU --------------------------------------------------------------
+def run_threads(args):
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    rehearse = os.environ.get("NGSC_BENCH_REHEARSE") == "1"   # all contexts on device 0 (one-GPU box)
+    if ndev < n and not rehearse:
+        raise SystemExit(f"--gpus {n} but this node shows {ndev} GPU(s)")
+    shares = [None] * n
+    errors = []
+    gate = threading.Barrier(n + 1)
+    dts = [0.0] * n
+    prof = {}
+
+    def worker(i):
+        try:
+            dev = 0 if rehearse else i
+            sh = Share(n, i, dev, args.size_mb * 1_000_000)
+            shares[i] = sh
+            for _ in range(args.warmup):
+                sh.step()
+            if i == 0:
+                prof["k"], prof["dom"] = profile_pass(sh)
+            else:
+                for _ in range(2):
+                    sh.step()
+            torch.cuda.synchronize(dev)
+            gate.wait()                      # barrier + synchronize, then exactly K steps, then the same again
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sh.step()
+            torch.cuda.synchronize(dev)
+            dts[i] = time.perf_counter() - t0
+            gate.wait()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((i, e))
+            gate.abort()
+
+    threads = [threading.Thread(target=worker, args=(i,), name=f"gpu{i}") for i in range(n)]
+    for t in threads:
+        t.start()
+    try:
+        gate.wait()
+        t0 = time.perf_counter()
+        gate.wait()
+        dt_wall = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt_wall = 0.0
+    for t in threads:
+        t.join()
+    if errors:
+        raise SystemExit(f"worker {errors[0][0]} failed: {errors[0][1]!r}")
+    dt = max(max(dts), dt_wall)              # MAX over the GPUs' own clocks and the main thread's
+    # block sizes of all ranks meet in host memory: same offsets computation as the RCCL path (api.file_offsets)
+    sizes_all = []
+    for sh in shares:
+        s, _ = sh.block_sizes()
+        sizes_all.extend(s)
+    api.file_offsets(sizes_all)
+    total_raw = sum(sh.my_raw for sh in shares)
+    total_out = sum(sh.res.total_bytes for sh in shares)
+    sh0 = shares[0]
+    sh0.eng.set_profiling(False)
+    mode = f"one process, {n} contexts on {n} host threads" + (" (rehearsal: all on device 0)" if rehearse else "")
+    report(sh0, args, n, dt, total_raw, total_out, prof["k"], prof["dom"], mode)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size-mb", type=int, default=1000, help="raw FASTQ MB per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        run_distributed(args, world)
+    elif args.gpus == 1:
+        run_distributed(args, 1)
+    else:
+        run_threads(args)
 
 
 if __name__ == "__main__":

@@ -73,7 +73,11 @@ int main(int argc, char **argv)
             for (ngsc_ctx *c : ctxs)
                 if (*ngsc_last_hip_error(c)) fprintf(stderr, "          device %d: %s\n", ngsc_ctx_device(c), ngsc_last_hip_error(c));
         destroy_all();
-        return rc == NGSC_ERR_IO ? 2 : 3;
+        // exit codes of the reference (phyNGSC.cpp:61-108): 1 usage, 2 cannot open, 3 allocation / device failure; the
+        // reference has no code for input it cannot compress (it runs into undefined behaviour there): 4 here
+        if (rc == NGSC_ERR_IO) return 2;
+        if (rc == NGSC_ERR_ARG) return 1;
+        return (rc == NGSC_ERR_NOMEM || rc == NGSC_ERR_HIP) ? 3 : 4;
     }
     // (a context's result tables describe its last job only: report the file that was written)
     unsigned long long out_bytes = 0;

@@ -46,6 +46,10 @@ CFG1 = GenConfig(seed=1234, style=0, len_min=36, len_max=36, qual_model=0)      
 CFG2 = GenConfig(seed=2, style=0, len_min=36, len_max=36, qual_model=0)                     # 1 GB, 36 bp
 CFG3 = GenConfig(seed=3, style=1, len_min=150, len_max=150, qual_model=1, n_rate_ppm=2000, n_lowq_pct=80)
 CFG5 = GenConfig(seed=5, style=2, len_min=36, len_max=200, qual_model=2, n_rate_ppm=2000, n_lowq_pct=80)
+# BASELINE configs[4] as stated: 36-300 bp mix, skewed quality alphabet.  Records above ~230 bp exceed the reference's
+# 500-byte overlap; CFG5_150 is the variant inside the reference's defined domain.
+CFG5_300 = GenConfig(seed=5, style=2, len_min=36, len_max=300, qual_model=2, n_rate_ppm=2000, n_lowq_pct=80)
+CFG5_150 = GenConfig(seed=5, style=2, len_min=36, len_max=150, qual_model=2, n_rate_ppm=2000, n_lowq_pct=80)
 # seekable (every record the same size) variant of CFG2 for multi-rank weak scaling
 CFG2_FIXED = GenConfig(seed=2, style=0, len_min=36, len_max=36, qual_model=0, fixed_width=1,
                        first_index=10_000_000)

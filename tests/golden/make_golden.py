@@ -208,6 +208,8 @@ GEN_CASES = [
     ("cfg2_100MB", fastq_gen.CFG2, 100_000_000, [2, 8]),
     ("cfg3_150bp_100MB", fastq_gen.CFG3, 100_000_000, [4, 8]),
     ("cfg5_mixed_60MB", fastq_gen.CFG5, 60_000_000, [8]),
+    ("cfg5_36_150_60MB", fastq_gen.CFG5_150, 60_000_000, [8]),
+    ("cfg5_36_300_60MB", fastq_gen.CFG5_300, 60_000_000, [8]),   # records beyond the overlap (Q7): kept because the reference's run is deterministic here and equals the oracle
     ("cfg2_1GB", fastq_gen.CFG2, 1_000_000_000, [8]),
     ("cfg2fixed_256MB", fastq_gen.CFG2_FIXED, 256 << 20, [8]),
 ]

@@ -327,14 +327,19 @@ def test_cli_file_to_file(tmp_path):
 
 
 def test_multi_context_file_driver(tmp_path, monkeypatch):
-    """ngsc_compress_file_multi: two contexts (here both on device 0, on two host threads) write the same
-    file as one context -- the single-process multi-GPU driver (phyNGSC.cpp:113-116 rank split)."""
+    """ngsc_compress_file_multi: several contexts, one host thread each, write the same file as one context -- the
+    single-process multi-GPU driver (phyNGSC.cpp:113-116 rank split).  The contexts sit on distinct devices when the
+    node has more than one (hipSetDevice per thread, per-device streams, pinned staging seen by every device);
+    on a one-GPU box they share device 0."""
     data = fastq_gen.generate(fastq_gen.CFG5, target_bytes=30_000_000)
     inp = tmp_path / "in.fastq"
     data.tofile(inp)
     want, _ = orc.compress_file(data, 8, threads=8)
-    e0, e1 = api.Engine(0), api.Engine(0)
-    for engines, name in (([e0], "one"), ([e0, e1], "two"), ([e0, e1, api.Engine(0), api.Engine(0)], "four")):
+    ndev = torch.cuda.device_count()
+    dev = lambda i: i % ndev   # noqa: E731
+    e0, e1 = api.Engine(dev(0)), api.Engine(dev(1))
+    assert [e0.device, e1.device] == [0, 1 if ndev > 1 else 0]
+    for engines, name in (([e0], "one"), ([e0, e1], "two"), ([e0, e1, api.Engine(dev(2)), api.Engine(dev(3))], "four")):
         outp = tmp_path / f"{name}.ngsc"
         api.compress_file_multi(engines, str(inp), str(outp), 8)
         assert outp.read_bytes() == want, name
@@ -369,11 +374,38 @@ def test_round_trip_goldens(eng, ngsc_path):
     assert orc.decompress(out) == data
 
 
-@pytest.mark.parametrize("cfg,size,P", [(fastq_gen.CFG3, 60_000_000, 8), (fastq_gen.CFG5, 40_000_000, 6)])
+@pytest.mark.parametrize("cfg,size,P", [(fastq_gen.CFG3, 60_000_000, 8), (fastq_gen.CFG5, 40_000_000, 6),
+                                        (fastq_gen.CFG5_300, 40_000_000, 8)])
 def test_round_trip_generated(eng, cfg, size, P):
     data = fastq_gen.generate(cfg, target_bytes=size)
     _, out = _gpu(eng, data, P)
     assert orc.decompress(out) == data.tobytes()
+
+
+def test_cfg5_as_stated_36_300bp(eng):
+    """BASELINE configs[4] as stated: 36-300 bp mix, skewed quality alphabet, 0.2 % N.  Against the oracle at several
+    rank counts (the P = 8 run is also pinned by the reference manifest manifest_cfg5_36_300_60MB.json)."""
+    data = fastq_gen.generate(fastq_gen.CFG5_300, target_bytes=80_000_000)
+    for P in (2, 8, 16):
+        _, out = _gpu(eng, data, P)
+        want, _ = orc.compress_file(data, P, threads=8)
+        assert out == want, P
+
+
+def test_bench_multi_gpu_modes_start_without_a_launcher():
+    """`python bench.py --gpus N` needs no external launcher: one process, N contexts on N host threads (here in
+    rehearsal form when the box has a single GPU: all contexts on device 0)."""
+    import sys
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env["NGSC_BENCH_REHEARSE"] = "1"
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size-mb", "64", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["virtual_ranks"] == 16
+    assert "2 contexts" in line["config"]["launch"]
 
 
 def _edge_cases():

@@ -13,7 +13,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
     python3 $repo/tools/pmc_summary.py $out/pmc_${tag}_$c > $out/pmc_${tag}_$c.json
     find $out/pmc_${tag}_$c -name "*.csv" -size +8M -delete
 done
-python3 - "$out" "$tag" <<'PY'
+khash=$(cd $repo && python3 -c "import bench; print(bench.kernel_source_hash())" 2>/dev/null | tail -1)
+python3 - "$out" "$tag" "$khash" <<'PY'
 import json, re, sys
 def norm(k):   # template arguments off; the word-parallel instance of the title measure kernel has its own name
     k = re.sub(r'k_title_measure_reg<true, \d+u?>', 'k_title_measure_swar', k)
@@ -21,8 +22,10 @@ def norm(k):   # template arguments off; the word-parallel instance of the title
 out, tag = sys.argv[1], sys.argv[2]
 f = json.load(open(f"{out}/pmc_{tag}_FETCH_SIZE.json")); w = json.load(open(f"{out}/pmc_{tag}_WRITE_SIZE.json"))
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, bench.py 1 GB cfg2 workload; FETCH_SIZE doubled per "
-               "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads) - an upper estimate for byte-granular access"}
+               "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads) - an upper estimate for byte-granular access",
+       "build": tag, "kernel_source_hash": sys.argv[3]}
 for k in f:
+    if not isinstance(f[k], dict): continue
     fk = f[k].get("FETCH_SIZE", 0.0); wk = w.get(k, {}).get("WRITE_SIZE", 0.0)
     res[norm(k)] = {"fetch_size_kb_raw": fk, "write_size_kb": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
               "launches_sampled": f[k].get("launches")}
