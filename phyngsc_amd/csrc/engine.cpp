@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct ngsc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string hip_err;
     bool profiling = false;
+    bool debug_sync = getenv("NGSC_DEBUG_SYNC") != nullptr;
     std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
     uint32_t min_text_slots = 0;  // text-field table slots the last call turned out to need (kept for the next call)
     bool slot_retry = false;
@@ -112,7 +114,8 @@ struct KScope {
     hipStream_t st;
     int idx = -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    KScope(ngsc_ctx *ctx, hipStream_t s, const char *name) : c(ctx), st(s)
+    const char *name_;
+    KScope(ngsc_ctx *ctx, hipStream_t s, const char *name) : c(ctx), st(s), name_(name)
     {
         if (!c->profiling) return;
         if (!c->profile_only.empty() && c->profile_only != name) return;
@@ -136,6 +139,11 @@ struct KScope {
     }
     ~KScope()
     {
+        if (c->debug_sync) {   // NGSC_DEBUG_SYNC=1: name the launch that failed
+            hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(st);
+            if (e1 != hipSuccess || e2 != hipSuccess)
+                fprintf(stderr, "[ngsc] %s: launch %s, run %s\n", name_, hipGetErrorString(e1), hipGetErrorString(e2));
+        }
         if (idx < 0) return;
         (void)hipEventRecord(e1, st);
         c->ktimes[idx].pending.emplace_back(e0, e1);
@@ -415,9 +423,13 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (const char *ev = getenv("NGSC_TILE_RECORDS")) r_max = (uint32_t)atoi(ev);
     // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile"
     // (NGSC_SQ_PATH=tile keeps the LDS-tiled kernels)
+    // ... superseded by one lane per 16-byte chunk out of an LDS-staged tile of TR records (kernels_chunk.hip); NGSC_SQ_PATH=reg
+    // keeps the lane-per-record kernels
     const char *sq_env = getenv("NGSC_SQ_PATH");
-    const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
-    const uint32_t R = sq_reg ? 256u : tile_records_for(max_rec_bytes, r_max);
+    const uint32_t TR = chunk_tile_records(max_rec_bytes);
+    const bool sq_chunk = TR != 0 && !(sq_env && (!strcmp(sq_env, "tile") || !strcmp(sq_env, "reg")));
+    const bool sq_reg = !sq_chunk && max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
+    const uint32_t R = sq_chunk ? TR : (sq_reg ? 256u : tile_records_for(max_rec_bytes, r_max));
     uint32_t n_tiles = 0;
     std::vector<uint32_t> tile_lo(S);
     for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
@@ -540,7 +552,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
     { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
     { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec, t_swar); }
-    if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
+    if (sq_chunk) { KScope k(c, st, "k_ck_stats"); launch_ck_stats(st, A, max_rec, TR, max_rec_bytes); }
+    else if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
     else if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
@@ -549,7 +562,9 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
     if ((rc = fork())) return rc;
     { KScope k(c, st2, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st2, A, max_rec, t_swar); }
-    if (sq_reg) {
+    if (sq_chunk) {
+        { KScope k(c, st, "k_ck_measure"); launch_ck_measure(st, A, max_rec, TR, max_rec_bytes); }
+    } else if (sq_reg) {
         { KScope k(c, st, "k_sq_measure_reg"); launch_sq_measure_reg(st, A, max_rec); }
     } else if (R) {
         { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
@@ -610,18 +625,19 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
-    if (sq_reg) {
-        // LDS staging of a 256-record tile's output, sized from what the sub-blocks really need (+25 %; a tile that
+    if (sq_reg || sq_chunk) {
+        // LDS staging of a tile's output, sized from what the sub-blocks really need (+25 %; a tile that
         // needs more writes straight to the zeroed output)
         uint32_t sw_q = 0, sw_d = 0;
+        const uint64_t trec = (uint64_t)R * 5 / 4;
         for (uint32_t s = 0; s < S; ++s) {
             const SbState &x = h_sb[s];
             const uint32_t nr = x.n_rec ? x.n_rec : 1;
-            sw_q = std::max(sw_q, (uint32_t)(((uint64_t)x.qbits * 320 / nr) / 32) + 64);
-            sw_d = std::max(sw_d, (uint32_t)(((uint64_t)x.dbits * 320 / nr) / 32) + 64);
+            sw_q = std::max(sw_q, (uint32_t)(((uint64_t)x.qbits * trec / nr) / 32) + 64);
+            sw_d = std::max(sw_d, (uint32_t)(((uint64_t)x.dbits * trec / nr) / 32) + 64);
         }
-        KScope k(c, st, "k_sq_pack_reg");
-        launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d);
+        if (sq_chunk) { KScope k(c, st, "k_ck_pack"); launch_ck_pack(st, A, max_rec, TR, max_rec_bytes, sw_q, sw_d); }
+        else { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
     else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }

@@ -25,6 +25,13 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t stage_q_words, uint32_t stage_d_words);
 
+// ---- kernels_chunk.hip (one lane per 16-byte chunk of a read, LDS-staged tiles) ----
+uint32_t chunk_tile_records(uint32_t max_rec_bytes);
+void launch_ck_stats(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes);
+void launch_ck_measure(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes);
+void launch_ck_pack(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes, uint32_t stage_q_words,
+                    uint32_t stage_d_words);
+
 // ---- kernels_stats.hip ----
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_finalize(hipStream_t st, const Arena &A);
