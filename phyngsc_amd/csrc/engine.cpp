@@ -423,11 +423,12 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (const char *ev = getenv("NGSC_TILE_RECORDS")) r_max = (uint32_t)atoi(ev);
     // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile"
     // (NGSC_SQ_PATH=tile keeps the LDS-tiled kernels)
-    // ... superseded by one lane per 16-byte chunk out of an LDS-staged tile of TR records (kernels_chunk.hip); NGSC_SQ_PATH=reg
-    // keeps the lane-per-record kernels
+    // NGSC_SQ_PATH=chunk: one lane per 16-byte chunk out of LDS-staged wave tiles of TR records (kernels_chunk.hip) - coalesced
+    // loads, no divergence over read lengths, but 15-50 % slower than the lane-per-record kernels on every configuration
+    // measured: kept as a tested alternative, not the default
     const char *sq_env = getenv("NGSC_SQ_PATH");
     const uint32_t TR = chunk_tile_records(max_rec_bytes);
-    const bool sq_chunk = TR != 0 && !(sq_env && (!strcmp(sq_env, "tile") || !strcmp(sq_env, "reg")));
+    const bool sq_chunk = TR != 0 && sq_env && !strcmp(sq_env, "chunk");
     const bool sq_reg = !sq_chunk && max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
     const uint32_t R = sq_chunk ? TR : (sq_reg ? 256u : tile_records_for(max_rec_bytes, r_max));
     uint32_t n_tiles = 0;

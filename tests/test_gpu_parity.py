@@ -109,18 +109,19 @@ PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "tit
               "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
 
 
-@pytest.mark.parametrize("tile_records", ["chunk", "chunk16", "chunk64", "reg", "1", "64", "128", "256"])
+@pytest.mark.parametrize("tile_records", ["reg", "chunk", "chunk16", "chunk32", "1", "64", "128", "256"])
 def test_kernel_paths_agree(eng, monkeypatch, tile_records):
-    """The sequence/quality kernels exist in four forms: one lane per 16-byte chunk out of an LDS-staged tile (the
-    default for records up to 2 KB; 16..256 records per tile), register-streaming (NGSC_SQ_PATH=reg: one lane per
-    record), LDS-tiled (NGSC_SQ_PATH=tile: 64/128/256 records per tile, 4/2/1 threads per record) and
+    """The sequence/quality kernels exist in four forms: register-streaming (one lane per record, the default for
+    records up to 2 KB), one lane per 16-byte chunk out of LDS-staged wave tiles (NGSC_SQ_PATH=chunk; 16..64 records
+    per tile), LDS-tiled (NGSC_SQ_PATH=tile: 64/128/256 records per tile, 4/2/1 threads per record) and
     wave-per-record (records above 2 KB; forced here with NGSC_TILE_RECORDS=1 = no tile size allowed): every form
     must reproduce the reference."""
     if tile_records.startswith("chunk"):
+        monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
         if tile_records != "chunk":
             monkeypatch.setenv("NGSC_CHUNK_TILE_RECORDS", tile_records[5:])
     elif tile_records == "reg":
-        monkeypatch.setenv("NGSC_SQ_PATH", "reg")
+        pass
     else:
         monkeypatch.setenv("NGSC_SQ_PATH", "tile")
         monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
