@@ -4,7 +4,7 @@
 // ngsc_compress_device() runs, for a range of virtual ranks:
 //   sync_first -> nl_count/scan -> [sync: line count] -> nl_write, validate, cuts -> [sync: cut list]
 //   -> title_stats, seq_qual_stats, finalize, title_hist, huffman, measure, scan/layout
-//   -> [sync: sizes] -> memset(out), headers, length table, title pack, quality/DNA pack -> [sync]
+//   -> zero(out), headers, length table, title pack, quality/DNA pack -> [sync: error word, sizes, result tables]
 // There is no CPU implementation of any of these stages in this library.
 #include "../../include/ngsc.h"
 #include "ngsc_kernels.h"
@@ -502,7 +502,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
 
     // host-initialised SbState + group offsets
     size_t sb_bytes = sizeof(SbState) * (size_t)S;
-    rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + 4096);
+    rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + o_first + 4096);
     if (rc) return rc;
     hp = (uint8_t *)c->h_pin;
     SbState *h_sb = (SbState *)hp;
@@ -576,11 +576,34 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (R) { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     else { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
-    // ---- sync 3: sizes ----
+    // ---- sizes and layout are on the device now; their copies for the host travel behind the pack kernels (no sync here) ----
     HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, st));
+    // ---- pack ----
+    { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap); }
+    { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
+    { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
+    if ((rc = fork())) return rc;
+    { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
+    if (sq_reg || sq_chunk) {
+        // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's longest
+        // length, + 25 % (from the job's maxima: no stream size has to come back to the host first; a tile that needs
+        // more writes straight to the zeroed output)
+        const uint64_t trec = (uint64_t)R * 5 / 4;
+        const uint32_t sw_q = (uint32_t)(trec * max_q * 5 / 32) + 64;
+        const uint32_t sw_d = (uint32_t)(trec * max_q * 5 / 64) + 64;
+        if (sq_chunk) { KScope k(c, st, "k_ck_pack"); launch_ck_pack(st, A, max_rec, TR, max_rec_bytes, sw_q, sw_d); }
+        else { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
+    }
+    else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
+    else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    if ((rc = join())) return rc;
+    // ---- the one sync behind the cut list: error word, sizes, result tables ----
+    uint8_t *hfin = hp + sb_bytes + o_first + 64;
+    HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);
+    HIPCHK(c, hipGetLastError());
+    const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);   // state behind the layout kernels
     const uint64_t total = *(uint64_t *)(hp + sb_bytes + o_outtot);
     c->res_bytes = total;
     if (err3 == NGSC_ERR_UNSUPPORTED && !c->slot_retry) {
@@ -599,6 +622,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         }
     }
     if (err3) return err3;
+    if (*(int32_t *)hfin) return *(int32_t *)hfin;
     c->res_sb.resize(S);
     for (uint32_t s = 0; s < S; ++s) {
         const SbState &x = h_sb[s];
@@ -620,33 +644,6 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         }
         rk.stream_bytes = b;
     }
-    // ---- pack ----
-    HIPCHK(c, hipMemsetAsync(d_out, 0, (size_t)std::min<uint64_t>(out_cap, (total + 15) & ~15ull), st));
-    { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
-    { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
-    if ((rc = fork())) return rc;
-    { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
-    if (sq_reg || sq_chunk) {
-        // LDS staging of a tile's output, sized from what the sub-blocks really need (+25 %; a tile that
-        // needs more writes straight to the zeroed output)
-        uint32_t sw_q = 0, sw_d = 0;
-        const uint64_t trec = (uint64_t)R * 5 / 4;
-        for (uint32_t s = 0; s < S; ++s) {
-            const SbState &x = h_sb[s];
-            const uint32_t nr = x.n_rec ? x.n_rec : 1;
-            sw_q = std::max(sw_q, (uint32_t)(((uint64_t)x.qbits * trec / nr) / 32) + 64);
-            sw_d = std::max(sw_d, (uint32_t)(((uint64_t)x.dbits * trec / nr) / 32) + 64);
-        }
-        if (sq_chunk) { KScope k(c, st, "k_ck_pack"); launch_ck_pack(st, A, max_rec, TR, max_rec_bytes, sw_q, sw_d); }
-        else { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
-    }
-    else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
-    else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
-    if ((rc = join())) return rc;
-    HIPCHK(c, hipMemcpyAsync(hp, d_err, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    HIPCHK(c, hipGetLastError());
-    if (*(int32_t *)hp) return *(int32_t *)hp;
     return NGSC_OK;
 }
 

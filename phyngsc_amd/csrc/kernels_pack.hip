@@ -359,7 +359,23 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_sq(Arena A, uint32_t lds_en
     }
 }
 
+// Zeroes the part of the output buffer that the sub-blocks will occupy (its size is on the device: no host round trip).
+// Shared words - the first / last word of a tile, a record, a stream - are merged with atomicOr by the pack kernels.
+__global__ __launch_bounds__(256) void k_zero_output(uint4 *out, const uint64_t *total_ptr, uint64_t out_cap)
+{
+    uint64_t total = *total_ptr;
+    if (total > out_cap) total = out_cap;
+    const uint64_t n16 = (total + 15) >> 4;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (uint64_t)gridDim.x * blockDim.x)
+        out[k] = make_uint4(0, 0, 0, 0);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
+void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap)
+{
+    hipLaunchKernelGGL(k_zero_output, dim3(4096), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), total_ptr, out_cap & ~15ull);
+}
+
 static uint32_t lds_entries_for(uint32_t qrows)
 {
     uint64_t e = (uint64_t)qrows * 96;

@@ -46,6 +46,7 @@ void launch_huffman_text(hipStream_t st, const Arena &A);
 void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_scan_sb(hipStream_t st, const Arena &A);
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out);
+void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap);
 void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off);
 void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);

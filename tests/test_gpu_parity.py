@@ -105,6 +105,16 @@ def test_against_oracle(eng, name, cfg, size, P):
     assert out == want
 
 
+@pytest.mark.parametrize("name,cfg,size,P", ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
+def test_chunk_path_against_oracle(eng, monkeypatch, name, cfg, size, P):
+    """The chunk-per-lane sequence/quality kernels (NGSC_SQ_PATH=chunk) on the generated cases."""
+    monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
+    data = fastq_gen.generate(cfg, target_bytes=size // 2)
+    _, out = _gpu(eng, data, P)
+    want, _ = orc.compress_file(data, P, threads=8)
+    assert out == want
+
+
 PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "title_numeric.p3", "title_long.p2",
               "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
 
@@ -430,6 +440,13 @@ def test_edge_cases(eng, name):
     want, _ = orc.compress_file(data, P)
     assert out == want
     assert orc.decompress(out) == data
+    import os as _os
+    _os.environ["NGSC_SQ_PATH"] = "chunk"      # ... and through the chunk-per-lane sequence/quality kernels
+    try:
+        _, out2 = _gpu(eng, data, P)
+    finally:
+        del _os.environ["NGSC_SQ_PATH"]
+    assert out2 == want
 
 
 @pytest.mark.parametrize("seed", range(0, 64))
