@@ -49,6 +49,7 @@ struct ngsc_ctx {
     bool debug_sync = getenv("NGSC_DEBUG_SYNC") != nullptr;
     std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
     uint32_t min_text_slots = 0;  // text-field table slots the last call turned out to need (kept for the next call)
+    uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
@@ -586,12 +587,16 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
     if (sq_reg || sq_chunk) {
-        // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's longest
-        // length, + 25 % (from the job's maxima: no stream size has to come back to the host first; a tile that needs
+        // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
+        // length, + 25 % (from the record count: no stream size has to come back to the host first; a tile that needs
         // more writes straight to the zeroed output)
+        // (average read length from the record count: a record is a title, two lines of the read's length and four more bytes)
         const uint64_t trec = (uint64_t)R * 5 / 4;
-        const uint32_t sw_q = (uint32_t)(trec * max_q * 5 / 32) + 64;
-        const uint32_t sw_d = (uint32_t)(trec * max_q * 5 / 64) + 64;
+        // ... and, once a call has been through, from the bits per base it saw: jobs of one file look alike)
+        const uint64_t avg_l = std::min<uint64_t>(max_q, (uint64_t)len / n_rec_total / 2 + 1);
+        const uint64_t qx = c->qbits_x16 ? c->qbits_x16 + 4 : 80, dx = c->dbits_x16 ? c->dbits_x16 + 2 : 40;
+        const uint32_t sw_q = (uint32_t)(trec * avg_l * qx / 16 / 32) + 64;
+        const uint32_t sw_d = (uint32_t)(trec * avg_l * dx / 16 / 32) + 64;
         if (sq_chunk) { KScope k(c, st, "k_ck_pack"); launch_ck_pack(st, A, max_rec, TR, max_rec_bytes, sw_q, sw_d); }
         else { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
@@ -624,8 +629,13 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (err3) return err3;
     if (*(int32_t *)hfin) return *(int32_t *)hfin;
     c->res_sb.resize(S);
+    c->qbits_x16 = c->dbits_x16 = 0;
     for (uint32_t s = 0; s < S; ++s) {
         const SbState &x = h_sb[s];
+        if (x.n_bases) {
+            c->qbits_x16 = std::max<uint32_t>(c->qbits_x16, (uint32_t)(((uint64_t)x.qbits * 16 + x.n_bases - 1) / x.n_bases));
+            c->dbits_x16 = std::max<uint32_t>(c->dbits_x16, (uint32_t)(((uint64_t)x.dbits * 16 + x.n_bases - 1) / x.n_bases));
+        }
         ngsc_subblock_t &r = c->res_sb[s];
         r.rank = x.rank; r.n_records = x.n_rec; r.win_pos = cuts[s].win_pos; r.wsize = cuts[s].wsize;
         r.out_off = x.out_off;

@@ -347,21 +347,42 @@ struct SqTabs {
     uint32_t lds_rows;
 };
 
+// Rows of SQ_QS entries: column q - 33 for the bytes 33..80, column 48 always zero, SQ_QROWS_EXTRA zero rows behind the
+// table.  The lean paths of measure and pack replace every byte that has no entry (behind the end of the read, a
+// transferred quality) by SQ_QPAD: it reads the zero entry, and the 16 lookups of a chunk are straight-line code.
+constexpr uint32_t SQ_QS = SR_HCOLS + 1;
+constexpr uint32_t SQ_QPAD = 0x51515151u;        // 33 + 48 in every byte
+constexpr uint32_t SQ_QROWS_EXTRA = 17;          // pad bytes of the last chunk, and the (q - 33) & 63 reach of the general path
 template <class T>
 __device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const SbState &sb, T *s_qtab, uint32_t lds_rows)
 {
     const uint32_t nq = sb.nqual;
     const uint32_t *qg = A.qcodes + (size_t)s * A.qrows * 256;
-    for (uint32_t k = threadIdx.x; k < lds_rows * SR_HCOLS; k += SR_THREADS) s_qtab[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (lds_rows + SQ_QROWS_EXTRA) * SQ_QS; k += SR_THREADS) s_qtab[k] = 0;
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < lds_rows * nq; k += SR_THREADS) {
         const uint32_t row = k / nq, ci = k % nq;
         const uint32_t col = (uint32_t)sb.qualities[ci] - 33u;
         if (col < SR_HCOLS) {
             const uint32_t e = qg[(size_t)row * 256 + ci];
-            s_qtab[row * SR_HCOLS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
+            s_qtab[row * SQ_QS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
         }
     }
+}
+
+// May the lean paths run on this sub-block?  Every alphabet symbol below 128 has a table column (the symbols from 128 on are
+// transferred qualities, or raw bytes with the high bit set, which the lean paths test for per chunk) and every row is in
+// the table.  Whole workgroup; thread = alphabet index.
+__device__ __forceinline__ bool sq_lean_alphabet(const SbState &sb, uint32_t lds_rows, uint32_t *s_flag)
+{
+    if (threadIdx.x == 0) *s_flag = 0;
+    __syncthreads();
+    if (threadIdx.x < sb.nqual) {
+        const uint32_t q = sb.qualities[threadIdx.x];
+        if (q < 128 && (q < 33 || q > 32 + SR_HCOLS)) atomicOr(s_flag, 1u);
+    }
+    __syncthreads();
+    return *s_flag == 0 && lds_rows > sb.max_q;
 }
 
 // entry (code << 5 | len) of quality byte q at position row-1, any q, any row
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     for (uint32_t b = 0; b < 4; ++b) {
                         const uint32_t u = 4 * k + b;
                         const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
-                        l[b] = s_qlen[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
+                        l[b] = s_qlen[row * SQ_QS + ((sr_byte(qw, u) - 33u) & 63u)];
                     }
                     if (__any((qpatch >> (4 * k)) & 15u)) {
 #pragma unroll
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 if (by_list && nall > k) {
                     const uint32_t pos = ((k < 2 ? ap.x : ap.y) >> (16 * (k & 1))) & 0xffffu, row = pos + 1;
                     const uint32_t q = A.buf[q0 + pos], col = q - 33;
-                    const uint32_t l_tab = (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SR_HCOLS + col] : (sq_qentry_slow(T, row, q) & 31u);
+                    const uint32_t l_tab = (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SQ_QS + col] : (sq_qentry_slow(T, row, q) & 31u);
                     const uint32_t qt = transfer_quality(s_amb[A.buf[s0 + pos]], (uint8_t)q);   // phyNGSC.cpp:579
                     qb += (sq_qentry_slow(T, row, qt) & 31u) - l_tab;
                 }
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     const uint32_t tile_last = tile_first + tpw < ntiles ? tile_first + tpw : ntiles;
     const int tid = threadIdx.x;
     uint32_t *s_qtab = s_dynw;
-    uint32_t *st_q = s_dynw + lds_rows * SR_HCOLS, *st_d = st_q + sw_q;
+    uint32_t *st_q = s_dynw + (lds_rows + SQ_QROWS_EXTRA) * SQ_QS, *st_d = st_q + sw_q;
 
     s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
     s_qcode[tid] = sb.qua_code[tid];
@@ -592,6 +613,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     if ((s_dcode[tid] & 31u) > 8) atomicOr(&s_longcode, 1u);
     __syncthreads();
     const bool short_codes = !s_longcode;
+    __shared__ uint32_t s_leanflag;
+    const bool lean_wg = sq_lean_alphabet(sb, lds_rows, &s_leanflag);
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
@@ -664,6 +687,106 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                     const uint4 S = Sb[kb], Q = Qb[kb];
                     const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
                     const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+                    // ---- lean path: alphabet inside the table (sq_lean_alphabet) and no high bit in this chunk's bytes ----
+                    if (lean_wg && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
+                        const bool tails = __any(nv != 16);
+                        uint32_t vmk[4] = {~0u, ~0u, ~0u, ~0u}, idx[4], dacc = 0;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            uint32_t w = sw[k];
+                            if (tails) {
+                                vmk[k] = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                                w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
+                            }
+                            idx[k] = sr_idx(w);
+                            dacc |= sr_not_acgt(w, idx[k]);
+                        }
+                        uint32_t ambm = 0, keep[4] = {vmk[0], vmk[1], vmk[2], vmk[3]};
+                        if (__any(dacc != 0)) {
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
+                                const uint32_t a01 = t_nonzero01(sr_not_acgt(w, idx[k]));
+                                ambm |= t_movemask(a01) << (4 * k);
+                                if (xfer) keep[k] &= ~(a01 * 0xffu);   // transferred qualities: patched below (phyNGSC.cpp:579)
+                            }
+                        }
+                        const uint32_t qpatch = xfer ? ambm : 0u;
+                        const bool masked = tails || __any(qpatch != 0);
+                        // quality: 16 entries in flight together (bytes without an entry read the zero column)
+                        const uint32_t rbase = (16 * ch + 1) * SQ_QS - 33u;
+                        uint32_t e[16];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t qm = masked ? ((qw[k] & keep[k]) | (SQ_QPAD & ~keep[k])) : qw[k];
+#pragma unroll
+                            for (uint32_t b = 0; b < 4; ++b) e[4 * k + b] = s_qtab[rbase + (4 * k + b) * SQ_QS + ((qm >> (8 * b)) & 0xffu)];
+                        }
+                        if (__any(qpatch)) {
+                            // all loads first, one wait (a load consumed inside its own predicated block is a memory round
+                            // trip per patched position of the wave)
+                            uint32_t t[16];
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; ++u) {
+                                t[u] = 0;
+                                if ((qpatch >> u) & 1u) {
+                                    const uint32_t q = transfer_quality(s_amb[sr_byte(sw, u)], (uint8_t)sr_byte(qw, u));
+                                    t[u] = sq_qentry_slow(T, 16 * ch + 1 + u, q);
+                                }
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; ++u) e[u] = ((qpatch >> u) & 1u) ? t[u] : e[u];
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            if (tails && !__any(nv > 4 * k)) continue;
+                            const uint32_t e0 = e[4 * k], e1 = e[4 * k + 1], e2 = e[4 * k + 2], e3 = e[4 * k + 3];
+                            const uint32_t l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
+                            const uint32_t tl = (e0 & 31u) + l1 + l2 + l3;
+                            if (__any(tl > 32)) {
+                                wq_.put(e0 >> 5, e0 & 31u); wq_.put(e1 >> 5, l1); wq_.put(e2 >> 5, l2); wq_.put(e3 >> 5, l3);
+                            } else {
+                                wq_.put(((((((e0 >> 5) << l1) | (e1 >> 5)) << l2) | (e2 >> 5)) << l3) | (e3 >> 5), tl);
+                            }
+                        }
+                        // DNA (tasks.cpp:544-557)
+                        if (plain && !__any(ambm != 0)) {
+                            if (nv) {
+                                uint32_t x = 0;
+#pragma unroll
+                                for (uint32_t k = 0; k < 4; ++k)
+                                    x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
+                                wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
+                            }
+                        } else if (short_codes) {
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                if (!__any(nv > 4 * k)) continue;
+                                uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vmk[k], c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vmk[k];
+                                if (__any((ambm >> (4 * k)) & 15u)) {
+#pragma unroll
+                                    for (uint32_t b = 0; b < 4; ++b) {
+                                        if ((ambm >> (4 * k + b)) & 1u) {
+                                            const uint32_t ee = xfer ? 0u : s_dcode[sr_byte(sw, 4 * k + b)];
+                                            l4 = (l4 & ~(0xffu << (8 * b))) | ((ee & 31u) << (8 * b));
+                                            c4 = (c4 & ~(0xffu << (8 * b))) | ((ee >> 5) << (8 * b));
+                                        }
+                                    }
+                                }
+                                const uint32_t l1 = (l4 >> 8) & 0xffu, l2 = (l4 >> 16) & 0xffu, l3 = l4 >> 24;
+                                const uint32_t c = (((((c4 & 0xffu) << l1) | ((c4 >> 8) & 0xffu)) << l2 | ((c4 >> 16) & 0xffu)) << l3) | (c4 >> 24);
+                                wd_.put(c, (l4 & 0xffu) + l1 + l2 + l3);
+                            }
+                        } else {
+#pragma unroll
+                            for (uint32_t u = 0; u < 16; ++u) {
+                                if (u < nv) {
+                                    const uint32_t c = sr_byte(sw, u);
+                                    if (!(xfer && s_amb[c] > 1)) { const uint32_t ee = s_dcode[c]; wd_.put(ee >> 5, ee & 31u); }
+                                }
+                            }
+                        }
+                    } else {
                     uint32_t qbad = 0, dacc = 0, idx[4];
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
@@ -703,7 +826,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                             for (uint32_t b = 0; b < 4; ++b) {
                                 const uint32_t u = 4 * k + b;
                                 const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
-                                e[b] = s_qtab[row * SR_HCOLS + ((sr_byte(qw, u) - 33u) & 63u)];
+                                e[b] = s_qtab[row * SQ_QS + ((sr_byte(qw, u) - 33u) & 63u)];
                             }
                             if (__any((qpatch >> (4 * k)) & 15u)) {
 #pragma unroll
@@ -771,6 +894,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                             }
                         }
                     }
+                    }   // (general path)
                 }
             }
         }
@@ -834,7 +958,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 
 static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)
 {
-    const uint32_t max_rows = budget / (SR_HCOLS * entry_bytes);
+    const uint32_t max_rows = budget / (SQ_QS * entry_bytes) - SQ_QROWS_EXTRA;
     return qrows < max_rows ? qrows : max_rows;
 }
 
@@ -844,7 +968,7 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     auto kern = sr_burst(A) ? k_sq_measure_reg<true> : k_sq_measure_reg<false>;
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (size_t)rows * SR_HCOLS + 64, st, A, rows, tpw);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw);
 }
 
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
@@ -854,7 +978,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     if (sw_d > 6144) sw_d = 6144;
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
-    const size_t lds = ((size_t)rows * SR_HCOLS + sw_q + sw_d) * 4;
+    const size_t lds = ((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + sw_q + sw_d) * 4;
     // one chunk per trip: with NB chunks fetched back to back this kernel is 8-10 % slower on every configuration (it
     // is bound by its bit writers, not by the loads), so only that variant is built
     auto kern = k_sq_pack_reg<false>;

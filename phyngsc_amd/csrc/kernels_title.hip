@@ -584,13 +584,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
 
 // Title of one record as 16 * W dwords (bytes past the title are other lines' bytes: every use masks by length),
 // written to the lane's LDS column, plus its separator / digit masks.
+// r0w: record 0's title as dwords (zero padded); diffmask: bit p set where byte p differs from record 0's byte p
 template <uint32_t W>
 __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
-                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W])
+                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W], const uint32_t *r0w, uint64_t (&diffmask)[W])
 {
-    uint32_t sp32[2 * W], dg32[2 * W];
+    uint32_t sp32[2 * W], dg32[2 * W], df32[2 * W];
 #pragma unroll
-    for (uint32_t k = 0; k < 2 * W; ++k) sp32[k] = dg32[k] = 0;
+    for (uint32_t k = 0; k < 2 * W; ++k) sp32[k] = dg32[k] = df32[k] = 0;
 #pragma unroll
     for (uint32_t m = 0; m < 4 * W; ++m) {
         uint4 q = make_uint4(0, 0, 0, 0);
@@ -605,6 +606,7 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
                 const uint32_t sh = 4 * ((4 * m + j) & 7);
                 sp32[m >> 1] |= sp << sh;
                 dg32[m >> 1] |= dg << sh;
+                df32[m >> 1] |= t_movemask(t_nonzero01(w[j] ^ r0w[4 * m + j])) << sh;
             }
         }
         s_w[4 * m + 0][tid] = q.x;
@@ -618,6 +620,7 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
         const uint64_t keep = t_lowbits(tlen > 64 * k ? tlen - 64 * k : 0);
         sepmask[k] = (((uint64_t)sp32[2 * k + 1] << 32) | sp32[2 * k]) & keep;
         digmask[k] = (((uint64_t)dg32[2 * k + 1] << 32) | dg32[2 * k]) & keep;
+        diffmask[k] = ((uint64_t)df32[2 * k + 1] << 32) | df32[2 * k];
     }
 }
 
@@ -666,8 +669,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     const uint32_t ls = A.ls[g], te = A.te[g];
     const uint32_t tlen = valid ? te - ls + 1 : 0;            // title bytes including the closing newline
 
-    uint64_t sepmask[W], digmask[W];
-    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask);
+    uint64_t sepmask[W], digmask[W], diffmask[W];
+    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, reinterpret_cast<const uint32_t *>(s_r0.title), diffmask);
     uint32_t nsep = 0;
 #pragma unroll
     for (uint32_t k = 0; k < W; ++k) {
@@ -682,8 +685,27 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         const uint32_t len = t_next_set<W>(sepmask, pos);
         const uint32_t minlen = len < len0 ? len : len0;
 
-        // compare with record 0's field, eight bytes per step
+        // A field that starts where record 0's field starts (every lane of the wave; true for all fields in front of the
+        // first one whose length varies) is compared through the title-wide difference mask: its bits [pos, pos + len)
+        // are the field's differing bytes.  No funnel-shifted LDS reads, no eight-byte steps.
         uint32_t w0 = 0, w1 = 0, diff = 0, c8 = 0;
+        const uint32_t pos0 = s_r0.start[f];
+        const bool aligned = len0 <= 64 && !__any(valid && (pos != pos0 || len > 64));
+        if (aligned) {
+            const uint64_t fd = t_window<W>(diffmask, pos0);
+            diff = (fd & t_lowbits(len0)) != 0 ? 1u : 0u;
+            const uint64_t hm = fd & t_lowbits(minlen);   // Hamming mask: tasks.cpp:187-193
+            if (__any(valid && hm != 0)) {
+                if (owned && (uint32_t)hm) t_lds_or(&s_stat[f * 24 + 10], (uint32_t)hm);
+                if (owned && (uint32_t)(hm >> 32)) t_lds_or(&s_stat[f * 24 + 11], (uint32_t)(hm >> 32));
+            }
+            if (kk != 0xff && __any(valid && !(len == len0 && diff == 0))) {   // the value parser below wants the field's first bytes
+                t_field8<W>(s_w, tid, pos, w0, w1);
+                const uint64_t km = t_lowbytes(len);
+                w0 &= (uint32_t)km;
+                w1 &= (uint32_t)(km >> 32);
+            }
+        } else
         do {
             uint32_t x0, x1;
             t_field8<W>(s_w, tid, pos + 8 * c8, x0, x1);
