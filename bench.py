@@ -298,7 +298,7 @@ def run_distributed(args, world: int):
         # the one (data-path-free) collective: block sizes -> file offsets (RCCL all-gather over xGMI)
         sizes_local, meta_local = sh.block_sizes()
         sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=cdev)
-        api.file_offsets(sizes_all)
+        api.file_offsets(sizes_all, api.ranks_per_group(sh.file_size, sh.P))
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -373,7 +373,7 @@ def run_threads(args):
     for sh in shares:
         s, _ = sh.block_sizes()
         sizes_all.extend(s)
-    api.file_offsets(sizes_all)
+    api.file_offsets(sizes_all, api.ranks_per_group(shares[0].file_size, shares[0].P))
     total_raw = sum(sh.my_raw for sh in shares)
     total_out = sum(sh.res.total_bytes for sh in shares)
     sh0 = shares[0]

@@ -121,6 +121,28 @@ int ngsc_compress_device(ngsc_ctx *ctx, const void *d_buf, uint64_t buf_len, uin
                          uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap,
                          void *hip_stream);
 
+/*
+ * One rank walked in several calls: the reference streams a rank's region through 8 MiB windows whatever its size
+ * (phyNGSC.cpp:113-128, 168, 745-755); a region of 4 GiB and more does not fit one ngsc_compress_device() job.
+ * *state: zero-initialised for the rank's first part (d_buf then starts at or before the rank's region, as above);
+ * afterwards it holds where the rank's loop stands - next_pos is the file offset the next part's buffer has to start at
+ * or before - and done == 1 once the rank is finished.  A call compresses every window whose records are complete in the
+ * buffer (all of them when the buffer reaches the end of the region or of the file) and leaves the results as
+ * ngsc_compress_device() does: one rank entry, the sub-blocks of this part.  NGSC_ERR_UNSUPPORTED: not even one window fits.
+ */
+typedef struct {
+    uint64_t next_pos;     /* file offset of the rank's next window = of its first record */
+    uint64_t bytes_read;   /* p_bytes_read so far (phyNGSC.cpp:745-746) */
+    uint64_t bsize;        /* size of the next window (phyNGSC.cpp:748-755) */
+    uint32_t overlap;      /* overlap in force for it */
+    uint32_t done;
+    int32_t overlap_used;  /* wr_ov_used of the rank (phyNGSC.cpp:160), set by its first part */
+    uint32_t resume;       /* 0 before the first part */
+} ngsc_rank_part_t;
+int ngsc_compress_rank_part(ngsc_ctx *ctx, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
+                            uint32_t P, uint32_t rank, ngsc_rank_part_t *state, void *d_out, uint64_t out_cap,
+                            void *hip_stream);
+
 uint64_t ngsc_result_bytes(ngsc_ctx *ctx);
 uint32_t ngsc_result_num_subblocks(ngsc_ctx *ctx);
 uint32_t ngsc_result_num_ranks(ngsc_ctx *ctx);
@@ -138,22 +160,31 @@ uint32_t ngsc_make_footer(uint8_t *out, uint32_t P, uint64_t fastq_size, uint32_
                           const int32_t *overlaps, const uint32_t *cbo, const uint32_t *lb_sizes);
 
 /*
+ * Block order of the files this library writes (the reference's is arrival order, different from run to run): ranks in
+ * groups of consecutive ranks whose regions make up at most NGSC_ORDER_GROUP_BYTES of input (floor(512 MiB / (file_size /
+ * P)) ranks, at least one), group after group; inside a group round k = k-th block of each of its ranks, ranks
+ * ascending.  A file of up to 512 MiB is one group.  A group's place depends only on the groups in front of it, so the
+ * driver writes each group while the next one is compressed.
+ */
+#define NGSC_ORDER_GROUP_BYTES (512ull << 20)
+
+/*
  * `<in.fastq> <out.ngsc>` (phyNGSC.cpp:61-108) with P virtual ranks on this context's GPU: reads the
- * file, uploads it, compresses, assembles blocks in the deterministic order "round k = k-th block of
- * every rank" and writes blocks + footer.  seconds_out (nullable, 3 doubles): read, H2D+device+D2H, plan+write.
+ * file job by job, uploads, compresses, and writes each group's blocks at its place (above) while the next
+ * job runs; footer at the end.  seconds_out (nullable, 3 doubles): read, H2D+device+D2H+write (overlapped), footer.
  */
 int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, uint32_t P, double *seconds_out);
 
 /*
  * The same job spread over n_ctx contexts (normally one per GPU of the node) from ONE process: the
- * P virtual ranks are dealt to the contexts in contiguous runs of P / n_ctx (P % n_ctx == 0), each
- * context's ranks run on its own host thread and device, and the blocks are assembled as above --
+ * groups of the block order are dealt to the contexts in turn (group g to context g % n_ctx; P % n_ctx == 0),
+ * each context works on its own host threads and device, and every group is written at its place --
  * so the file is byte-identical for every n_ctx.  This replaces the reference's `mpiexec -np P`
  * fan-out (phyNGSC.cpp:45-57, 113-116) when one host drives several GPUs; there is no device-to-
  * device traffic, only the per-rank block lists meet on the host (phyNGSC.cpp:875-1057).
- * Files of any size: every context walks its ranks in jobs of consecutive ranks below the engine's
- * 4 GiB job limit, reading each job's byte range from the file itself; only one rank's region
- * (file_size / P) has to stay below 4 GiB.
+ * Files and rank regions of any size: a context walks its groups in jobs of consecutive ranks, and a rank whose
+ * region is larger than a job in parts (ngsc_compress_rank_part), reading each job's byte range from the file
+ * itself; host memory holds two jobs' input and output, not the file.
  */
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
                              double *seconds_out);

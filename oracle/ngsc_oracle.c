@@ -1050,15 +1050,26 @@ int ngsc_o_compress_file(const uint8_t *fastq, uint64_t size, uint32_t P, int th
         uint32_t *lbs = (uint32_t *)malloc(sizeof(uint32_t) * P);
         uint64_t off = 0;
         uint32_t bi = 0;
-        /* deterministic order: round k = k-th block of every rank (replaces arrival order,
-           phyNGSC.cpp:875/925 MPI_File_write_shared + :997-1009 timestamp sort) */
-        for (uint32_t k = 0; k < maxb; ++k)
-            for (uint32_t r = 0; r < P; ++r)
-                if (k < ro[r].n_blocks) {
-                    memcpy(o + off, ro[r].blocks[k], ro[r].block_len[k]);
-                    off += ro[r].block_len[k];
-                    cbo[bi++] = r;
-                }
+        /* deterministic order (replaces arrival order, phyNGSC.cpp:875/925 MPI_File_write_shared + :997-1009
+           timestamp sort): ranks in groups of consecutive ranks whose regions make up at most 512 MiB of input,
+           group after group; inside a group round k = k-th block of each of its ranks.  (The order equal-speed ranks
+           produce when a node works through the file 512 MiB at a time; one group = the whole file up to 512 MiB.) */
+        uint64_t region = size / P;
+        uint32_t rpg = region ? (uint32_t)((512ull << 20) / region) : P;
+        if (rpg < 1) rpg = 1;
+        if (rpg > P) rpg = P;
+        (void)maxb;
+        for (uint32_t g0 = 0; g0 < P; g0 += rpg) {
+            uint32_t g1 = g0 + rpg < P ? g0 + rpg : P, gmax = 0;
+            for (uint32_t r = g0; r < g1; ++r) if (ro[r].n_blocks > gmax) gmax = ro[r].n_blocks;
+            for (uint32_t k = 0; k < gmax; ++k)
+                for (uint32_t r = g0; r < g1; ++r)
+                    if (k < ro[r].n_blocks) {
+                        memcpy(o + off, ro[r].blocks[k], ro[r].block_len[k]);
+                        off += ro[r].block_len[k];
+                        cbo[bi++] = r;
+                    }
+        }
         for (uint32_t r = 0; r < P; ++r) { ov[r] = ro[r].overlap_used; lbs[r] = ro[r].last_block_size; }
         off += ngsc_o_make_footer(o + off, P, size, nb, nsb, ov, cbo, lbs);
         *out = o;

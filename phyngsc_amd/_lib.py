@@ -17,7 +17,7 @@ EXPORTS = [
     "ngsc_set_profiling", "ngsc_reset_kernel_times", "ngsc_get_kernel_times", "ngsc_compress_device",
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
-    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only",
+    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -39,6 +39,13 @@ class SubBlock(ctypes.Structure):
 class Rank(ctypes.Structure):
     _fields_ = [("rank", ctypes.c_uint32), ("n_subblocks", ctypes.c_uint32), ("first_subblock", ctypes.c_uint32),
                 ("overlap_used", ctypes.c_int32), ("stream_off", ctypes.c_uint64), ("stream_bytes", ctypes.c_uint64)]
+
+
+class RankPart(ctypes.Structure):
+    """ngsc_rank_part_t: where a rank's loop stands between the calls of ngsc_compress_rank_part()."""
+    _fields_ = [("next_pos", ctypes.c_uint64), ("bytes_read", ctypes.c_uint64), ("bsize", ctypes.c_uint64),
+                ("overlap", ctypes.c_uint32), ("done", ctypes.c_uint32), ("overlap_used", ctypes.c_int32),
+                ("resume", ctypes.c_uint32)]
 
 
 class Block(ctypes.Structure):
@@ -86,6 +93,8 @@ def lib():
     L.ngsc_get_kernel_times.argtypes = [vp, ctypes.POINTER(KernelTime), u32]
     L.ngsc_compress_device.restype = ctypes.c_int
     L.ngsc_compress_device.argtypes = [vp, vp, u64, u64, u64, u32, u32, u32, vp, u64, vp]
+    L.ngsc_compress_rank_part.restype = ctypes.c_int
+    L.ngsc_compress_rank_part.argtypes = [vp, vp, u64, u64, u64, u32, u32, ctypes.POINTER(RankPart), vp, u64, vp]
     L.ngsc_result_bytes.restype = u64
     L.ngsc_result_bytes.argtypes = [vp]
     L.ngsc_result_num_subblocks.restype = u32

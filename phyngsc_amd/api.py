@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import Block, KernelTime, NgscError, Rank, SubBlock
+from ._lib import Block, KernelTime, NgscError, Rank, RankPart, SubBlock
 
 WINDOW = 1 << 23   # READ_BUFFER_SIZE, defs.h:20
 OVERLAP = 500      # phyNGSC.cpp:48
@@ -119,6 +119,28 @@ class Engine:
             ctypes.memmove(rks, rp, ctypes.sizeof(rks))
         return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
 
+    def compress_rank_part(self, d_in, file_size: int, P: int, rank: int, state: RankPart, buf_off: int, out=None,
+                           stream: Optional[int] = None) -> DeviceResult:
+        """One part of a rank that is walked in several calls (ngsc.h: ngsc_compress_rank_part): every window whose
+        records are complete in d_in; ``state`` (zero-initialised before the first part) is updated in place."""
+        import torch
+        if out is None:
+            out = torch.empty(int(d_in.numel() * 0.6) + (16 << 20), dtype=torch.uint8, device=d_in.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_in.device).cuda_stream
+        rc = self._L.ngsc_compress_rank_part(self._h, d_in.data_ptr(), d_in.numel(), buf_off, file_size, P, rank,
+                                             ctypes.byref(state), out.data_ptr(), out.numel(), ctypes.c_void_p(stream))
+        if rc:
+            raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
+        nsb = self._L.ngsc_result_num_subblocks(self._h)
+        nrk = self._L.ngsc_result_num_ranks(self._h)
+        sbs, rks = (SubBlock * nsb)(), (Rank * nrk)()
+        if nsb:
+            ctypes.memmove(sbs, self._L.ngsc_result_subblocks(self._h), ctypes.sizeof(sbs))
+        if nrk:
+            ctypes.memmove(rks, self._L.ngsc_result_ranks(self._h), ctypes.sizeof(rks))
+        return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
+
     def compress_file(self, in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
         """``<in.fastq> <out.ngsc>`` on this GPU; returns (read, H2D+device+D2H, plan+write) seconds."""
         sec = (ctypes.c_double * 3)()
@@ -173,13 +195,27 @@ def make_footer(P: int, fastq_size: int, n_subblocks: int, overlaps: Sequence[in
     return bytes(out[:n])
 
 
-def round_robin_order(blocks_per_rank: Sequence[int]) -> List[Tuple[int, int]]:
-    """Deterministic block order: round k = k-th block of every rank, ranks ascending."""
+ORDER_GROUP_BYTES = 512 << 20   # NGSC_ORDER_GROUP_BYTES (ngsc.h): part of the definition of the block order
+
+
+def ranks_per_group(file_size: int, P: int) -> int:
+    """Consecutive ranks whose regions make up at most 512 MiB of input form a group of the block order."""
+    region = file_size // P
+    return max(1, min(P, ORDER_GROUP_BYTES // region)) if region else P
+
+
+def round_robin_order(blocks_per_rank: Sequence[int], ranks_per_grp: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Deterministic block order: rank groups in turn (``ranks_per_group``; one group when None); inside a group
+    round k = k-th block of each of its ranks, ranks ascending."""
+    P = len(blocks_per_rank)
+    rpg = ranks_per_grp or max(P, 1)
     order = []
-    for k in range(max(blocks_per_rank, default=0)):
-        for r, nb in enumerate(blocks_per_rank):
-            if k < nb:
-                order.append((r, k))
+    for g0 in range(0, P, rpg):
+        grp = range(g0, min(P, g0 + rpg))
+        for k in range(max((blocks_per_rank[r] for r in grp), default=0)):
+            for r in grp:
+                if k < blocks_per_rank[r]:
+                    order.append((r, k))
     return order
 
 
@@ -193,7 +229,7 @@ def assemble_container(res: DeviceResult, P: int, fastq_size: int) -> bytes:
         rank_blocks.append(plan_blocks(P, rk.rank, sizes))
     parts = []
     cbo = []
-    for r, k in round_robin_order([len(b) for b in rank_blocks]):
+    for r, k in round_robin_order([len(b) for b in rank_blocks], ranks_per_group(fastq_size, P)):
         b = rank_blocks[r][k]
         base = res.ranks[r].stream_off + b.stream_off
         parts.append(bytes(b.header[:b.header_len]))
@@ -258,11 +294,11 @@ def exchange_block_sizes(local_sizes: List[List[int]], local_meta: List[Tuple[in
     return sizes, meta
 
 
-def file_offsets(sizes_per_rank: Sequence[Sequence[int]]):
+def file_offsets(sizes_per_rank: Sequence[Sequence[int]], ranks_per_grp: Optional[int] = None):
     """Exclusive prefix sum over the deterministic block order -> {(rank, k): file offset}, cbo, end."""
     off = 0
     table, cbo = {}, []
-    for r, k in round_robin_order([len(s) for s in sizes_per_rank]):
+    for r, k in round_robin_order([len(s) for s in sizes_per_rank], ranks_per_grp):
         table[(r, k)] = off
         off += sizes_per_rank[r][k]
         cbo.append(r)

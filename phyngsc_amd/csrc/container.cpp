@@ -4,7 +4,8 @@
 //
 // Block order: the reference appends blocks with MPI_File_write_shared in arrival order and records
 // it in the footer's CBO list; any order that keeps each rank's blocks in sequence is a valid file
-// (tasks.cpp:1282-1292).  We use the deterministic order "round k = k-th block of every rank".
+// (tasks.cpp:1282-1292).  We use a deterministic order: groups of consecutive ranks (at most 512 MiB of input each), and
+// inside a group "round k = k-th block of each of its ranks" (see ranks_per_group() below).
 #include "../../include/ngsc.h"
 #include "ngsc_common.h"
 
@@ -143,30 +144,59 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool write_all(int fd, const void *p, size_t n)
+static bool pwrite_all(int fd, const void *p, size_t n, uint64_t off)
 {
     const uint8_t *b = (const uint8_t *)p;
     while (n) {
-        ssize_t w = ::write(fd, b, n);
+        ssize_t w = ::pwrite(fd, b, n, (off_t)off);
         if (w <= 0) return false;
         b += w;
         n -= (size_t)w;
+        off += (uint64_t)w;
     }
     return true;
 }
 
-// One worker = one context (= one GPU).  It walks its virtual ranks in JOBS of consecutive ranks of about 512 MiB
-// (NGSC_JOB_BYTES sets the size; the engine's own limit is 4 GiB per job): a job's byte range is read from the file
-// into pinned memory, uploaded, compressed, and its sub-block streams brought back.  Workers share nothing but the file.
-struct Worker {
-    ngsc_ctx *ctx = nullptr;
-    uint32_t rank_lo = 0, rank_hi = 0;
-    int rc = NGSC_OK;
-    double io_s = 0;                        // time spent reading the file
-    std::vector<uint8_t *> chunks;          // one pinned buffer per job: its sub-block bytes, rank after rank
-    std::vector<const uint8_t *> rank_ptr;  // per entry of ranks: where that rank's stream starts
-    std::vector<ngsc_rank_t> ranks;         // first_subblock into sb_sizes
-    std::vector<uint32_t> sb_sizes;         // per sub-block, in result order
+// ---- block order --------------------------------------------------------------------------------------------------
+// Ranks in groups of consecutive ranks whose regions make up at most NGSC_ORDER_GROUP_BYTES of input, group after
+// group; inside a group round k = k-th block of each of its ranks.  A group's place in the file depends only on the
+// groups in front of it, so a group is written as soon as it is compressed: host memory holds a group, not the file.
+static uint32_t ranks_per_group(uint64_t FS, uint32_t P)
+{
+    const uint64_t region = FS / P;
+    uint64_t rpg = region ? NGSC_ORDER_GROUP_BYTES / region : P;
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(P, rpg));
+}
+
+// What the workers share: the output file and the place of the next group in it.
+struct Sink {
+    int fd = -1;
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t next_group = 0;   // the group whose blocks go to `cursor`
+    uint64_t cursor = 0;
+    bool fail = false;
+    std::vector<uint32_t> cbo;             // WRID of every block in file order
+    std::vector<int32_t> ov;               // per rank
+    std::vector<uint32_t> lbs, nblocks;    // per rank: last block size, block count
+    uint32_t n_sub_total = 0;
+    // waits for the group's turn; returns false when another worker failed
+    bool begin_group(uint32_t g)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return fail || next_group == g; });
+        return !fail;
+    }
+    void end_group()
+    {
+        { std::lock_guard<std::mutex> lk(m); ++next_group; }
+        cv.notify_all();
+    }
+    void abort()
+    {
+        { std::lock_guard<std::mutex> lk(m); fail = true; }
+        cv.notify_all();
+    }
 };
 
 static uint64_t job_limit()
@@ -184,72 +214,125 @@ static void job_range(uint64_t FS, uint32_t P, uint32_t a, uint32_t b, uint64_t 
     hi = std::min<uint64_t>(FS, (uint64_t)g1.wr_end + 1 + 65536);
 }
 
-// Two-stage pipeline per worker: a reader thread fills one of two pinned buffers from the file and uploads it
-// while the worker thread compresses the previous job and brings its streams back.
-struct JobPipe {
-    std::mutex m;
-    std::condition_variable cv;
-    int uploaded = 0;    // jobs whose input is in device memory
-    int consumed = 0;    // jobs whose compression is finished (their input buffers are free again)
-    int reader_rc = NGSC_OK;
-    bool abort = false;
+// One unit of device work: consecutive whole ranks [a, b) of one group, or one PART of a rank whose region is larger
+// than a job (ngsc_compress_rank_part; the parts' buffers overlap by a window and a record, so that every part starts at
+// or before the window its predecessor left).
+struct Job {
+    uint32_t group, a, b;
+    uint64_t lo, hi;       // byte range of the file the job's buffer holds
+    bool part, first_part, last_of_group;
+    bool stream;           // part of a rank that is a group of its own: its blocks are written as they fill
+    bool last_part;        // the part that reaches the end of the rank's region
+};
+constexpr uint64_t PART_OVERLAP = (uint64_t)WINDOW + 65536;   // a window + the longest record a part boundary allows
+
+// One worker = one context (= one GPU) and every n-th group.  A reader thread fills one of two pinned buffers from the
+// file and uploads it while the worker thread compresses the previous job; a writer thread brings the sub-block streams
+// back into one of two pinned buffers, plans the blocks and writes them at the group's place while the next job runs.
+struct Worker {
+    ngsc_ctx *ctx = nullptr;
+    uint32_t index = 0, n_workers = 1;
+    int rc = NGSC_OK;
+    double io_s = 0, t_comp = 0, t_wait_in = 0, t_wait_out = 0, t_d2h = 0, t_write = 0;
 };
 
-static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
+struct Pipe {
+    std::mutex m;
+    std::condition_variable cv;
+    int uploaded = 0;      // jobs whose input is in device memory
+    int compressed = 0;    // jobs whose compression is finished (input buffers free again, output waits for the writer)
+    int written = 0;       // jobs whose output has left its device / pinned buffers
+    int rc = NGSC_OK;
+    bool abort = false;
+    void fail(int code)
+    {
+        { std::lock_guard<std::mutex> lk(m); if (!rc) rc = code; abort = true; }
+        cv.notify_all();
+    }
+};
+
+// results of one job, copied out of the context before the next job overwrites them
+struct JobResult {
+    uint64_t total = 0;
+    std::vector<ngsc_rank_t> ranks;
+    std::vector<uint32_t> sb_sizes;
+    ngsc_rank_part_t part;
+};
+
+static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, uint32_t P)
 {
     const int dev = ngsc_ctx_device(w->ctx);
-    if (hipSetDevice(dev) != hipSuccess) { w->rc = NGSC_ERR_HIP; return; }
-    const uint64_t limit = job_limit();
-    // the jobs, and the largest one (buffers are allocated once)
-    std::vector<std::pair<uint32_t, uint32_t>> jobs;
+    if (hipSetDevice(dev) != hipSuccess) { w->rc = NGSC_ERR_HIP; sink->abort(); return; }
+    const uint64_t limit = std::min<uint64_t>(job_limit(), 0xE0000000ull);
+    const uint32_t rpg = ranks_per_group(FS, P), n_groups = (P + rpg - 1) / rpg;
+    // ---- the jobs of this worker's groups ----
+    std::vector<Job> jobs;
     uint64_t max_len = 0;
-    for (uint32_t a = w->rank_lo; a < w->rank_hi;) {
-        uint32_t b = a + 1;
-        uint64_t lo, hi;
-        job_range(FS, P, a, b, lo, hi);
-        if (hi - lo >= 0xFFFFFF00ull) { w->rc = NGSC_ERR_UNSUPPORTED; return; }   // one rank alone is too big: use more ranks
-        while (b < w->rank_hi) {
-            uint64_t lo2, hi2;
-            job_range(FS, P, a, b + 1, lo2, hi2);
-            if (hi2 - lo2 > limit) break;
-            ++b;
-            hi = hi2;
+    for (uint32_t g = w->index; g < n_groups; g += w->n_workers) {
+        const uint32_t g0 = g * rpg, g1 = std::min(P, g0 + rpg);
+        for (uint32_t a = g0; a < g1;) {
+            uint64_t lo, hi;
+            job_range(FS, P, a, a + 1, lo, hi);
+            if (hi - lo > limit) {   // one rank alone is more than a job: walk it in parts
+                const uint64_t rank_hi = hi;
+                const uint64_t rank_end = std::min<uint64_t>(FS, (uint64_t)rank_geometry(FS, P, a).wr_end + 1);
+                bool first = true;
+                if (limit <= 2 * PART_OVERLAP) { w->rc = NGSC_ERR_ARG; sink->abort(); return; }
+                for (uint64_t p = lo;; p = (p + limit - PART_OVERLAP) & ~15ull) {
+                    uint64_t e = std::min<uint64_t>(rank_hi, p + limit);
+                    if (e >= rank_end) e = rank_hi;   // the part that reaches the end of the region finishes the rank
+                    jobs.push_back({g, a, a + 1, p, e, true, first, false, g1 - g0 == 1, e == rank_hi});
+                    max_len = std::max(max_len, e - p);
+                    first = false;
+                    if (e == rank_hi) break;
+                }
+                ++a;
+            } else {
+                uint32_t b = a + 1;
+                while (b < g1) {
+                    uint64_t lo2, hi2;
+                    job_range(FS, P, a, b + 1, lo2, hi2);
+                    if (hi2 - lo2 > limit) break;
+                    ++b;
+                    hi = hi2;
+                }
+                jobs.push_back({g, a, b, lo, hi, false, false, false, false, false});
+                max_len = std::max(max_len, hi - lo);
+                a = b;
+            }
         }
-        max_len = std::max(max_len, hi - lo);
-        jobs.emplace_back(a, b);
-        a = b;
+        jobs.back().last_of_group = true;
     }
-    const double t_alloc0 = now_s();
+    if (jobs.empty()) return;
     const int nbuf = jobs.size() > 1 ? 2 : 1;
-    void *d_in[2] = {nullptr, nullptr}, *h_in[2] = {nullptr, nullptr}, *d_out = nullptr;
-    hipStream_t copy_stream = nullptr;
+    void *d_in[2] = {nullptr, nullptr}, *h_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+    hipStream_t in_stream = nullptr, out_stream = nullptr;
     const uint64_t out_cap = max_len + (max_len >> 2) + (64u << 20);
+    const double t_alloc0 = now_s();
     for (int i = 0; i < nbuf && !w->rc; ++i)
-        if (hipMalloc(&d_in[i], max_len + 64) != hipSuccess || hipHostMalloc(&h_in[i], max_len + 64, hipHostMallocDefault) != hipSuccess)
+        if (hipMalloc(&d_in[i], max_len + 64) != hipSuccess || hipHostMalloc(&h_in[i], max_len + 64, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&d_out[i], out_cap) != hipSuccess || hipHostMalloc(&h_out[i], out_cap, hipHostMallocDefault) != hipSuccess)
             w->rc = NGSC_ERR_HIP;
-    if (!w->rc && (hipMalloc(&d_out, out_cap) != hipSuccess || hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess))
+    if (!w->rc && (hipStreamCreateWithFlags(&in_stream, hipStreamNonBlocking) != hipSuccess ||
+                   hipStreamCreateWithFlags(&out_stream, hipStreamNonBlocking) != hipSuccess))
         w->rc = NGSC_ERR_HIP;
-
-    const bool verbose = getenv("NGSC_VERBOSE") != nullptr;
-    double t_comp = 0, t_d2h = 0, t_wait = 0;
     const double t_alloc = now_s() - t_alloc0;
-    JobPipe pipe;
-    std::thread reader;
+    Pipe pipe;
+    std::vector<JobResult> results(jobs.size());
+    std::thread reader, writer;
     if (!w->rc) {
+        // ---- reader: file -> pinned -> device, one job ahead ----
         reader = std::thread([&]() {
-            int rc = NGSC_OK;
-            int fd = -1;
+            int rc = NGSC_OK, fd = -1;
             if (hipSetDevice(dev) != hipSuccess) rc = NGSC_ERR_HIP;
             else if ((fd = ::open(in_path, O_RDONLY)) < 0) rc = NGSC_ERR_IO;
             for (size_t j = 0; j < jobs.size() && !rc; ++j) {
                 {   // buffer j % nbuf is free once job j - nbuf has been compressed
                     std::unique_lock<std::mutex> lk(pipe.m);
-                    pipe.cv.wait(lk, [&] { return pipe.abort || pipe.consumed + nbuf > (int)j; });
+                    pipe.cv.wait(lk, [&] { return pipe.abort || pipe.compressed + nbuf > (int)j; });
                     if (pipe.abort) break;
                 }
-                uint64_t lo, hi;
-                job_range(FS, P, jobs[j].first, jobs[j].second, lo, hi);
-                const uint64_t len = hi - lo;
+                const uint64_t lo = jobs[j].lo, len = jobs[j].hi - jobs[j].lo;
                 uint8_t *hb = (uint8_t *)h_in[j % nbuf];
                 const double t0 = now_s();
                 uint64_t got = 0;
@@ -260,80 +343,215 @@ static void run_worker(Worker *w, const char *in_path, uint64_t FS, uint32_t P)
                 }
                 w->io_s += now_s() - t0;
                 if (got != len) { rc = NGSC_ERR_IO; break; }
-                if (hipMemcpyAsync(d_in[j % nbuf], hb, len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
-                    hipStreamSynchronize(copy_stream) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-                {
-                    std::lock_guard<std::mutex> lk(pipe.m);
-                    pipe.uploaded = (int)j + 1;
-                }
+                if (hipMemcpyAsync(d_in[j % nbuf], hb, len, hipMemcpyHostToDevice, in_stream) != hipSuccess ||
+                    hipStreamSynchronize(in_stream) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+                { std::lock_guard<std::mutex> lk(pipe.m); pipe.uploaded = (int)j + 1; }
                 pipe.cv.notify_all();
             }
             if (fd >= 0) ::close(fd);
-            {
-                std::lock_guard<std::mutex> lk(pipe.m);
-                pipe.reader_rc = rc;
-                if (rc) pipe.abort = true;
+            if (rc) pipe.fail(rc);
+        });
+        // ---- writer: device -> pinned, block plan, pwrite at the group's place ----
+        writer = std::thread([&]() {
+            int rc = NGSC_OK;
+            if (hipSetDevice(dev) != hipSuccess) rc = NGSC_ERR_HIP;
+            // the group being collected
+            struct RankAcc { uint32_t rank; int32_t ov; std::vector<uint32_t> sb; std::vector<uint8_t> carry; uint64_t carry_base = 0;
+                             uint32_t emitted = 0; uint32_t last_size = 0; };
+            std::vector<RankAcc> acc;         // ranks of the current group, in rank order (carry: a rank's stream when the
+                                              // group came in more than one job)
+            bool holding_turn = false;        // a single rank walked in parts writes its blocks as they fill
+            std::vector<ngsc_block_t> blocks;
+            auto plan = [&](RankAcc &ra) -> int {
+                uint64_t bytes = 0;
+                for (uint32_t x : ra.sb) bytes += x;
+                const uint32_t capb = (uint32_t)(bytes / (NGSC_BLOCK_SIZE - 4096)) + 4;
+                blocks.resize(capb);
+                uint32_t nb = 0;
+                int r = ngsc_plan_blocks(P, ra.rank, ra.sb.data(), (uint32_t)ra.sb.size(), blocks.data(), capb, &nb);
+                blocks.resize(r ? 0 : nb);
+                return r;
+            };
+            for (size_t j = 0; j < jobs.size() && !rc; ++j) {
+                {
+                    std::unique_lock<std::mutex> lk(pipe.m);
+                    pipe.cv.wait(lk, [&] { return pipe.abort || pipe.compressed > (int)j; });
+                    if (pipe.abort) break;
+                }
+                const Job &jb = jobs[j];
+                const JobResult &res = results[j];
+                uint8_t *hb = (uint8_t *)h_out[j % nbuf];
+                double t0 = now_s();
+                if (res.total && (hipMemcpyAsync(hb, d_out[j % nbuf], res.total, hipMemcpyDeviceToHost, out_stream) != hipSuccess ||
+                                  hipStreamSynchronize(out_stream) != hipSuccess)) { rc = NGSC_ERR_HIP; break; }
+                w->t_d2h += now_s() - t0;
+                t0 = now_s();
+                const bool single_job_group = !jb.part && jb.last_of_group && acc.empty();
+                // collect the job's ranks
+                const size_t acc0 = acc.size();
+                for (size_t k = 0; k < res.ranks.size(); ++k) {
+                    const ngsc_rank_t &rk = res.ranks[k];
+                    if (jb.part && !jb.first_part) {   // the same rank goes on
+                        RankAcc &ra = acc.back();
+                        ra.sb.insert(ra.sb.end(), res.sb_sizes.begin(), res.sb_sizes.end());
+                        ra.carry.insert(ra.carry.end(), hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
+                    } else {
+                        RankAcc ra;
+                        ra.rank = rk.rank;
+                        ra.ov = jb.part ? res.part.overlap_used : rk.overlap_used;
+                        ra.sb.assign(res.sb_sizes.begin() + rk.first_subblock, res.sb_sizes.begin() + rk.first_subblock + rk.n_subblocks);
+                        if (!single_job_group) ra.carry.assign(hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
+                        acc.push_back(std::move(ra));
+                    }
+                }
+                (void)acc0;
+                if (jb.part && jb.stream) {
+                    // ---- one rank, its blocks written as they fill (the group is this rank: its blocks follow each other) ----
+                    RankAcc &ra = acc.back();
+                    if (!holding_turn) {
+                        if (!sink->begin_group(jb.group)) { rc = NGSC_ERR_IO; break; }
+                        holding_turn = true;
+                    }
+                    if ((rc = plan(ra))) break;
+                    const bool done = res.part.done != 0;
+                    const uint32_t upto = done ? (uint32_t)blocks.size() : (blocks.empty() ? 0 : (uint32_t)blocks.size() - 1);
+                    bool okw = true;
+                    uint64_t drop_to = ra.carry_base;
+                    for (uint32_t k = ra.emitted; k < upto && okw; ++k) {
+                        const ngsc_block_t &b = blocks[k];
+                        okw = pwrite_all(sink->fd, b.header, b.header_len, sink->cursor) &&
+                              pwrite_all(sink->fd, ra.carry.data() + (b.stream_off - ra.carry_base), b.payload, sink->cursor + b.header_len);
+                        sink->cursor += b.size;            // (this worker holds the turn: nobody else moves the cursor)
+                        sink->cbo.push_back(ra.rank);
+                        ra.last_size = b.size;
+                        drop_to = b.stream_off + b.payload;
+                    }
+                    if (!okw) { rc = NGSC_ERR_IO; break; }
+                    ra.emitted = upto;
+                    ra.carry.erase(ra.carry.begin(), ra.carry.begin() + (size_t)(drop_to - ra.carry_base));
+                    ra.carry_base = drop_to;
+                    if (done) {
+                        sink->ov[ra.rank] = ra.ov; sink->lbs[ra.rank] = ra.last_size; sink->nblocks[ra.rank] = ra.emitted;
+                        sink->n_sub_total += (uint32_t)ra.sb.size();
+                    }
+                }
+                if (jb.last_of_group) {
+                    if (holding_turn) {
+                        holding_turn = false;
+                        sink->end_group();
+                    } else {
+                        // ---- whole ranks: plan every rank's blocks, take the group's place, write round by round ----
+                        std::vector<std::vector<ngsc_block_t>> rb(acc.size());
+                        uint32_t maxb = 0;
+                        uint64_t gbytes = 0;
+                        for (size_t k = 0; k < acc.size() && !rc; ++k) {
+                            if ((rc = plan(acc[k]))) break;
+                            rb[k] = blocks;
+                            maxb = std::max<uint32_t>(maxb, (uint32_t)rb[k].size());
+                            for (auto &b : rb[k]) gbytes += b.size;
+                        }
+                        if (rc) break;
+                        if (!sink->begin_group(jb.group)) { rc = NGSC_ERR_IO; break; }
+                        uint64_t off = sink->cursor;
+                        sink->cursor += gbytes;
+                        std::vector<std::pair<uint64_t, std::pair<size_t, uint32_t>>> todo;   // offset, (rank slot, block)
+                        for (uint32_t k = 0; k < maxb; ++k)
+                            for (size_t r = 0; r < acc.size(); ++r)
+                                if (k < rb[r].size()) {
+                                    todo.push_back({off, {r, k}});
+                                    off += rb[r][k].size;
+                                    sink->cbo.push_back(acc[r].rank);
+                                }
+                        for (size_t r = 0; r < acc.size(); ++r) {
+                            sink->ov[acc[r].rank] = acc[r].ov;
+                            sink->lbs[acc[r].rank] = rb[r].empty() ? 0 : rb[r].back().size;
+                            sink->nblocks[acc[r].rank] = (uint32_t)rb[r].size();
+                            sink->n_sub_total += (uint32_t)acc[r].sb.size();
+                        }
+                        sink->end_group();   // the place is taken: later groups may go on while these bytes are written
+                        bool okw = true;
+                        for (auto &t : todo) {
+                            const size_t r = t.second.first;
+                            const ngsc_block_t &b = rb[r][t.second.second];
+                            const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
+                            okw = okw && pwrite_all(sink->fd, b.header, b.header_len, t.first) &&
+                                  pwrite_all(sink->fd, stream + b.stream_off, b.payload, t.first + b.header_len);
+                        }
+                        if (!okw) { rc = NGSC_ERR_IO; break; }
+                    }
+                    acc.clear();
+                }
+                w->t_write += now_s() - t0;
+                { std::lock_guard<std::mutex> lk(pipe.m); pipe.written = (int)j + 1; }
+                pipe.cv.notify_all();
             }
-            pipe.cv.notify_all();
+            if (rc) { pipe.fail(rc); sink->abort(); }
         });
     }
+    // ---- the worker thread itself: compress job after job ----
+    ngsc_rank_part_t part;
+    memset(&part, 0, sizeof part);
     for (size_t j = 0; j < jobs.size() && !w->rc; ++j) {
         double t0 = now_s();
         {
             std::unique_lock<std::mutex> lk(pipe.m);
             pipe.cv.wait(lk, [&] { return pipe.abort || pipe.uploaded > (int)j; });
-            if (pipe.abort) { w->rc = pipe.reader_rc ? pipe.reader_rc : NGSC_ERR_IO; break; }
+            if (pipe.abort) break;
         }
-        t_wait += now_s() - t0;
+        w->t_wait_in += now_s() - t0;
         t0 = now_s();
-        uint64_t lo, hi;
-        job_range(FS, P, jobs[j].first, jobs[j].second, lo, hi);
-        w->rc = ngsc_compress_device(w->ctx, d_in[j % nbuf], hi - lo, lo, FS, P, jobs[j].first, jobs[j].second, d_out, out_cap, nullptr);
-        if (w->rc) break;
-        t_comp += now_s() - t0;
+        {   // output buffer j % nbuf is free once job j - nbuf has been written
+            std::unique_lock<std::mutex> lk(pipe.m);
+            pipe.cv.wait(lk, [&] { return pipe.abort || pipe.written + nbuf > (int)j; });
+            if (pipe.abort) break;
+        }
+        w->t_wait_out += now_s() - t0;
         t0 = now_s();
-        const uint64_t total = ngsc_result_bytes(w->ctx);
-        void *chunk = nullptr;   // pinned: a pageable destination makes the copy run at ~2 GB/s
-        if (hipHostMalloc(&chunk, total + 64, hipHostMallocDefault) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
-        w->chunks.push_back((uint8_t *)chunk);
-        if (total && hipMemcpy(chunk, d_out, total, hipMemcpyDeviceToHost) != hipSuccess) { w->rc = NGSC_ERR_HIP; break; }
-        t_d2h += now_s() - t0;
+        const Job &jb = jobs[j];
+        int rc;
+        if (jb.part) {
+            if (jb.first_part) memset(&part, 0, sizeof part);
+            else if (part.done || part.next_pos < jb.lo || part.next_pos >= jb.hi) { pipe.fail(NGSC_ERR_UNSUPPORTED); break; }   // a record longer than the parts' overlap
+            rc = ngsc_compress_rank_part(w->ctx, d_in[j % nbuf], jb.hi - jb.lo, jb.lo, FS, P, jb.a, &part, d_out[j % nbuf], out_cap, nullptr);
+            if (!rc && jb.last_part != (part.done != 0)) rc = NGSC_ERR_UNSUPPORTED;
+        } else {
+            rc = ngsc_compress_device(w->ctx, d_in[j % nbuf], jb.hi - jb.lo, jb.lo, FS, P, jb.a, jb.b, d_out[j % nbuf], out_cap, nullptr);
+        }
+        if (rc) { pipe.fail(rc); break; }
+        w->t_comp += now_s() - t0;
+        JobResult &res = results[j];
+        res.total = ngsc_result_bytes(w->ctx);
+        res.part = part;
         const ngsc_subblock_t *sbs = ngsc_result_subblocks(w->ctx);
         const ngsc_rank_t *rks = ngsc_result_ranks(w->ctx);
         const uint32_t nr = ngsc_result_num_ranks(w->ctx), ns = ngsc_result_num_subblocks(w->ctx);
-        const uint32_t sb_base = (uint32_t)w->sb_sizes.size();
-        for (uint32_t k = 0; k < nr; ++k) {
-            ngsc_rank_t rk = rks[k];
-            w->rank_ptr.push_back((const uint8_t *)chunk + rk.stream_off);
-            rk.first_subblock += sb_base;
-            w->ranks.push_back(rk);
-        }
-        for (uint32_t k = 0; k < ns; ++k) w->sb_sizes.push_back(sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len);
-        {
-            std::lock_guard<std::mutex> lk(pipe.m);
-            pipe.consumed = (int)j + 1;
-        }
+        res.ranks.assign(rks, rks + nr);
+        res.sb_sizes.resize(ns);
+        for (uint32_t k = 0; k < ns; ++k) res.sb_sizes[k] = sbs[k].info_len + sbs[k].title_len + sbs[k].qual_len + sbs[k].dna_len;
+        { std::lock_guard<std::mutex> lk(pipe.m); pipe.compressed = (int)j + 1; }
         pipe.cv.notify_all();
     }
-    if (reader.joinable()) {
-        {
-            std::lock_guard<std::mutex> lk(pipe.m);
-            if (w->rc) pipe.abort = true;
-        }
-        pipe.cv.notify_all();
-        reader.join();
-        if (!w->rc && pipe.reader_rc) w->rc = pipe.reader_rc;
+    {   // let the threads run out (or stop them)
+        std::unique_lock<std::mutex> lk(pipe.m);
+        pipe.cv.wait(lk, [&] { return pipe.abort || pipe.written >= (int)jobs.size(); });
     }
+    if (reader.joinable()) reader.join();
+    if (writer.joinable()) writer.join();
+    if (!w->rc && pipe.rc) w->rc = pipe.rc;
+    if (w->rc) sink->abort();
     const double t_free = now_s();
     for (int i = 0; i < 2; ++i) {
         if (d_in[i]) (void)hipFree(d_in[i]);
         if (h_in[i]) (void)hipHostFree(h_in[i]);
+        if (d_out[i]) (void)hipFree(d_out[i]);
+        if (h_out[i]) (void)hipHostFree(h_out[i]);
     }
-    if (d_out) (void)hipFree(d_out);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
-    if (verbose)
-        fprintf(stderr, "[ngsc] device %d: %zu jobs, buffers %.3f s (alloc, before the first job), wait-for-input %.3f s, compress %.3f s, "
-                        "D2H %.3f s, file read %.3f s (overlapped), free %.3f s\n", dev, jobs.size(), t_alloc, t_wait, t_comp, t_d2h, w->io_s, now_s() - t_free);
+    if (in_stream) (void)hipStreamDestroy(in_stream);
+    if (out_stream) (void)hipStreamDestroy(out_stream);
+    if (getenv("NGSC_VERBOSE"))
+        fprintf(stderr, "[ngsc] device %d: %zu jobs, buffers %.3f s (alloc, before the first job), waits: input %.3f s, output buffer %.3f s; "
+                        "compress %.3f s; beside it: file read %.3f s, D2H %.3f s, plan + write %.3f s; free %.3f s\n", dev, jobs.size(), t_alloc,
+                w->t_wait_in, w->t_wait_out, w->t_comp, w->io_s, w->t_d2h, w->t_write, now_s() - t_free);
 }
 
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
@@ -346,71 +564,41 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     struct stat sbuf;
     if (::stat(in_path, &sbuf) != 0 || sbuf.st_size <= 0) return NGSC_ERR_IO;
     const uint64_t FS = (uint64_t)sbuf.st_size;
+    Sink sink;
+    sink.fd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (sink.fd < 0) return NGSC_ERR_IO;
+    sink.ov.assign(P, 0);
+    sink.lbs.assign(P, 0);
+    sink.nblocks.assign(P, 0);
     double t1 = now_s();
 
-    // virtual ranks are dealt to the contexts in contiguous runs (P is a multiple of the context count)
+    // the groups of the block order are dealt to the contexts in turn: group g to context g % n_ctx
     std::vector<Worker> workers(n_ctx);
-    const uint32_t per = P / n_ctx;
-    for (uint32_t i = 0; i < n_ctx; ++i) { workers[i].ctx = ctxs[i]; workers[i].rank_lo = i * per; workers[i].rank_hi = (i + 1) * per; }
-    if (n_ctx == 1) run_worker(&workers[0], in_path, FS, P);
+    for (uint32_t i = 0; i < n_ctx; ++i) { workers[i].ctx = ctxs[i]; workers[i].index = i; workers[i].n_workers = n_ctx; }
+    if (n_ctx == 1) run_worker(&workers[0], &sink, in_path, FS, P);
     else {
         std::vector<std::thread> th;
-        for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], in_path, FS, P);
+        for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], &sink, in_path, FS, P);
         for (auto &t : th) t.join();
     }
     double t2 = now_s();
-    auto free_chunks = [&]() {
-        for (auto &w : workers) {
-            for (uint8_t *c : w.chunks) (void)hipHostFree(c);
-            w.chunks.clear();
-        }
-    };
+    int rc = NGSC_OK;
     for (auto &w : workers)
-        if (w.rc) { const int rc = w.rc; free_chunks(); return rc; }
-
-    // container: blocks of every rank, deterministic order, footer (phyNGSC.cpp:842-1057)
-    std::vector<std::vector<ngsc_block_t>> rb(P);
-    std::vector<int32_t> ov(P);
-    std::vector<uint32_t> lbs(P);
-    std::vector<const uint8_t *> stream(P);
-    uint32_t n_sub_total = 0, max_blocks = 0, n_blocks_total = 0;
-    for (auto &w : workers) {
-        for (size_t ri = 0; ri < w.ranks.size(); ++ri) {
-            const ngsc_rank_t &rk = w.ranks[ri];
-            const uint32_t r = rk.rank;
-            uint32_t capb = (uint32_t)(rk.stream_bytes / (NGSC_BLOCK_SIZE - 4096)) + 4, nb = 0;
-            rb[r].resize(capb);
-            int rc = ngsc_plan_blocks(P, r, w.sb_sizes.data() + rk.first_subblock, rk.n_subblocks, rb[r].data(), capb, &nb);
-            if (rc) { free_chunks(); return rc; }
-            rb[r].resize(nb);
-            ov[r] = rk.overlap_used;
-            lbs[r] = nb ? rb[r][nb - 1].size : 0;
-            stream[r] = w.rank_ptr[ri];
-            n_sub_total += rk.n_subblocks;
-            n_blocks_total += nb;
-            max_blocks = std::max(max_blocks, nb);
-        }
+        if (w.rc) { rc = w.rc; break; }
+    bool okw = !sink.fail;
+    if (!rc && okw) {
+        // footer (phyNGSC.cpp:930-1057)
+        const uint32_t n_blocks_total = (uint32_t)sink.cbo.size();
+        std::vector<uint8_t> footer(256 + 4 * (size_t)n_blocks_total + 8 * (size_t)P);
+        uint32_t fl = ngsc_make_footer(footer.data(), P, FS, n_blocks_total, sink.n_sub_total, sink.ov.data(), sink.cbo.data(), sink.lbs.data());
+        okw = pwrite_all(sink.fd, footer.data(), fl, sink.cursor);
     }
-    int ofd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (ofd < 0) { free_chunks(); return NGSC_ERR_IO; }
-    std::vector<uint32_t> cbo;
-    bool okw = true;
-    for (uint32_t k = 0; k < max_blocks && okw; ++k)
-        for (uint32_t r = 0; r < P && okw; ++r)
-            if (k < rb[r].size()) {
-                const ngsc_block_t &b = rb[r][k];
-                okw = write_all(ofd, b.header, b.header_len) && write_all(ofd, stream[r] + b.stream_off, b.payload);
-                cbo.push_back(r);
-            }
-    std::vector<uint8_t> footer(256 + 4 * (size_t)n_blocks_total + 8 * (size_t)P);
-    uint32_t fl = ngsc_make_footer(footer.data(), P, FS, n_blocks_total, n_sub_total, ov.data(), cbo.data(), lbs.data());
-    okw = okw && write_all(ofd, footer.data(), fl);
-    ::close(ofd);
+    ::close(sink.fd);
     double t3 = now_s();
-    free_chunks();
     double io = 0;
     for (auto &w : workers) io = std::max(io, w.io_s);
     if (seconds_out) { seconds_out[0] = (t1 - t0) + io; seconds_out[1] = (t2 - t1) - io; seconds_out[2] = t3 - t2; }
+    if (rc) return rc;
     return okw ? NGSC_OK : NGSC_ERR_IO;
 }
 

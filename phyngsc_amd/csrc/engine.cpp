@@ -267,21 +267,31 @@ uint32_t ngsc_result_num_ranks(ngsc_ctx *c) { return c ? (uint32_t)c->res_rank.s
 const ngsc_subblock_t *ngsc_result_subblocks(ngsc_ctx *c) { return c ? c->res_sb.data() : nullptr; }
 const ngsc_rank_t *ngsc_result_ranks(ngsc_ctx *c) { return c ? c->res_rank.data() : nullptr; }
 
-int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
-                         uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream)
+}  // extern "C"
+
+// The whole path for ranks [rank_lo, rank_hi).  part != nullptr: ONE rank, walked in several calls (ngsc_compress_rank_part):
+// from tells where its loop stands (resume == 0: at its first record), the buffer may end before the rank does, and
+// *part receives where the loop stands afterwards.
+static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
+                         uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream,
+                         const PlanResume &from, ngsc_rank_part_t *part)
 {
     if (!c || !d_buf || !d_out || P < 2 || rank_lo >= rank_hi || rank_hi > P || !file_size) return NGSC_ERR_ARG;
     if (buf_len == 0 || buf_len >= 0xFFFFFF00ull || buf_off + buf_len > file_size) return NGSC_ERR_ARG;
     if (((uintptr_t)d_buf & 15) || ((uintptr_t)d_out & 15)) return NGSC_ERR_ARG;
     if (file_size / P == 0) return NGSC_ERR_ARG;
     const uint32_t n_ranks = rank_hi - rank_lo;
+    if (part && n_ranks != 1) return NGSC_ERR_ARG;
     {
         RankGeom g0 = rank_geometry(file_size, P, rank_lo), g1 = rank_geometry(file_size, P, rank_hi - 1);
-        if (rank_lo == 0 ? buf_off != 0 : (int64_t)buf_off > g0.wr_start) return NGSC_ERR_ARG;
-        // the buffer must reach the end of the last rank's region (+ the reference's overlap) or EOF
+        if (from.resume) {
+            if (buf_off > from.next_pos || from.next_pos >= buf_off + buf_len) return NGSC_ERR_ARG;
+        } else if (rank_lo == 0 ? buf_off != 0 : (int64_t)buf_off > g0.wr_start) return NGSC_ERR_ARG;
+        // the buffer must reach the end of the last rank's region (+ the reference's overlap) or EOF - unless the rank is
+        // walked in parts
         uint64_t need_end = (uint64_t)g1.wr_end + 1;
         if (need_end > file_size) need_end = file_size;
-        if (buf_off + buf_len < need_end) return NGSC_ERR_ARG;
+        if (!part && buf_off + buf_len < need_end) return NGSC_ERR_ARG;
     }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -335,7 +345,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- stage A: line index ----
     {
         KScope k(c, st, "k_sync_first");
-        launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err);
+        launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err, from.resume ? from.next_pos : 0);
     }
     { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask, buf_off + buf_len == file_size); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
@@ -343,7 +353,8 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     {
         KScope k(c, st, "k_cuts_validate");
         launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
-                             max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr);
+                             max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr, from,
+                             part ? buf_off + buf_len : 0);
     }
     // ---- sync 2: cut list ----
     size_t plan_bytes = cs.off - o_plans;
@@ -367,7 +378,13 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         for (uint32_t k = 0; k < h_plans[i].n_cuts; ++k) cuts.push_back(h_cuts[(size_t)i * max_cuts + k]);
     }
     const uint32_t S = (uint32_t)cuts.size();
-    if (!S) return NGSC_ERR_FORMAT;
+    if (part) {
+        part->next_pos = h_plans[0].next_pos; part->bytes_read = h_plans[0].bytes_read; part->bsize = h_plans[0].bsize;
+        part->overlap = h_plans[0].overlap; part->done = h_plans[0].done;
+        if (!from.resume) part->overlap_used = h_plans[0].overlap_used;
+        part->resume = 1;
+    }
+    if (!S) return part && !part->done ? NGSC_ERR_UNSUPPORTED /* not one window fits the buffer */ : NGSC_ERR_FORMAT;
     // per-record arrays
     const size_t rec_cap = (size_t)n_rec_total + 2;
     // Arrays whose per-record values depend on the sub-block (title bits, cached fields, candidate values, payload bit
@@ -619,7 +636,7 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             int r = NGSC_ERR_UNSUPPORTED;
             for (uint32_t want = std::max(asked, 2 * n_slots);; want *= 2) {
                 c->min_text_slots = want;
-                r = ngsc_compress_device(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream);
+                r = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
                 if (r != NGSC_ERR_UNSUPPORTED || want >= S * MAX_FIELDS) break;
             }
             c->slot_retry = false;
@@ -655,6 +672,29 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         rk.stream_bytes = b;
     }
     return NGSC_OK;
+}
+
+extern "C" {
+
+int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
+                         uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream)
+{
+    PlanResume from;
+    memset(&from, 0, sizeof from);
+    return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, nullptr);
+}
+
+int ngsc_compress_rank_part(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size, uint32_t P,
+                            uint32_t rank, ngsc_rank_part_t *state, void *d_out, uint64_t out_cap, void *hip_stream)
+{
+    if (!state || state->done) return NGSC_ERR_ARG;
+    PlanResume from;
+    memset(&from, 0, sizeof from);
+    if (state->resume) {
+        from.resume = 1; from.next_pos = state->next_pos; from.bytes_read = state->bytes_read; from.bsize = state->bsize;
+        from.overlap = state->overlap;
+    }
+    return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank, rank + 1, d_out, out_cap, hip_stream, from, state);
 }
 
 }  // extern "C"

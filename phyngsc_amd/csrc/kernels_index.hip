@@ -205,12 +205,21 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
 // First-record synchronisation of every virtual rank > 0 (phyNGSC.cpp:131-156): first '@' at or after
 // the region start, then the first newline after it; if the byte after that newline is '@' the record
 // starts there, otherwise at the first '@'.  One wave per rank, 64 bytes per step.
+// resume_abs != 0: the rank is taken up at this file offset (the first record of its next window): nothing to search.
 __global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size,
                                                    uint32_t P, uint32_t rank_lo, uint64_t *first_abs, uint32_t *start_rel,
-                                                   int32_t *err)
+                                                   int32_t *err, uint64_t resume_abs)
 {
     const uint32_t r = rank_lo + blockIdx.x;
     const int lane = threadIdx.x;
+    if (resume_abs) {
+        if (lane == 0) {
+            if (resume_abs < buf_off || resume_abs - buf_off >= len) atomicMin(err, (int32_t)ERR_ARG);
+            first_abs[blockIdx.x] = resume_abs;
+            if (blockIdx.x == 0) *start_rel = (uint32_t)(resume_abs - buf_off);
+        }
+        return;
+    }
     RankGeom g = rank_geometry(file_size, P, r);
     if (r == 0) {
         if (lane == 0) { first_abs[blockIdx.x] = 0; if (blockIdx.x == 0) *start_rel = 0; }
@@ -288,7 +297,8 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
                                                        uint64_t buf_off, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
                                                        const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                                                        uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
-                                                       uint32_t *max_title, int32_t *err, const uint8_t *tail_buf)
+                                                       uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, PlanResume from,
+                                                       uint64_t buf_end_abs)
 {
     const uint32_t n_rec_total = *total_lines / 4;
     // tail_buf: the job buffer when it ends where the file ends.  Two real newlines behind the last complete record (the
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
         if (threadIdx.x >= 64) return;   // one wave per rank; all lanes run the (uniform) planner, the searches are wave-wide
         const uint32_t i = blockIdx.x;
         int rc = plan_rank_with(WaveSearch(), file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
-                                cuts + (size_t)i * max_cuts, max_cuts, &plans[i]);
+                                cuts + (size_t)i * max_cuts, max_cuts, &plans[i], &from, buf_end_abs);
         // ... and behind the first record of a window the loop does not skip that byte (phyNGSC.cpp:295-300): there two
         // blank lines qualify as well
         if (!rc && tail_buf && (*total_lines & 3u) == 3u && n_rec_total) {
@@ -323,10 +333,10 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
 uint32_t index_num_tiles(uint32_t len) { return len / TILE_BYTES + 1; }   // covers position len itself (assumed final newline)
 
 void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
-                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err)
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs)
 {
     hipLaunchKernelGGL(k_sync_first, dim3(n_ranks), dim3(64), 0, st, buf, len, buf_off, file_size, P, rank_lo, first_abs,
-                       start_rel, err);
+                       start_rel, err, resume_abs);
 }
 
 void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask,
@@ -353,7 +363,8 @@ void launch_nl_write(hipStream_t st, const uint32_t *nl_mask, uint32_t len, cons
 void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
-                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf)
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
+                          uint64_t buf_end_abs)
 {
     // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
     // wave per 64 records
@@ -361,7 +372,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
     if (vblocks < 1) vblocks = 1;
     if (vblocks > 16384) vblocks = 16384;
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf);
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs);
 }
 
 }  // namespace ngsc

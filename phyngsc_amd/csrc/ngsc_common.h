@@ -158,6 +158,19 @@ struct RankPlan {
     int32_t overlap_used;  // wr_ov_used, phyNGSC.cpp:160
     uint32_t first_rec;
     int32_t err;
+    // where the rank's loop stands behind the last planned sub-block (a rank walked in several parts, ngsc_compress_rank_part)
+    uint64_t next_pos;     // file offset of the next window = of its first record
+    uint64_t bytes_read;   // p_bytes_read, phyNGSC.cpp:745-746
+    uint64_t bsize;        // size of the next window, phyNGSC.cpp:748-755
+    uint32_t overlap;      // overlap in force for it
+    uint32_t done;         // the rank is finished
+};
+
+// A rank taken up in the middle (all zero / null: from its first record).
+struct PlanResume {
+    uint64_t next_pos, bytes_read, bsize;
+    uint32_t overlap;
+    uint32_t resume;       // 0: start of the rank
 };
 
 // Per (sub-block, field) statistics accumulated with unsigned atomicMax / atomicOr over zeroed memory.
@@ -717,20 +730,38 @@ struct ScalarSearch {
 };
 // (... or a whole wave probing 64 positions per round, see kernels_index.hip)
 
+// buf_end_abs: file offset behind the job buffer's last byte, for a rank that is walked in several parts: a window is
+// planned only while every record that starts inside it is complete in the buffer (or the buffer reaches the end of
+// the rank's region); the rest is left to the next part (RankPlan::next_pos ...).  0: the buffer holds the whole rank.
 template <class Search>
 NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P, uint32_t r, uint64_t buf_off, const uint32_t *te,
                            const uint32_t *ls, uint32_t n_rec_total, uint64_t first_abs, Cut *cuts, uint32_t max_cuts,
-                           RankPlan *plan)
+                           RankPlan *plan, const PlanResume *from = nullptr, uint64_t buf_end_abs = 0)
 {
     RankGeom g = rank_geometry(file_size, P, r);
     plan->n_cuts = 0;
     plan->overlap_used = (int32_t)((int64_t)first_abs - g.wr_start);
+    plan->done = 0;
     uint32_t cur = search.one(ls, n_rec_total + 1, first_abs - buf_off);
     plan->first_rec = cur;
     if (cur > n_rec_total || (uint64_t)ls[cur] + buf_off != first_abs) return ERR_FORMAT;
     int64_t bytes_read = 0, win_pos = g.wr_start, bsize = g.bsize;
     uint32_t overlap = g.overlap;
+    if (from && from->resume) {
+        bytes_read = (int64_t)from->bytes_read;
+        win_pos = (int64_t)from->next_pos;
+        bsize = (int64_t)from->bsize;
+        overlap = from->overlap;
+    }
+    const uint64_t rank_end = (uint64_t)g.wr_end + 1 < file_size ? (uint64_t)g.wr_end + 1 : file_size;
+    const bool whole = buf_end_abs == 0 || buf_end_abs >= rank_end;       // the buffer reaches the end of the rank's region
+    const uint64_t indexed_end = (uint64_t)ls[n_rec_total] + buf_off;     // behind the last complete record of the buffer
     while (bytes_read < g.region) {
+        if (!whole && (uint64_t)(win_pos + bsize) > indexed_end) {        // this window waits for the next part
+            plan->next_pos = (uint64_t)win_pos; plan->bytes_read = (uint64_t)bytes_read; plan->bsize = (uint64_t)bsize;
+            plan->overlap = overlap;
+            return OK;
+        }
         if (cur >= n_rec_total) return ERR_FORMAT;
         int64_t wend = win_pos + bsize, stop_at = win_pos + bsize - (int64_t)overlap;
         uint32_t last = cur;
@@ -762,6 +793,8 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
         }
         cur = last + 1;
     }
+    plan->done = 1;
+    plan->next_pos = (uint64_t)win_pos; plan->bytes_read = (uint64_t)bytes_read; plan->bsize = (uint64_t)bsize; plan->overlap = overlap;
     return OK;
 }
 

@@ -8,7 +8,7 @@ namespace ngsc {
 // ---- kernels_index.hip ----
 uint32_t index_num_tiles(uint32_t len);
 void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
-                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err);
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs);
 void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask,
                      bool at_file_end);
 size_t index_mask_words(uint32_t len);
@@ -18,7 +18,8 @@ void launch_nl_write(hipStream_t st, const uint32_t *nl_mask, uint32_t len, cons
 void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t buf_off,
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
-                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf);
+                          uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
+                          uint64_t buf_end_abs);
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);

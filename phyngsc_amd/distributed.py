@@ -44,7 +44,7 @@ def write_container(path: str, P: int, fastq_size: int, local: Sequence[LocalRan
         sizes, meta = sizes_local, meta_local
         rank0 = True
     assert len(sizes) == P, f"gathered {len(sizes)} ranks, expected {P}"
-    offsets, cbo, end = api.file_offsets(sizes)
+    offsets, cbo, end = api.file_offsets(sizes, api.ranks_per_group(fastq_size, P))
     if rank0:
         # create / truncate before anyone writes
         with open(path, "wb"):

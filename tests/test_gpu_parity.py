@@ -230,6 +230,39 @@ def test_rank_split_invariance_and_repeatability(eng):
     assert sum(sb.n_records for sb in whole.subblocks) == n_rec
 
 
+def test_rank_walked_in_parts(eng):
+    """ngsc_compress_rank_part: a rank's region streamed through the engine in several buffers (the reference takes a
+    region of any size through 8 MiB windows, phyNGSC.cpp:113-128, 168, 745-755; one engine job stays below 4 GiB).
+    The sub-blocks of the parts, one after the other, are the sub-blocks of the whole-rank call."""
+    data = fastq_gen.generate(fastq_gen.GenConfig(seed=23, style=1, len_min=60, len_max=110, qual_model=2, n_rate_ppm=1500,
+                                                  n_lowq_pct=70), target_bytes=150_000_000)
+    P = 3
+    d_all = torch.from_numpy(data).cuda()
+    whole = eng.compress_device(d_all, data.size, P)
+    whole_host = whole.out[:whole.total_bytes].cpu().numpy().copy()
+    for part_bytes in (20_000_000, 33_000_000):
+        got = []
+        for rank in range(P):
+            st = _lib.RankPart()
+            pos = api.region_bounds(data.size, P, rank)[0]
+            sizes, ov = [], None
+            guard = 0
+            while not st.done:
+                lo = pos & ~15
+                hi = min(data.size, lo + part_bytes)
+                part = torch.from_numpy(data[lo:hi].copy()).cuda()
+                r = eng.compress_rank_part(part, data.size, P, rank, st, buf_off=lo)
+                got.append(r.out[:r.total_bytes].cpu().numpy().copy())
+                sizes += [sb.size for sb in r.subblocks]
+                pos = st.next_pos
+                guard += 1
+                assert guard < 100
+            rk = whole.ranks[rank]
+            assert sizes == [whole.subblocks[rk.first_subblock + k].size for k in range(rk.n_subblocks)]
+            assert st.overlap_used == rk.overlap_used
+        assert np.array_equal(np.concatenate(got), whole_host), part_bytes
+
+
 def test_full_size_properties_1gb(eng):
     """BASELINE configs[1] size (1 GB, 36 bp): structure checks that do not need the reference -
     sizes add up, every sub-block header carries its record count, total records conserved."""
@@ -378,6 +411,39 @@ def test_multi_context_file_driver(tmp_path, monkeypatch):
     assert outp.read_bytes() == want
     assert subprocess.run([exe, str(inp), str(outp), "--ranks", "8", "--devices", "0,0,0"],
                           capture_output=True).returncode == 1
+
+
+def test_file_driver_parts_groups_and_streamed_writes(tmp_path, monkeypatch):
+    """The file driver beyond one group (ngsc.h: NGSC_ORDER_GROUP_BYTES): (a) a rank larger than a job is walked in parts
+    (ngsc_compress_rank_part) - inside a multi-rank group its stream is collected, (b) as a group of its own (region above
+    512 MiB) its blocks are written as they fill; (c) groups dealt to two contexts in turn are written at their places.
+    Every file is byte-identical to the oracle's, which orders the blocks by the same group rule."""
+    ndev = torch.cuda.device_count()
+    data = fastq_gen.generate(fastq_gen.CFG3, target_bytes=60_000_000)
+    inp = tmp_path / "a.fastq"
+    data.tofile(inp)
+    want, _ = orc.compress_file(data, 2, threads=2)
+    monkeypatch.setenv("NGSC_JOB_BYTES", str(20_000_000))   # a rank is 30 MB: two parts each
+    outp = tmp_path / "a.ngsc"
+    api.compress_file_multi([api.Engine(0)], str(inp), str(outp), 2)
+    assert outp.read_bytes() == want
+    monkeypatch.delenv("NGSC_JOB_BYTES")
+    del data, want
+    big = fastq_gen.generate(fastq_gen.CFG2, target_bytes=1_300_000_000)
+    inp = tmp_path / "b.fastq"
+    big.tofile(inp)
+    for P, engines in ((2, [api.Engine(0)]), (4, [api.Engine(0), api.Engine(1 % ndev)])):
+        want, _ = orc.compress_file(big, P, threads=8)
+        foot = nf.read_footer(want)
+        if P == 2:   # two groups of one rank: all of rank 0's blocks, then all of rank 1's
+            assert foot.CBO == sorted(foot.CBO) and foot.CBO[0] == 0 and foot.CBO[-1] == 1
+        outp = tmp_path / f"b{P}.ngsc"
+        api.compress_file_multi(engines, str(inp), str(outp), P)
+        with open(outp, "rb") as f:
+            got = f.read()
+        assert got == want, P
+        del got, want
+        outp.unlink()
 
 
 @pytest.mark.parametrize("ngsc_path", SMALL[::3], ids=[os.path.basename(p) for p in SMALL[::3]])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): a FASTQ file larger than one engine job (4 GiB) through the command line tool, checked
-byte for byte against the oracle.  usage: big_file_check.py [GB=5] [ranks=16] [cfg2|cfg3|cfg5]"""
+byte for byte against the oracle.  usage: big_file_check.py [GB=5] [ranks=16[,ranks..]] [cfg2|cfg3|cfg5]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,22 +9,26 @@ from phyngsc_amd import fastq_gen
 from oracle import binding as orc
 
 gb = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
-P = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+PS = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "16").split(",")]
 cfg = {"cfg2": fastq_gen.CFG2, "cfg3": fastq_gen.CFG3, "cfg5": fastq_gen.CFG5}[sys.argv[3] if len(sys.argv) > 3 else "cfg2"]
 t0 = time.time()
 data = fastq_gen.generate(cfg, target_bytes=int(gb * 1e9))
 inp, outp = "/tmp/big_in.fastq", "/tmp/big_out.ngsc"
 data.tofile(inp)
 print(f"generated {data.size/1e9:.2f} GB in {time.time()-t0:.1f} s", flush=True)
-t0 = time.time()
-r = subprocess.run([os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc"), inp, outp, "--ranks", str(P)], capture_output=True, text=True, env=dict(os.environ, NGSC_VERBOSE="1"))
-print(r.stdout.strip(), r.stderr.strip(), f"[ngsc wall {time.time()-t0:.1f} s, rc {r.returncode}]", flush=True)
-t0 = time.time()
-want, st = orc.compress_file(data, P, threads=min(P, os.cpu_count() or 1))
-print(f"oracle {time.time()-t0:.1f} s, {len(want)} B", flush=True)
-got = np.fromfile(outp, dtype=np.uint8)
-want = np.frombuffer(want, dtype=np.uint8) if isinstance(want, (bytes, bytearray)) else want
-same = got.size == want.size and bool(np.array_equal(got, want))
-print("IDENTICAL" if same else f"DIFFERENT ({got.size} vs {want.size} bytes)")
+ok_all = True
+for P in PS:
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc"), inp, outp, "--ranks", str(P)], capture_output=True, text=True, env=dict(os.environ, NGSC_VERBOSE="1"))
+    print(r.stdout.strip(), r.stderr.strip(), f"[ngsc wall {time.time()-t0:.1f} s, rc {r.returncode}]", flush=True)
+    t0 = time.time()
+    want, st = orc.compress_file(data, P, threads=min(P, os.cpu_count() or 1))
+    print(f"oracle {time.time()-t0:.1f} s, {len(want)} B", flush=True)
+    got = np.fromfile(outp, dtype=np.uint8)
+    want = np.frombuffer(want, dtype=np.uint8) if isinstance(want, (bytes, bytearray)) else want
+    same = got.size == want.size and bool(np.array_equal(got, want))
+    ok_all = ok_all and same and r.returncode == 0
+    print(f"ranks {P}: " + ("IDENTICAL" if same else f"DIFFERENT ({got.size} vs {want.size} bytes)"), flush=True)
+    del want, got
 os.remove(inp); os.remove(outp)
-sys.exit(0 if same and r.returncode == 0 else 1)
+sys.exit(0 if ok_all else 1)
