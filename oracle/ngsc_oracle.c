@@ -661,9 +661,20 @@ int ngsc_o_subblock(const uint8_t *win, uint64_t avail, uint64_t wsize, uint64_t
     }
 
     /* ---- DNA / quality prepass phyNGSC.cpp:462-653 ---- */
+    /* Colour space (SOLiD reads: a primer base, then transitions '0'..'3', '.' = unknown), phyNGSC.cpp:473-547.  The first
+       record of the sub-block decides (the reference decides per OpenMP thread: this is its one-thread behaviour, the
+       one the golden files pin): colours when its second character is a digit, "no begin nucleotide" when its first
+       one is.  While every read starts with the first read's primer base and first quality, reads are stored without
+       them ("delta constant", translation = 1); the first read that differs ends that for the rest of the sub-block. */
+    int cs_delta, cs_nobegin, cs_const = 1;
+    uint8_t cs_seq0, cs_qua0;
     {
         uint32_t s0 = te[0] + 1;
-        if (buf[s0 + 1] >= '0' && buf[s0 + 1] <= '3') { rc = NGSC_O_ECOLORSPACE; goto out; } /* :478 */
+        cs_seq0 = buf[s0];
+        cs_qua0 = buf[se[0] + 3];
+        cs_delta = buf[s0 + 1] >= '0' && buf[s0 + 1] <= '3';   /* :478 */
+        cs_nobegin = cs_seq0 >= '0' && cs_seq0 <= '3';         /* :480-484 */
+        if (cs_nobegin) cs_const = 0;
     }
     uint32_t dna_occ[256], qua_seen[256];
     memset(dna_occ, 0, sizeof dna_occ);
@@ -674,6 +685,43 @@ int ngsc_o_subblock(const uint8_t *win, uint64_t avail, uint64_t wsize, uint64_t
     for (uint32_t r = 0; r < n; ++r) {
         uint32_t s = te[r] + 1, e = se[r], L = e - s, q0 = se[r] + 3;
         if ((uint64_t)q0 + L > avail) { rc = NGSC_O_EFORMAT; goto out; } /* quality line cut off by the end of the data */
+        const uint32_t q0_orig = q0;
+        uint32_t ql = L;   /* quality symbols of the record */
+        if (cs_delta && !cs_nobegin && cs_const) cs_const = buf[s] == cs_seq0 && buf[q0] == cs_qua0;   /* :489-493 */
+        if (cs_delta) {
+            /* :495-546.  A transition c turns base b into b ^ c on the two-bit scale A, C, G, T; '.' and '/' give 'N'
+               and leave the running base alone.  The decoded base goes to the read, shifted left by one when the primer
+               base is dropped; the "quality" position gets the read's own byte - the colour when shifted, else the base
+               just stored (the reference copies from the sequence line here, :531) - so only a kept first quality
+               survives. */
+            static const char base_of[4] = {'A', 'C', 'G', 'T'};
+            const uint32_t tr = (uint32_t)cs_const;
+            if (L < tr) { rc = NGSC_O_EFORMAT; goto out; }   /* an empty read: the reference would write in front of it */
+            uint32_t cur = 0;   /* 'A' */
+            uint8_t sym = 'A';
+            uint32_t k = 0;
+            if (!cs_nobegin) {
+                sym = buf[s];
+                dna_occ[sym]++;
+                k = 1;
+            }
+            for (; k < L; ++k) {
+                if (sym == 'A') cur = 0; else if (sym == 'C') cur = 1; else if (sym == 'G') cur = 2; else if (sym == 'T') cur = 3;
+                const uint32_t c = (uint32_t)buf[s + k] - '.';
+                if (c > 5) { rc = NGSC_O_EFORMAT; goto out; }   /* not a colour: the reference indexes past its table */
+                sym = c < 2 ? 'N' : (uint8_t)base_of[cur ^ (c - 2)];
+                dna_occ[sym]++;
+                const uint8_t colour = buf[s + k];
+                buf[s + k - tr] = sym;
+                buf[q0 + k - tr] = tr ? colour : sym;
+            }
+            buf[e - tr] = 0;
+            buf[q0 + L - tr] = 0;
+            e -= tr;
+            ql -= tr;
+            L = e - s;
+        }
+        (void)q0_orig;
         /* transfer test :549-571: every non-ACGT IUPAC base must have quality '!'..'(' */
         int any = 0, ok = 1;
         for (uint32_t j = 0; j < L; ++j) {
@@ -695,16 +743,20 @@ int ngsc_o_subblock(const uint8_t *win, uint64_t avail, uint64_t wsize, uint64_t
             buf[k] = 0;
             newlen = k - s;
         }
-        for (uint32_t j = 0; j < newlen; ++j) dna_occ[buf[s + j]]++;   /* :593-599 */
-        for (uint32_t j = 0; j < L; ++j) qua_seen[buf[q0 + j]] = 1;    /* :614-615 */
-        if (L > max_q) max_q = L;
+        if (!cs_delta)
+            for (uint32_t j = 0; j < newlen; ++j) dna_occ[buf[s + j]]++;   /* :593-599 (colour space counted while decoding) */
+        for (uint32_t j = 0; j < ql; ++j) qua_seen[buf[q0 + j]] = 1;   /* :614-615 */
+        if (ql > max_q) max_q = ql;
         if (newlen > max_s) max_s = newlen;
         slen[r] = newlen;
-        qlen[r] = L;
+        qlen[r] = ql;
     }
     /* flags: :433-435, :645-667.  The min-length reduction never lowers its UINT_MAX initial
        value (:633-640), so FLAG_VARIABLE_LENGTH is always set; DELTA_CONSTANT stays set (Q1). */
-    uint32_t flags = F_PLUS_ONLY | F_DNA_PLAIN | F_CONST_NUM_FIELDS | F_DELTA_CONSTANT | F_VARIABLE_LENGTH;
+    uint32_t flags = F_PLUS_ONLY | F_DNA_PLAIN | F_CONST_NUM_FIELDS | F_VARIABLE_LENGTH;
+    if (cs_const) flags |= F_DELTA_CONSTANT;
+    if (cs_delta) flags |= F_USE_DELTA;
+    if (cs_nobegin) flags |= F_DELTA_NO_BEGIN_NUC;
     uint8_t symbols[256], qualities[256], sym_code[256], qua_code[256];
     uint32_t nsym = 0, nqual = 0;
     memset(sym_code, 0, 256);

@@ -144,6 +144,38 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// number of threads a big read or write of the file driver is split over (page-cache copies run at ~10 GB/s per thread)
+static unsigned io_threads()
+{
+    const char *e = getenv("NGSC_IO_THREADS");
+    const int v = e ? atoi(e) : 4;
+    return (unsigned)std::max(1, std::min(v, 16));
+}
+
+// pread of [off, off + len) into dst, split over io_threads() threads
+static bool pread_parallel(int fd, uint8_t *dst, uint64_t len, uint64_t off)
+{
+    const unsigned nt = len < (64u << 20) ? 1u : io_threads();
+    std::vector<std::thread> th;
+    std::vector<char> ok(nt, 1);
+    const uint64_t per = ((len + nt - 1) / nt + 4095) & ~4095ull;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint64_t a = std::min<uint64_t>(len, (uint64_t)t * per), b = std::min<uint64_t>(len, a + per);
+        auto work = [=, &ok]() {
+            uint64_t got = a;
+            while (got < b) {
+                const ssize_t r = ::pread(fd, dst + got, (size_t)std::min<uint64_t>(b - got, 1u << 30), (off_t)(off + got));
+                if (r <= 0) { ok[t] = 0; return; }
+                got += (uint64_t)r;
+            }
+        };
+        if (t + 1 == nt) work(); else th.emplace_back(work);
+    }
+    for (auto &x : th) x.join();
+    for (char c : ok) if (!c) return false;
+    return true;
+}
+
 static bool pwrite_all(int fd, const void *p, size_t n, uint64_t off)
 {
     const uint8_t *b = (const uint8_t *)p;
@@ -335,14 +367,9 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                 const uint64_t lo = jobs[j].lo, len = jobs[j].hi - jobs[j].lo;
                 uint8_t *hb = (uint8_t *)h_in[j % nbuf];
                 const double t0 = now_s();
-                uint64_t got = 0;
-                while (got < len) {
-                    const ssize_t r = ::pread(fd, hb + got, (size_t)std::min<uint64_t>(len - got, 1u << 30), (off_t)(lo + got));
-                    if (r <= 0) break;
-                    got += (uint64_t)r;
-                }
+                const bool okr = pread_parallel(fd, hb, len, lo);
                 w->io_s += now_s() - t0;
-                if (got != len) { rc = NGSC_ERR_IO; break; }
+                if (!okr) { rc = NGSC_ERR_IO; break; }
                 if (hipMemcpyAsync(d_in[j % nbuf], hb, len, hipMemcpyHostToDevice, in_stream) != hipSuccess ||
                     hipStreamSynchronize(in_stream) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
                 { std::lock_guard<std::mutex> lk(pipe.m); pipe.uploaded = (int)j + 1; }
@@ -469,14 +496,26 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                             sink->n_sub_total += (uint32_t)acc[r].sb.size();
                         }
                         sink->end_group();   // the place is taken: later groups may go on while these bytes are written
-                        bool okw = true;
-                        for (auto &t : todo) {
-                            const size_t r = t.second.first;
-                            const ngsc_block_t &b = rb[r][t.second.second];
-                            const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
-                            okw = okw && pwrite_all(sink->fd, b.header, b.header_len, t.first) &&
-                                  pwrite_all(sink->fd, stream + b.stream_off, b.payload, t.first + b.header_len);
+                        // the blocks are independent writes: a few threads share them
+                        const unsigned nt = todo.size() < 8 ? 1u : io_threads();
+                        std::vector<char> okv(nt, 1);
+                        std::vector<std::thread> th;
+                        for (unsigned t0i = 0; t0i < nt; ++t0i) {
+                            auto work = [&, t0i]() {
+                                for (size_t x = t0i; x < todo.size(); x += nt) {
+                                    const auto &t = todo[x];
+                                    const size_t r = t.second.first;
+                                    const ngsc_block_t &b = rb[r][t.second.second];
+                                    const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
+                                    if (!pwrite_all(sink->fd, b.header, b.header_len, t.first) ||
+                                        !pwrite_all(sink->fd, stream + b.stream_off, b.payload, t.first + b.header_len)) okv[t0i] = 0;
+                                }
+                            };
+                            if (t0i + 1 == nt) work(); else th.emplace_back(work);
                         }
+                        for (auto &x : th) x.join();
+                        bool okw = true;
+                        for (char c : okv) okw = okw && c;
                         if (!okw) { rc = NGSC_ERR_IO; break; }
                     }
                     acc.clear();

@@ -49,13 +49,14 @@ struct ngsc_ctx {
     bool debug_sync = getenv("NGSC_DEBUG_SYNC") != nullptr;
     std::string profile_only;   // when set, only this kernel is timed (two event records per call instead of ~60)
     uint32_t min_text_slots = 0;  // text-field table slots the last call turned out to need (kept for the next call)
+    bool cs_retry = false;        // the job is run again on a copy in which colour-space reads are decoded
     uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
 
     // workspace
-    DevBuf small, tiles, recs, recs2, persb, zero, slots, misc;
+    DevBuf small, tiles, recs, recs2, persb, zero, slots, misc, cscopy;
     // pinned host staging
     void *h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -211,7 +212,7 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc})
+    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc, &c->cscopy})
         if (b->p) (void)hipFree(b->p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     collect_times(c);
@@ -547,6 +548,17 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // NGSC_OVERLAP=1: the title chain on a second stream beside the sequence/quality chain.  Worth 2-3 % on the bench
     // workload (both chains are limited by the same per-CU resources), so the default keeps everything on the
     // caller's stream, where per-kernel timings mean what they say.
+    // Colour-space sub-blocks (found by the statistics kernels of a first run, which then ends with ERR_COLORSPACE): the job
+    // runs on a copy of its input in which they are decoded to bases as the reference decodes them (kernels_cs.hip)
+    if (c->cs_retry) {
+        rc = ensure(c, c->cscopy, (size_t)len + 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->cscopy.p, buf, len, hipMemcpyDeviceToDevice, st));
+        KScope k(c, st, "k_cs_decode");
+        launch_cs(st, A, max_rec, buf, (uint8_t *)c->cscopy.p, d_se);
+        A.buf = (const uint8_t *)c->cscopy.p;
+        A.cs_mode = 1;
+    }
     const char *ov_env = getenv("NGSC_OVERLAP");
     const bool overlap = ov_env && !strcmp(ov_env, "1");
     hipStream_t st2 = overlap ? c->side_stream : st;
@@ -642,6 +654,12 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             c->slot_retry = false;
             return r;
         }
+    }
+    if ((err3 == NGSC_ERR_COLORSPACE || *(int32_t *)hfin == NGSC_ERR_COLORSPACE) && !c->cs_retry) {
+        c->cs_retry = true;
+        const int r = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
+        c->cs_retry = false;
+        return r;
     }
     if (err3) return err3;
     if (*(int32_t *)hfin) return *(int32_t *)hfin;

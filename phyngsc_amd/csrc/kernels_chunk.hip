@@ -262,9 +262,8 @@ __global__ __launch_bounds__(CK_THREADS) void k_ck_stats(Arena A, uint32_t TR, u
             // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it
             const uint32_t rec = M.rec[lane], L = (rec >> 16) & 0x7fffu, sq0 = rec & 0xffffu;
             if (ck_byte(M.in, sq0 + L + 1) != '+' || ck_byte(M.in, sq0 + L + 2) != '\n') atomicMin(A.err, (int32_t)ERR_FORMAT);
-            if (t0r + lane == 0 && L >= 2) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
-                const uint32_t c1 = ck_byte(M.in, sq0 + 1);
-                if (c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+            if (t0r + lane == 0 && L >= 1 && !A.cs_mode) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
+                if (cs_first_read(ck_byte(M.in, sq0), ck_byte(M.in, sq0 + 1))) atomicMin(A.err, (int32_t)ERR_COLORSPACE);
             }
             mq = L > mq ? L : mq;
             sum_l += L;

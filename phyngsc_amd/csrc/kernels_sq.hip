@@ -71,9 +71,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
             // line 3 of every record must be a bare '+' (README.md:97-103); the reference assumes it.  Checked below from
             // the bytes that follow the read inside its last 16-byte chunk; an empty read has no chunk:
             if (L == 0 && (load8_unaligned(A.buf, se, A.buf_len).x & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
-            if (i == 0 && L >= 2) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
-                const uint8_t c1 = A.buf[s0 + 1];
-                if (c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+            if (i == 0 && L >= 1 && !A.cs_mode) {   // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
+                if (cs_first_read(A.buf[s0], A.buf[s0 + 1])) atomicMin(A.err, (int32_t)ERR_COLORSPACE);   // (the job runs again, decoded)
             }
         }
 

@@ -61,9 +61,8 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
         const uint32_t t = A.te[g], e = A.se[g];
         const uint32_t L = e - t - 1, s0 = t + 1, q0 = e + 3;
         if (lane == 0 && (buf[e + 1] != '+' || buf[e + 2] != '\n')) atomicMin(A.err, (int32_t)ERR_FORMAT);  // bare '+' line
-        if (r == 0 && lane == 0) {
-            uint8_t c1 = buf[s0 + 1];  // colour-space detection, phyNGSC.cpp:478
-            if (L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+        if (r == 0 && lane == 0 && L >= 1 && !A.cs_mode) {   // colour-space detection, phyNGSC.cpp:478
+            if (cs_first_read(buf[s0], buf[s0 + 1])) atomicMin(A.err, (int32_t)ERR_COLORSPACE);
         }
         // pass 1: transfer test (phyNGSC.cpp:549-571).  The serial loop breaks at the first failure, so
         // the outcome is "some ambiguous base" && "no failure anywhere" - order independent.
@@ -154,7 +153,10 @@ __global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
     const uint32_t nsym = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
     // flags: phyNGSC.cpp:433-435, 645-667 (VARIABLE_LENGTH and DELTA_CONSTANT always end up set, Q1);
     // AnalyzeDNA (tasks.cpp:226-257) keeps DNA_PLAIN iff <= 4 symbols (its skew test compares zeros, Q4)
-    uint32_t flags = F_PLUS_ONLY | F_CONST_NUM_FIELDS | F_DELTA_CONSTANT | F_VARIABLE_LENGTH;
+    uint32_t flags = F_PLUS_ONLY | F_CONST_NUM_FIELDS | F_VARIABLE_LENGTH;
+    if (!(sb.cs & 4)) flags |= F_DELTA_CONSTANT;
+    if (sb.cs & 1) flags |= F_USE_DELTA;
+    if (sb.cs & 2) flags |= F_DELTA_NO_BEGIN_NUC;
     if (nsym <= 4) flags |= F_DNA_PLAIN;
     // DNA code LUT by raw byte; the Huffman case is overwritten by the tree kernel
     A.dcodes[(size_t)s * 256 + tid] = hass ? ((is << 5) | 2u) : 0u;

@@ -200,9 +200,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_seq_qual_stats_tile(Arena A, uin
         uint32_t se = A.se[i0 + tid] - b0;
         if (tb[se + 1] != '+' || tb[se + 2] != '\n') atomicMin(A.err, (int32_t)ERR_FORMAT);
     }
-    if (t0 == 0 && tid == 0) {  // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
-        uint8_t c1 = tb[S.s0 + 1];
-        if (S.L >= 2 && c1 >= '0' && c1 <= '3') atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+    if (t0 == 0 && tid == 0 && S.L >= 1 && !A.cs_mode) {  // colour-space detection on the sub-block's first record, phyNGSC.cpp:478
+        if (cs_first_read(tb[S.s0], tb[S.s0 + 1])) atomicMin(A.err, (int32_t)ERR_COLORSPACE);
     }
     const uint32_t len = S.j1 - S.j0;
     const uint32_t maxl = wmax(len);

@@ -86,6 +86,9 @@ NGSC_HD uint32_t amb_code(uint8_t c)
     }
 }
 
+// Does a sub-block whose first read starts with these two bytes need the colour-space treatment? (phyNGSC.cpp:478-484)
+NGSC_HD bool cs_first_read(uint32_t c0, uint32_t c1) { return (c1 >= '0' && c1 <= '3') || (c0 >= '0' && c0 <= '3'); }
+
 // quality byte of a transferred base (phyNGSC.cpp:579)
 NGSC_HD uint8_t transfer_quality(uint32_t amb, uint8_t q) { return (uint8_t)(128 + (amb << 3) - 16 + (q - 33)); }
 
@@ -224,6 +227,10 @@ struct SbState {        // per sub-block scalars
     uint32_t ncf;                   // number of non-constant title fields
     uint32_t slot_bias;             // record index + slot_bias = the record's slot in the arrays that depend on the sub-block
                                     // (slot of the sub-block's first record = records of all earlier sub-blocks; mod 2^32)
+    uint32_t cs;                    // colour space (phyNGSC.cpp:473-547): bit0 reads are colours (FLAG_USE_DELTA), bit1 no primer
+                                    // base (FLAG_DELTA_NO_BEGIN_NUC), bit2 NOT every read starts like the first (!FLAG_DELTA_CONSTANT)
+    uint32_t cs_v;                  // first record that does not start like the first one (reads in front of it are stored
+                                    // without their primer base and first quality)
     uint64_t out_off;               // byte offset of the sub-block in the output buffer
     uint8_t symbols[256];
     uint8_t qualities[256];
@@ -297,6 +304,7 @@ struct Arena {
     uint32_t *tblob_len;    // [n_slots][129]
     uint32_t qrows;         // job max quality length + 1
     uint32_t n_sb;
+    uint32_t cs_mode;       // the job runs on a copy of its input in which colour-space reads are decoded (kernels_cs.hip)
     uint8_t *out;           // output buffer
 };
 

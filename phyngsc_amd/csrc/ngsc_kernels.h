@@ -33,6 +33,9 @@ void launch_ck_measure(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_
 void launch_ck_pack(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes, uint32_t stage_q_words,
                     uint32_t stage_d_words);
 
+// ---- kernels_cs.hip (colour-space reads decoded into a copy of the job's input) ----
+void launch_cs(hipStream_t st, const Arena &A, uint32_t max_rec, const uint8_t *orig, uint8_t *copy, uint32_t *se_w);
+
 // ---- kernels_stats.hip ----
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_finalize(hipStream_t st, const Arena &A);

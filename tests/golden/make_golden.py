@@ -199,6 +199,24 @@ def small_cases():
     add("many_text_fields", "".join(rec("@T" + " ".join("".join(rng3.choice("abcdefgh") for _ in range(1 + (k + rng3.randrange(3)) % 4))
                                                         for k in range(8)), rand_seq(rng3, 50), rand_qual(rng3, 50))
                                     for i in range(1800)), [10])   # 10 sub-blocks x 8 varying text fields
+    # colour space (SOLiD csfastq): primer base + transitions 0..3, '.' = unknown (phyNGSC.cpp:473-547)
+    rng4 = random.Random(20261006)
+
+    def cs_read(L, dots=0.0, primer="T"):
+        return primer + "".join("." if rng4.random() < dots else rng4.choice("0123") for _ in range(L - 1))
+
+    def cs_qual(L, first="!"):
+        return first + "".join(chr(rng4.randint(34, 70)) for _ in range(L - 1))
+    add("cs_constant", "".join(rec(f"@solid_{i}_F3", cs_read(36), cs_qual(36)) for i in range(1500)), [2, 3])
+    add("cs_breaks", "".join(rec(f"@solid_{i}_F3", cs_read(36), cs_qual(36, "!" if i < 400 or i % 5 else "5"))
+                             for i in range(1500)), [2])           # the 401st read ends "delta constant" (rank 0), rank 1 starts anew
+    add("cs_dots", "".join(rec(f"@solid_{i}_F3", cs_read(50, dots=0.02), cs_qual(50)) for i in range(1200)), [2])
+    add("cs_primers", "".join(rec(f"@solid_{i}_F3", cs_read(30 + i % 9, primer="TGAC"[i % 4]), cs_qual(30 + i % 9))
+                              for i in range(1500)), [2])
+    add("cs_no_primer", "".join(rec(f"@solid_{i}_F3", cs_read(36, dots=0.005, primer=rng4.choice("0123")), cs_qual(36))
+                                for i in range(1500)), [2])
+    add("digit_first_base", "".join(rec(f"@d.{i}", ("2" if i % 700 == 0 else "A") + rand_seq(rng4, 35), rand_qual(rng4, 36))
+                                    for i in range(1400)), [2])    # base space whose first read starts with a digit: flags only
     return cases
 
 

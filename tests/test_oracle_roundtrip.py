@@ -13,7 +13,9 @@ from oracle import binding as orc
 from phyngsc_amd import fastq_gen, ngsc_format as nf
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SMALL = sorted(glob.glob(os.path.join(GOLDEN, "small", "*.ngsc")))
+# Colour-space files (cs_*) are not reversible: the reference overwrites the quality line with the decoded bases or the
+# colours (phyNGSC.cpp:531) and stores bases instead of transitions, so their streams do not hold the input any more.
+SMALL = sorted(p for p in glob.glob(os.path.join(GOLDEN, "small", "*.ngsc")) if not os.path.basename(p).startswith("cs_"))
 
 
 @pytest.mark.parametrize("ngsc_path", SMALL, ids=[os.path.basename(p) for p in SMALL])
