@@ -149,6 +149,19 @@ uint32_t ngsc_result_num_ranks(ngsc_ctx *ctx);
 const ngsc_subblock_t *ngsc_result_subblocks(ngsc_ctx *ctx);
 const ngsc_rank_t *ngsc_result_ranks(ngsc_ctx *ctx);
 
+/*
+ * The inverse path: n_sb sub-blocks (each info | title | quality | DNA as ngsc_compress_device() writes them; sb_off /
+ * sb_len: their byte offsets and lengths inside d_sub, host arrays) -> the FASTQ text of their records, sub-block
+ * after sub-block, in d_text; text_off[0 .. n_sb] (host) receives where each sub-block's text starts and the total.
+ * Replaces the reference's uncalled decoder fragments (FetchTitleHeader / FetchTitleBody / FetchDNA / FetchQuality,
+ * tasks.cpp:625-1101; LoadTree / Decode, huffman.cpp:122-219).  A sub-block is one bit string whose streams have no
+ * stored lengths, so the unit of parallel work is the sub-block: one wave each for the serial streams, then all threads
+ * for the record assembly.  Colour-space sub-blocks (FLAG_USE_DELTA) are stored lossily by the format and are refused
+ * (NGSC_ERR_COLORSPACE).  n_records: nullable, records per sub-block.  The stream is synchronised on return.
+ */
+int ngsc_decompress_device(ngsc_ctx *ctx, const void *d_sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
+                           void *d_text, uint64_t text_cap, uint64_t *text_off, uint32_t *n_records, void *hip_stream);
+
 /* ---- container (host side) ------------------------------------------------------------------- */
 /* Splits one rank's sub-block sizes into 8 MiB blocks (phyNGSC.cpp:842-928). */
 int ngsc_plan_blocks(uint32_t P, uint32_t wrid, const uint32_t *sb_sizes, uint32_t n_sb, ngsc_block_t *blocks,

@@ -17,7 +17,7 @@ EXPORTS = [
     "ngsc_set_profiling", "ngsc_reset_kernel_times", "ngsc_get_kernel_times", "ngsc_compress_device",
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
-    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part",
+    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -95,6 +95,9 @@ def lib():
     L.ngsc_compress_device.argtypes = [vp, vp, u64, u64, u64, u32, u32, u32, vp, u64, vp]
     L.ngsc_compress_rank_part.restype = ctypes.c_int
     L.ngsc_compress_rank_part.argtypes = [vp, vp, u64, u64, u64, u32, u32, ctypes.POINTER(RankPart), vp, u64, vp]
+    L.ngsc_decompress_device.restype = ctypes.c_int
+    L.ngsc_decompress_device.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u32), u32, vp, u64, ctypes.POINTER(u64),
+                                         ctypes.POINTER(u32), vp]
     L.ngsc_result_bytes.restype = u64
     L.ngsc_result_bytes.argtypes = [vp]
     L.ngsc_result_num_subblocks.restype = u32

@@ -141,6 +141,27 @@ class Engine:
             ctypes.memmove(rks, self._L.ngsc_result_ranks(self._h), ctypes.sizeof(rks))
         return DeviceResult(int(self._L.ngsc_result_bytes(self._h)), sbs, rks, out)
 
+    def decompress_device(self, d_sub, offsets: Sequence[int], lengths: Sequence[int], text_cap: Optional[int] = None,
+                          stream: Optional[int] = None):
+        """The inverse path (ngsc.h: ngsc_decompress_device): sub-blocks in HBM -> FASTQ text in HBM.
+        Returns (text tensor, text offsets per sub-block + total, records per sub-block)."""
+        import torch
+        n = len(offsets)
+        offs = (ctypes.c_uint64 * n)(*offsets)
+        lens = (ctypes.c_uint32 * n)(*lengths)
+        toff = (ctypes.c_uint64 * (n + 1))()
+        nrec = (ctypes.c_uint32 * n)()
+        if text_cap is None:
+            text_cap = n * (9 << 20)
+        text = torch.empty(text_cap, dtype=torch.uint8, device=d_sub.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_sub.device).cuda_stream
+        rc = self._L.ngsc_decompress_device(self._h, d_sub.data_ptr(), offs, lens, n, text.data_ptr(), text_cap, toff, nrec,
+                                            ctypes.c_void_p(stream))
+        if rc:
+            raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
+        return text[:toff[n]], list(toff), list(nrec)
+
     def compress_file(self, in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
         """``<in.fastq> <out.ngsc>`` on this GPU; returns (read, H2D+device+D2H, plan+write) seconds."""
         sec = (ctypes.c_double * 3)()
@@ -250,6 +271,28 @@ def compress_bytes(data, P: int = 8, engine: Optional[Engine] = None, device: in
     res = eng.compress_device(d_in, arr.size, P)
     torch.cuda.synchronize()
     return assemble_container(res, P, arr.size)
+
+
+def decompress_bytes(ngsc: bytes, engine: Optional[Engine] = None, device: int = 0) -> bytes:
+    """.ngsc container -> FASTQ text through the GPU decoder: the sub-blocks of every rank, ranks ascending (each rank's
+    records are a contiguous run of the file, phyNGSC.cpp:113-166); the container is taken apart on the host."""
+    import torch
+    from . import ngsc_format
+    eng = engine or Engine(device)
+    streams = ngsc_format.rank_streams(bytes(ngsc))
+    subs = [sb for w in sorted(streams) for sb in streams[w]]
+    offs, pos = [], 0
+    for sb in subs:
+        offs.append(pos)
+        pos += (len(sb) + 15) & ~15
+    buf = np.zeros(pos + 16, dtype=np.uint8)
+    for o, sb in zip(offs, subs):
+        buf[o:o + len(sb)] = np.frombuffer(sb, dtype=np.uint8)
+    d_sub = torch.from_numpy(buf).to(f"cuda:{eng.device}")
+    text, toff, _ = eng.decompress_device(d_sub, offs, [len(sb) for sb in subs])
+    out = text.cpu().numpy().tobytes()
+    fs = ngsc_format.read_footer(bytes(ngsc)).FS   # (a file whose last line had no newline decodes with one too many)
+    return out[:fs] if len(out) == fs + 1 and out.endswith(b"\n") else out
 
 
 # ---- multi-process (one process per GPU) ------------------------------------------------------------

@@ -148,7 +148,7 @@ static double now_s()
 static unsigned io_threads()
 {
     const char *e = getenv("NGSC_IO_THREADS");
-    const int v = e ? atoi(e) : 4;
+    const int v = e ? atoi(e) : 8;
     return (unsigned)std::max(1, std::min(v, 16));
 }
 
@@ -186,6 +186,27 @@ static bool pwrite_all(int fd, const void *p, size_t n, uint64_t off)
         n -= (size_t)w;
         off += (uint64_t)w;
     }
+    return true;
+}
+
+// independent writes shared by io_threads() threads
+struct WriteItem { uint64_t off; const uint8_t *hdr; uint32_t hdr_len; const uint8_t *payload; uint32_t len; };
+static bool write_items(int fd, const std::vector<WriteItem> &items)
+{
+    const unsigned nt = items.size() < 4 ? 1u : std::min<unsigned>(io_threads(), (unsigned)items.size());
+    std::vector<char> okv(nt, 1);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        auto work = [&, t]() {
+            for (size_t x = t; x < items.size(); x += nt) {
+                const WriteItem &w = items[x];
+                if (!pwrite_all(fd, w.hdr, w.hdr_len, w.off) || !pwrite_all(fd, w.payload, w.len, w.off + w.hdr_len)) okv[t] = 0;
+            }
+        };
+        if (t + 1 == nt) work(); else th.emplace_back(work);
+    }
+    for (auto &x : th) x.join();
+    for (char c : okv) if (!c) return false;
     return true;
 }
 
@@ -442,18 +463,17 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                     if ((rc = plan(ra))) break;
                     const bool done = res.part.done != 0;
                     const uint32_t upto = done ? (uint32_t)blocks.size() : (blocks.empty() ? 0 : (uint32_t)blocks.size() - 1);
-                    bool okw = true;
                     uint64_t drop_to = ra.carry_base;
-                    for (uint32_t k = ra.emitted; k < upto && okw; ++k) {
+                    std::vector<WriteItem> items;
+                    for (uint32_t k = ra.emitted; k < upto; ++k) {
                         const ngsc_block_t &b = blocks[k];
-                        okw = pwrite_all(sink->fd, b.header, b.header_len, sink->cursor) &&
-                              pwrite_all(sink->fd, ra.carry.data() + (b.stream_off - ra.carry_base), b.payload, sink->cursor + b.header_len);
+                        items.push_back({sink->cursor, b.header, b.header_len, ra.carry.data() + (b.stream_off - ra.carry_base), b.payload});
                         sink->cursor += b.size;            // (this worker holds the turn: nobody else moves the cursor)
                         sink->cbo.push_back(ra.rank);
                         ra.last_size = b.size;
                         drop_to = b.stream_off + b.payload;
                     }
-                    if (!okw) { rc = NGSC_ERR_IO; break; }
+                    if (!write_items(sink->fd, items)) { rc = NGSC_ERR_IO; break; }
                     ra.emitted = upto;
                     ra.carry.erase(ra.carry.begin(), ra.carry.begin() + (size_t)(drop_to - ra.carry_base));
                     ra.carry_base = drop_to;
@@ -497,26 +517,14 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                         }
                         sink->end_group();   // the place is taken: later groups may go on while these bytes are written
                         // the blocks are independent writes: a few threads share them
-                        const unsigned nt = todo.size() < 8 ? 1u : io_threads();
-                        std::vector<char> okv(nt, 1);
-                        std::vector<std::thread> th;
-                        for (unsigned t0i = 0; t0i < nt; ++t0i) {
-                            auto work = [&, t0i]() {
-                                for (size_t x = t0i; x < todo.size(); x += nt) {
-                                    const auto &t = todo[x];
-                                    const size_t r = t.second.first;
-                                    const ngsc_block_t &b = rb[r][t.second.second];
-                                    const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
-                                    if (!pwrite_all(sink->fd, b.header, b.header_len, t.first) ||
-                                        !pwrite_all(sink->fd, stream + b.stream_off, b.payload, t.first + b.header_len)) okv[t0i] = 0;
-                                }
-                            };
-                            if (t0i + 1 == nt) work(); else th.emplace_back(work);
+                        std::vector<WriteItem> items;
+                        for (auto &t : todo) {
+                            const size_t r = t.second.first;
+                            const ngsc_block_t &b = rb[r][t.second.second];
+                            const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
+                            items.push_back({t.first, b.header, b.header_len, stream + b.stream_off, b.payload});
                         }
-                        for (auto &x : th) x.join();
-                        bool okw = true;
-                        for (char c : okv) okw = okw && c;
-                        if (!okw) { rc = NGSC_ERR_IO; break; }
+                        if (!write_items(sink->fd, items)) { rc = NGSC_ERR_IO; break; }
                     }
                     acc.clear();
                 }

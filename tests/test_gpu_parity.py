@@ -501,6 +501,45 @@ def test_bench_multi_gpu_modes_start_without_a_launcher():
     assert "2 contexts" in line["config"]["launch"]
 
 
+@pytest.mark.parametrize("ngsc_path", REVERSIBLE, ids=[os.path.basename(p) for p in REVERSIBLE])
+def test_gpu_decoder_on_reference_outputs(eng, ngsc_path):
+    """The GPU decoder (ngsc_decompress_device) turns the committed outputs of the UNMODIFIED reference back into the
+    FASTQ files they were made from - the same pin the CPU decoder of oracle/ has."""
+    m = re.match(r"(.*)\.p(\d+)\.ngsc$", ngsc_path)
+    with open(m.group(1) + ".fastq", "rb") as f:
+        want = f.read()
+    with open(ngsc_path, "rb") as f:
+        got = api.decompress_bytes(f.read(), engine=eng)
+    assert got == want
+
+
+@pytest.mark.parametrize("cfg,size,P", [(fastq_gen.CFG2, 120_000_000, 8), (fastq_gen.CFG3, 60_000_000, 4), (fastq_gen.CFG5_300, 40_000_000, 6)])
+def test_gpu_round_trip(eng, cfg, size, P):
+    """compress on the GPU -> decompress on the GPU -> the input; sub-block by sub-block the GPU decoder agrees with the
+    CPU decoder of oracle/."""
+    data = fastq_gen.generate(cfg, target_bytes=size)
+    res, out = _gpu(eng, data, P)
+    assert api.decompress_bytes(out, engine=eng) == data.tobytes()
+    offs = [sb.out_off for sb in res.subblocks]
+    lens = [sb.size for sb in res.subblocks]
+    text, toff, nrec = eng.decompress_device(res.out, offs, lens)
+    host = text.cpu().numpy()
+    sub = res.out[:res.total_bytes].cpu().numpy()
+    assert nrec == [sb.n_records for sb in res.subblocks]
+    for k in (0, len(offs) // 2, len(offs) - 1):
+        want, used, _ = orc.decode_subblock(sub[offs[k]:offs[k] + lens[k]])
+        assert used == lens[k] and host[toff[k]:toff[k + 1]].tobytes() == want
+
+
+def test_gpu_decoder_refuses_garbage(eng):
+    data = fastq_gen.generate(fastq_gen.CFG1, target_bytes=2_000_000)
+    res, _ = _gpu(eng, data, 2)
+    sub = res.out[:res.total_bytes].clone()
+    sub[40:4000] = 0xA5          # title header / body damaged
+    with pytest.raises(api.NgscError):
+        eng.decompress_device(sub, [res.subblocks[0].out_off], [res.subblocks[0].size])
+
+
 def _edge_cases():
     from tests.edge_cases import build
     return build()
