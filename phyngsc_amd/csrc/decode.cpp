@@ -33,9 +33,9 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     hipStream_t st = (hipStream_t)hip_stream;   // nullptr: the default stream
     // scratch of one sub-block: a sub-block holds the records of one 8 MiB window (+ the record that straddles its end)
     const uint32_t rec_cap = MAX_RECORDS + 2;
-    const uint64_t tcap = 9ull << 20, qcap = 5ull << 20, pool = 3ull << 20;
-    const uint64_t stride = ((4ull * rec_cap * 3 + 64 + tcap + 2 * qcap + pool) + 255) & ~255ull;
-    const uint32_t batch = std::min<uint32_t>(n_sb, 512);
+    const uint64_t tcap = 10ull << 20, qcap = 0, pool = 4ull << 20;   // text area: titles, qualities, bases <= the window's text
+    const uint64_t stride = ((4ull * rec_cap * 3 + 96 + tcap + pool) + 255) & ~255ull;
+    const uint32_t batch = std::min<uint32_t>(n_sb, 2048);              // ~15 MiB of scratch per sub-block in flight
     uint8_t *scratch = nullptr;
     uint64_t *d_off = nullptr, *d_toff = nullptr;
     uint32_t *d_len = nullptr;

@@ -60,6 +60,19 @@ struct BitIn {
         pos += n;
         return v;
     }
+    __device__ uint32_t peek(uint32_t n)   // the next n <= 16 bits without moving (zeros behind the end of the stream)
+    {
+        if (have < n) fill();
+        return (uint32_t)(win >> (64 - n));
+    }
+    __device__ void skip(uint32_t n)       // n bits that peek() has shown
+    {
+        if (!n) return;
+        if (pos + n > nbits) { bad = bad ? bad : 1; pos = nbits; have = 0; win = 0; return; }
+        win <<= n;
+        have -= n;
+        pos += n;
+    }
     __device__ uint32_t bit() { return bits(1); }
     __device__ void align()
     {
@@ -74,7 +87,35 @@ struct BitIn {
 struct DTree {
     uint32_t n, root;       // symbols; root node id (leaf ids 0..n-1, internal ids from n in visit order)
     uint16_t *lc, *rc;      // [n] indexed by node id - n
+    uint16_t *tab;          // [1 << DEC_K] by the next DEC_K bits: length << 12 | symbol; 0 = code longer than DEC_K bits (or
+                            // symbol 0 of a one-symbol tree): walk the tree.  nullptr: no table
 };
+constexpr uint32_t DEC_K = 9;
+
+// Decode table of a loaded tree: a dependent load per SYMBOL instead of one per code bit (a lone lane pays the full
+// latency of each).  Depth-first over the codes of at most DEC_K bits; entry = node | len << 10 | code << 14.
+__device__ void tree_table(DTree &t, uint16_t *tab, uint32_t K = DEC_K)
+{
+    t.tab = K == DEC_K ? tab : nullptr;   // (tree_get() reads DEC_K-bit tables; the quality loop addresses its own)
+    if (!tab) return;
+    for (uint32_t x = 0; x < (1u << K); ++x) tab[x] = 0;
+    uint32_t stack[2 * DEC_K + 4];
+    uint32_t sp = 0;
+    stack[sp++] = t.root;
+    while (sp) {
+        const uint32_t e = stack[--sp];
+        const uint32_t node = e & 1023u, len = (e >> 10) & 15u, code = e >> 14;
+        if (node < t.n) {
+            const uint32_t span = 1u << (K - len), first = code << (K - len);
+            const uint16_t v = (uint16_t)((len << 12) | node);
+            for (uint32_t x = 0; x < span; ++x) tab[first + x] = v;
+        } else if (len < K) {
+            const uint32_t idx = node - t.n;
+            stack[sp++] = t.rc[idx] | ((len + 1) << 10) | (((code << 1) | 1u) << 14);
+            stack[sp++] = t.lc[idx] | ((len + 1) << 10) | ((code << 1) << 14);
+        }
+    }
+}
 
 struct Pool {   // bump allocator over the sub-block's scratch
     uint8_t *base;
@@ -126,6 +167,7 @@ __device__ bool tree_load(BitIn &r, uint32_t expect_n, Pool &pool, DTree &t, uin
         if (!sp) break;
     }
     t.root = rootref;
+    t.tab = nullptr;
     if (r.bad) return false;
     r.seek(end);
     return true;
@@ -133,6 +175,10 @@ __device__ bool tree_load(BitIn &r, uint32_t expect_n, Pool &pool, DTree &t, uin
 
 __device__ __forceinline__ uint32_t tree_get(const DTree &t, BitIn &r)
 {
+    if (t.tab) {
+        const uint32_t e = t.tab[r.peek(DEC_K)];
+        if (e) { r.skip(e >> 12); return e & 0xfffu; }
+    }
     uint32_t node = t.root;
     while (node >= t.n) {
         const uint32_t idx = node - t.n;
@@ -162,24 +208,27 @@ struct DecSub {
     uint8_t dsym[256];
 };
 
+// decimal digits of v straight into dst (no local array: a lone lane's scratch memory costs a memory round trip per byte)
 __device__ __forceinline__ uint32_t dec_put_decimal(uint8_t *dst, uint32_t v)
 {
-    uint8_t tmp[12];
-    uint32_t k = 0;
-    do { tmp[k++] = (uint8_t)('0' + v % 10); v /= 10; } while (v);
-    for (uint32_t i = 0; i < k; ++i) dst[i] = tmp[k - 1 - i];
-    return k;
+    uint32_t nd = 1;
+    for (uint32_t t = v; t >= 10; t /= 10) ++nd;
+    for (uint32_t k = nd; k-- > 0;) { dst[k] = (uint8_t)('0' + v % 10); v /= 10; }
+    return nd;
 }
 
-// scratch layout of one sub-block: [qlen n][toff n+1][slen n][titles tcap][qual qcap][seq (Huffman DNA) qcap][pool]
+// scratch layout of one sub-block: [qlen n][toff n+1][slen n][lay 2][text tcap][pool].  The text area holds the titles,
+// then - where they end, which is known before the quality stream is opened - the qualities, then the bases of a
+// Huffman-coded alphabet: together never more than the sub-block's FASTQ text.
 struct DecScratch {
     uint32_t *qlen, *toff, *slen;
-    uint8_t *titles, *qual, *seq;
+    uint64_t *lay;          // [0] offset of the qualities in the text area, [1] of the bases
+    uint8_t *titles;
     uint8_t *pool;
-    uint64_t tcap, qcap, pool_cap;
+    uint64_t tcap, pool_cap;
 };
 
-__device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, uint32_t rec_cap, uint64_t tcap, uint64_t qcap)
+__device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, uint32_t rec_cap, uint64_t tcap, uint64_t)
 {
     DecScratch D;
     uint8_t *b = base + (uint64_t)s * stride;
@@ -187,11 +236,10 @@ __device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, ui
     D.toff = (uint32_t *)b; b += 4ull * (rec_cap + 1);
     D.slen = (uint32_t *)b; b += 4ull * rec_cap;
     b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
+    D.lay = (uint64_t *)b; b += 16;
     D.titles = b; b += tcap;
-    D.qual = b; b += qcap;
-    D.seq = b; b += qcap;
     D.pool = b;
-    D.tcap = tcap; D.qcap = qcap;
+    D.tcap = tcap;
     D.pool_cap = stride - (uint64_t)(b - (base + (uint64_t)s * stride));
     return D;
 }
@@ -199,7 +247,7 @@ __device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, ui
 // One wave per sub-block; lane 0 decodes the serial streams.
 __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
                                                     uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
-                                                    DecSub *out)
+                                                    DecSub *out, uint32_t lds_entries)
 {
     const uint32_t s = blockIdx.x;
     if (s >= n_sb || threadIdx.x != 0) return;
@@ -218,6 +266,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     (void)r.u8();
     const uint32_t nqual = r.u8(), flags = r.u32();
     if (r.bad || n == 0 || n > rec_cap || !nsym || !nqual || max_q > (1u << 24)) { O.err = ERR_FORMAT; return; }
+    uint64_t qual_total = 0;
     if (flags & F_USE_DELTA) { O.err = ERR_COLORSPACE; return; }   // colour space is stored lossily (phyNGSC.cpp:531): nothing to give back
     O.n_rec = n; O.max_q = max_q; O.flags = flags; O.nsym = nsym; O.plain = (flags & F_DNA_PLAIN) ? 1u : 0u;
     {
@@ -230,19 +279,22 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             if (L > max_q) r.bad = 1;
         }
         r.align();
-        if (r.bad || tot > D.qcap) { O.err = r.bad ? ERR_FORMAT : ERR_CAPACITY; return; }
+        if (r.bad || 2 * tot > D.tcap) { O.err = r.bad ? ERR_FORMAT : ERR_CAPACITY; return; }
+        qual_total = tot;
     }
 
     // ---- title header (cf. FetchTitleHeader tasks.cpp:625-735; value-coding trees as the encoder stores them, Q2b) ----
     const uint32_t nf = r.u32();
     if (r.bad || nf == 0 || nf > DEC_MAX_FIELDS) { O.err = r.bad ? ERR_FORMAT : ERR_UNSUPPORTED; return; }
-    DField *F = (DField *)pool.take(sizeof(DField) * nf);
-    if (!F) { O.err = ERR_NOMEM; return; }
+    __shared__ DField s_F[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
+    DField *F = s_F;
     const uint32_t keep_from = num_values_kept_from(nf);
     for (uint32_t f = 0; f < nf && !r.bad; ++f) {
         DField &fd = F[f];
         fd.l = nullptr; fd.has_g = 0; fd.gval = nullptr; fd.data0 = fd.ham = nullptr; fd.gval_len = 0; fd.prev = 0; fd.gflag = 0;
         fd.is_num = fd.is_len_const = fd.delta_coding = 0;
+        fd.len0 = fd.min_len = fd.max_len = fd.bits_len = fd.bits_num = fd.bits_val = 0;
+        fd.min_v = fd.max_v = fd.min_d = fd.max_d = 0;
         fd.sep = (uint8_t)r.u8();
         fd.is_const = r.u8() != 0;
         if (fd.is_const) {
@@ -263,7 +315,10 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             fd.bits_num = bit_length((uint64_t)diff);
             fd.bits_val = bit_length((uint64_t)vr);
             const bool have_map = fd.delta_coding ? (n >= 2u) : (f >= keep_from);
-            if (diff + 1 <= (int64_t)MAX_NUM_HUF && have_map) fd.has_g = tree_load(r, (uint32_t)(diff + 1), pool, fd.g, stack) ? 1 : 0;
+            if (diff + 1 <= (int64_t)MAX_NUM_HUF && have_map) {
+                fd.has_g = tree_load(r, (uint32_t)(diff + 1), pool, fd.g, stack) ? 1 : 0;
+                if (fd.has_g) tree_table(fd.g, (uint16_t *)pool.take(2u << DEC_K));
+            }
             continue;
         }
         fd.is_len_const = r.u8() != 0;
@@ -281,8 +336,9 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
         for (uint32_t j = 0; j < fd.len0; ++j) fd.ham[j] = (uint8_t)r.bit();
         const uint32_t npos = fd.max_len < MAX_STAT_LEN ? fd.max_len : MAX_STAT_LEN;
         for (uint32_t j = 0; j < npos && !r.bad; ++j)
-            if (j >= fd.len0 || !fd.ham[j]) tree_load(r, 256, pool, fd.l[j], stack);
-        if (fd.max_len >= MAX_STAT_LEN && !r.bad) tree_load(r, 256, pool, fd.l[MAX_STAT_LEN], stack);
+            if (j >= fd.len0 || !fd.ham[j]) { if (tree_load(r, 256, pool, fd.l[j], stack)) tree_table(fd.l[j], (uint16_t *)pool.take(2u << DEC_K)); }
+        if (fd.max_len >= MAX_STAT_LEN && !r.bad && tree_load(r, 256, pool, fd.l[MAX_STAT_LEN], stack))
+            tree_table(fd.l[MAX_STAT_LEN], (uint16_t *)pool.take(2u << DEC_K));
         r.align();
     }
     if (r.bad) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
@@ -290,7 +346,6 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     // ---- title body (cf. FetchTitleBody tasks.cpp:738-954): groups of 32 records, byte aligned ----
     {
         uint64_t tn = 0;
-        uint8_t num[16];
         for (uint32_t g0 = 0; g0 < n && !r.bad; g0 += GROUP) {
             const uint32_t g1 = g0 + GROUP < n ? g0 + GROUP : n;
             for (uint32_t f = 0; f < nf; ++f)
@@ -312,9 +367,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
                             v = fd.delta_coding ? fd.prev + fd.min_d + x : fd.min_v + x;
                         }
                         fd.prev = v;
-                        const uint32_t k = dec_put_decimal(num, (uint32_t)v);
-                        for (uint32_t j = 0; j < k; ++j) D.titles[tn + j] = num[j];
-                        tn += k;
+                        tn += dec_put_decimal(D.titles + tn, (uint32_t)v);
                     } else if (i != g0 && fd.gflag) {
                         for (uint32_t j = 0; j < fd.gval_len; ++j) D.titles[tn + j] = fd.gval[j];
                         tn += fd.gval_len;
@@ -346,13 +399,25 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
 
     // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees, codes by position ----
     uint64_t text = D.toff[n];
+    const uint64_t q_at = (text + 15) & ~15ull, s_at = q_at + ((qual_total + 15) & ~15ull);
+    if (s_at + qual_total > D.tcap) { O.err = ERR_CAPACITY; return; }
+    D.lay[0] = q_at; D.lay[1] = s_at;
+    uint8_t *d_qual = D.titles + q_at, *d_seq = D.titles + s_at;
     {
-        uint8_t qsym[256];
+        __shared__ uint8_t qsym[256];
         r.align();
         for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
         DTree *qt = (DTree *)pool.take(sizeof(DTree) * ((uint64_t)max_q + 1));
         if (!qt) { O.err = ERR_NOMEM; return; }
-        for (uint32_t p = 0; p <= max_q && !r.bad; ++p) tree_load(r, nqual, pool, qt[p], stack);
+        // the per-position tables: in LDS while they fit (the quality codes are most of the sub-block's symbols)
+        extern __shared__ __align__(16) uint16_t s_qtab[];
+        uint32_t Kq = DEC_K;   // the widest tables that fit (codes longer than Kq bits walk their tree)
+        while (Kq > 5 && (((uint64_t)max_q + 1) << Kq) > lds_entries) --Kq;
+        const bool q_lds = (((uint64_t)max_q + 1) << Kq) <= lds_entries;
+        uint16_t *qtab = q_lds ? s_qtab : (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
+        if (!qtab) { O.err = ERR_NOMEM; return; }
+        for (uint32_t p = 0; p <= max_q && !r.bad; ++p)
+            if (tree_load(r, nqual, pool, qt[p], stack)) tree_table(qt[p], qtab + ((size_t)p << Kq), Kq);
         r.align();
         if (r.bad) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
         uint64_t k = 0;
@@ -360,8 +425,12 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             const uint32_t L = D.qlen[i];
             uint32_t kept = 0;
             for (uint32_t j = 0; j < L; ++j) {
-                const uint8_t q = qsym[tree_get(qt[j + 1], r)];
-                D.qual[k++] = q;
+                const uint32_t e = qtab[((size_t)(j + 1) << Kq) + r.peek(Kq)];
+                uint32_t sym;
+                if (e) { r.skip(e >> 12); sym = e & 0xfffu; }
+                else sym = tree_get(qt[j + 1], r);
+                const uint8_t q = qsym[sym];
+                d_qual[k++] = q;
                 kept += q < 128;   // (a byte from 128 on is a transferred ambiguity code: no base in the DNA stream)
             }
             D.slen[i] = kept;
@@ -376,12 +445,13 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     if (!O.plain) {
         DTree dt;
         if (!tree_load(r, nsym, pool, dt, stack)) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
+        tree_table(dt, (uint16_t *)pool.take(2u << DEC_K));
         uint64_t k = 0;
         for (uint32_t i = 0; i < n && !r.bad; ++i)
             for (uint32_t j = 0; j < D.slen[i]; ++j) {
                 const uint32_t c = tree_get(dt, r);
                 if (c >= nsym) { r.bad = 1; break; }
-                D.seq[k++] = O.dsym[c];
+                d_seq[k++] = O.dsym[c];
             }
         if (r.bad) { O.err = ERR_FORMAT; return; }
     } else {
@@ -439,7 +509,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
             const uint8_t *t = D.titles + D.toff[i];
             for (uint32_t j = 0; j < tl; ++j) o[j] = t[j];      // (ends with the last field's separator, '\n')
             o += tl;
-            const uint8_t *q = D.qual + o_q;
+            const uint8_t *q = D.titles + D.lay[0] + o_q;
             uint64_t bi = o_b;                                   // index of the record's next base in the DNA stream
             for (uint32_t j = 0; j < L; ++j) {
                 const uint32_t qv = q[j];
@@ -453,7 +523,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
                     c = O.dsym[(sb[bp >> 3] >> (6 - (bp & 7))) & 3u];
                     ++bi;
                 } else {
-                    c = D.seq[bi++];
+                    c = D.titles[D.lay[1] + bi++];
                 }
                 o[j] = c;
                 o[L + 3 + j] = qo;
@@ -470,7 +540,10 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
 void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
                         uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out)
 {
-    hipLaunchKernelGGL(k_dec_streams, dim3(n_sb), dim3(64), 0, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap, (DecSub *)out);
+    const uint32_t lds_entries = 30u << 10;   // 60 KB of 16-bit table entries: the per-position tables of reads up to 59 bases
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_streams), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_entries));
+    hipLaunchKernelGGL(k_dec_streams, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
+                       (DecSub *)out, lds_entries);
 }
 
 void launch_dec_assemble(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch, uint64_t stride,
