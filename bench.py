@@ -84,11 +84,11 @@ def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
         "k_seq_qual_stats": 2 * bases,
         "k_measure_sq": 2 * bases,
         "k_pack_sq": 2 * bases + q_out + d_out,
-        # dense-stream path (kernels_dense.hip)
-        "k_split": raw + 2 * bases,
-        "k_dq_stats": 2 * bases,
-        "k_dq_measure": bases,
-        "k_dq_pack": 2 * bases + q_out + d_out,
+        # chunk-per-lane path (kernels_chunk.hip, NGSC_SQ_PATH=chunk)
+        "k_ck_stats": 2 * bases,
+        "k_ck_measure": bases,
+        "k_ck_pack": 2 * bases + q_out + d_out,
+        "k_zero_output": sum(sb.size for sb in res.subblocks),
     }
 
 
