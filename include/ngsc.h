@@ -202,6 +202,15 @@ int ngsc_compress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path,
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
                              double *seconds_out);
 
+/*
+ * `<in.ngsc> <out.fastq>`: the container read back (ReadFooter tasks.cpp:1203-1292; block headers as MakeHeader
+ * tasks.cpp:1179-1200 wrote them; the reference has the fragments but no caller).  Ranks ascending, each rank's sub-blocks
+ * through ngsc_decompress_device() in batches; rank r's text is written at r * (FS / P) + OV[r], so a record that two
+ * ranks stored appears once and the file gets its exact size back.  Accepts any block order, the
+ * reference's arrival order included.  seconds_out (nullable, 3 doubles): file reads, H2D + decode + D2H, writes.
+ */
+int ngsc_decompress_file(ngsc_ctx *ctx, const char *in_path, const char *out_path, double *seconds_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ EXPORTS = [
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
     "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
+    "ngsc_decompress_file",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -98,6 +99,8 @@ def lib():
     L.ngsc_decompress_device.restype = ctypes.c_int
     L.ngsc_decompress_device.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u32), u32, vp, u64, ctypes.POINTER(u64),
                                          ctypes.POINTER(u32), vp]
+    L.ngsc_decompress_file.restype = ctypes.c_int
+    L.ngsc_decompress_file.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
     L.ngsc_result_bytes.restype = u64
     L.ngsc_result_bytes.argtypes = [vp]
     L.ngsc_result_num_subblocks.restype = u32

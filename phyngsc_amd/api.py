@@ -171,6 +171,15 @@ class Engine:
         return sec[0], sec[1], sec[2]
 
 
+    def decompress_file(self, in_path: str, out_path: str) -> Tuple[float, float, float]:
+        """``<in.ngsc> <out.fastq>`` (ngsc.h: ngsc_decompress_file); returns (read, H2D+decode+D2H, write) seconds."""
+        sec = (ctypes.c_double * 3)()
+        rc = self._L.ngsc_decompress_file(self._h, in_path.encode(), out_path.encode(), sec)
+        if rc:
+            raise NgscError(rc, self._L.ngsc_last_hip_error(self._h).decode())
+        return sec[0], sec[1], sec[2]
+
+
 def compress_file_multi(engines: Sequence["Engine"], in_path: str, out_path: str, P: int = 8) -> Tuple[float, float, float]:
     """One process, several contexts (one per GPU): ranks are dealt in runs of P/len(engines); the file is
     byte-identical to the single-context one (ngsc.h: ngsc_compress_file_multi)."""

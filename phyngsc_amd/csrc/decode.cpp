@@ -5,8 +5,13 @@
 #include "ngsc_kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 using namespace ngsc;
@@ -76,6 +81,229 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     if (d_toff) (void)hipFree(d_toff);
     if (d_len) (void)hipFree(d_len);
     if (d_res) (void)hipFree(d_res);
+    return rc;
+}
+
+// ---- container reader --------------------------------------------------------------------------------------------------
+namespace {
+
+struct BitRd {   // MSB-first reads (the reading side of BitStream, bit_stream.h:280-433); never walks past the buffer
+    const uint8_t *p; uint64_t n, bit = 0; bool ok = true;
+    BitRd(const uint8_t *d, uint64_t len) : p(d), n(len) {}
+    uint32_t get(uint32_t w)
+    {
+        uint32_t v = 0;
+        for (; w; --w, ++bit) {
+            if ((bit >> 3) >= n) { ok = false; return 0; }
+            v = (v << 1) | ((p[bit >> 3] >> (7 - (bit & 7))) & 1u);
+        }
+        return v;
+    }
+};
+
+uint32_t ceil_log2_u32(uint32_t x) { uint32_t b = 0; while ((1ull << b) < x) ++b; return b; }
+
+struct FooterIn {   // ReadFooter, tasks.cpp:1203-1292 (written by MakeFooter :1104-1176)
+    uint32_t PS = 0, BS = 0, SS = 0, LBES = 0;
+    uint64_t FS = 0;
+    std::vector<uint32_t> OV, CBO, LBS;
+};
+
+bool parse_footer(const uint8_t *d, uint64_t len, FooterIn &f)
+{
+    BitRd r(d, len);
+    const uint32_t BEPS = r.get(4), BEFS = r.get(6), BEBS = r.get(4), BESS = r.get(4), BELB = r.get(5), BEOV = r.get(4);
+    f.LBES = r.get(1);
+    f.PS = r.get(BEPS);
+    if (BEFS > 32) { const uint64_t hi = r.get(BEFS - 32); f.FS = (hi << 32) | r.get(32); }
+    else f.FS = r.get(BEFS);
+    f.BS = r.get(BEBS);
+    f.SS = r.get(BESS);
+    if (!r.ok || f.PS < 1 || (uint64_t)f.BS * ceil_log2_u32(f.PS) > len * 8) return false;
+    f.OV.assign(f.PS, 0);
+    for (uint32_t i = 1; i < f.PS; ++i) f.OV[i] = r.get(BEOV);
+    const uint32_t cb = ceil_log2_u32(f.PS);
+    f.CBO.resize(f.BS);
+    for (uint32_t j = 0; j < f.BS; ++j) { f.CBO[j] = r.get(cb); if (f.CBO[j] >= f.PS) return false; }
+    if (!f.LBES) { f.LBS.resize(f.PS); for (uint32_t i = 0; i < f.PS; ++i) f.LBS[i] = r.get(BELB); }
+    return r.ok;
+}
+
+struct Piece { uint64_t off; uint32_t len; };
+struct SubIn { uint32_t rank; uint32_t bytes = 0; std::vector<Piece> pieces; };
+
+bool pread_all(int fd, void *dst, uint64_t n, uint64_t off)
+{
+    uint8_t *p = (uint8_t *)dst;
+    while (n) {
+        const ssize_t k = pread(fd, p, n, (off_t)off);
+        if (k <= 0) return false;
+        p += k; n -= (uint64_t)k; off += (uint64_t)k;
+    }
+    return true;
+}
+bool pwrite_all_at(int fd, const void *src, uint64_t n, uint64_t off)
+{
+    const uint8_t *p = (const uint8_t *)src;
+    while (n) {
+        const ssize_t k = pwrite(fd, p, n, (off_t)off);
+        if (k <= 0) return false;
+        p += k; n -= (uint64_t)k; off += (uint64_t)k;
+    }
+    return true;
+}
+double dsec() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// `.ngsc` -> FASTQ.  Footer, then every block's header (blocks lie in the footer's CBO order, 8 MiB each except a rank's
+// last), which gives each rank's sub-blocks as pieces of the file (a sub-block may continue over block borders: BCSS bits,
+// tasks.cpp:1179-1200); ranks ascending, their sub-blocks go through ngsc_decompress_device() in batches and the text of
+// rank r lands at its place in the output: s_r = r * (FS / P) + OV[r] (the first-record sync distance the footer keeps,
+// phyNGSC.cpp:131-160) up to s_(r+1).  A record that two ranks both stored (phyNGSC.cpp:295-300) is
+// thereby written once, and a file whose last line had no newline gets its exact size back.
+int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path, double *seconds_out)
+{
+    if (!c || !in_path || !out_path) return NGSC_ERR_ARG;
+    if (hipSetDevice(ngsc_ctx_device(c)) != hipSuccess) return NGSC_ERR_HIP;
+    const double t0 = dsec();
+    double t_read = 0, t_dev = 0, t_write = 0;
+    const int fd = open(in_path, O_RDONLY);
+    if (fd < 0) return NGSC_ERR_IO;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size < 4) { close(fd); return sb.st_size < 4 ? NGSC_ERR_FORMAT : NGSC_ERR_IO; }
+    const uint64_t size = (uint64_t)sb.st_size;
+    uint8_t tail[2];
+    if (!pread_all(fd, tail, 2, size - 2)) { close(fd); return NGSC_ERR_IO; }
+    const uint64_t flen = ((uint64_t)tail[0] << 8) | tail[1];
+    if (flen + 2 > size) { close(fd); return NGSC_ERR_FORMAT; }
+    std::vector<uint8_t> fbytes(flen);
+    FooterIn F;
+    if (!pread_all(fd, fbytes.data(), flen, size - 2 - flen)) { close(fd); return NGSC_ERR_IO; }
+    if (!parse_footer(fbytes.data(), flen, F)) { close(fd); return NGSC_ERR_FORMAT; }
+    const uint64_t body = size - 2 - flen;
+    // block sizes (tasks.cpp:1280-1292): 8 MiB except the last block of each rank; with LBES all last blocks share a size
+    std::vector<int64_t> last_of(F.PS, -1);
+    for (uint32_t j = 0; j < F.BS; ++j) last_of[F.CBO[j]] = j;
+    std::vector<uint64_t> bsize(F.BS, NGSC_BLOCK_SIZE), boff(F.BS + 1, 0);
+    uint32_t n_last = 0;
+    for (uint32_t w = 0; w < F.PS; ++w) n_last += last_of[w] >= 0;
+    if (F.LBES) {
+        const uint64_t full = (uint64_t)(F.BS - n_last) * NGSC_BLOCK_SIZE;
+        if (!n_last || body < full || (body - full) % n_last) { close(fd); return NGSC_ERR_FORMAT; }
+        for (uint32_t w = 0; w < F.PS; ++w) if (last_of[w] >= 0) bsize[last_of[w]] = (body - full) / n_last;
+    } else {
+        for (uint32_t w = 0; w < F.PS; ++w) if (last_of[w] >= 0) bsize[last_of[w]] = F.LBS[w];
+    }
+    for (uint32_t j = 0; j < F.BS; ++j) boff[j + 1] = boff[j] + bsize[j];
+    if (boff[F.BS] != body) { close(fd); return NGSC_ERR_FORMAT; }
+    // headers -> per-rank sub-block piece lists
+    std::vector<std::vector<SubIn>> subs(F.PS);
+    std::vector<SubIn> open_sub(F.PS);
+    std::vector<uint8_t> open_has(F.PS, 0);
+    const uint32_t bewr = ceil_log2_u32(F.PS);
+    std::vector<uint8_t> hb(4096 + 8);
+    double tr = dsec();
+    for (uint32_t j = 0; j < F.BS; ++j) {
+        const uint64_t n = std::min<uint64_t>(hb.size(), bsize[j]);
+        if (!pread_all(fd, hb.data(), n, boff[j])) { close(fd); return NGSC_ERR_IO; }
+        BitRd r(hb.data(), n);
+        const uint32_t wrid = r.get(bewr), bhs = r.get(12), nosb = r.get(6), beso = r.get(5), bcss = r.get(2);
+        if (!r.ok || wrid != F.CBO[j] || bhs > bsize[j]) { close(fd); return NGSC_ERR_FORMAT; }
+        uint64_t pos = boff[j] + bhs;
+        for (uint32_t i = 0; i < nosb; ++i) {
+            const uint32_t ln = r.get(beso);
+            if (!r.ok || pos + ln > boff[j + 1]) { close(fd); return NGSC_ERR_FORMAT; }
+            const bool first_cont = i == 0 && (bcss & 2), last_cont = i == nosb - 1 && (bcss & 1);
+            if (first_cont != (open_has[wrid] != 0)) { close(fd); return NGSC_ERR_FORMAT; }   // a continuation needs its beginning
+            if (!first_cont) { open_sub[wrid] = SubIn(); open_sub[wrid].rank = wrid; }
+            open_sub[wrid].pieces.push_back({pos, ln});
+            open_sub[wrid].bytes += ln;
+            pos += ln;
+            open_has[wrid] = last_cont;
+            if (!last_cont) subs[wrid].push_back(std::move(open_sub[wrid]));
+        }
+    }
+    for (uint32_t w = 0; w < F.PS; ++w) if (open_has[w]) { close(fd); return NGSC_ERR_FORMAT; }
+    t_read += dsec() - tr;
+    // where each rank's text belongs
+    std::vector<uint64_t> s_at(F.PS + 1);
+    for (uint32_t w = 0; w < F.PS; ++w) s_at[w] = std::min<uint64_t>(F.FS, (uint64_t)w * (F.FS / F.PS) + F.OV[w]);
+    s_at[F.PS] = F.FS;
+    for (uint32_t w = 0; w < F.PS; ++w) if (s_at[w + 1] < s_at[w]) { close(fd); return NGSC_ERR_FORMAT; }
+    const int ofd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (ofd < 0) { close(fd); return NGSC_ERR_IO; }
+    // batches: at most 256 sub-blocks or 1 GiB of compressed bytes
+    std::vector<const SubIn *> order;
+    for (uint32_t w = 0; w < F.PS; ++w) for (const SubIn &x : subs[w]) order.push_back(&x);
+    const uint64_t text_per_sb = 10ull << 20;
+    std::vector<uint64_t> written(F.PS, 0);
+    int rc = NGSC_OK;
+    uint8_t *h_in = nullptr, *h_text = nullptr, *d_in = nullptr, *d_text = nullptr;
+    uint64_t cap_in = 0, cap_text = 0;
+    for (size_t b0 = 0; b0 < order.size() && !rc;) {
+        size_t b1 = b0; uint64_t bytes = 0;
+        while (b1 < order.size() && b1 - b0 < 256 && bytes + order[b1]->bytes + 32 <= (1ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
+        if (b1 == b0) { bytes = (order[b1]->bytes + 15u) & ~15ull; ++b1; }
+        const uint32_t nb = (uint32_t)(b1 - b0);
+        const uint64_t need_in = bytes + 64, need_text = nb * text_per_sb;
+        if (need_in > cap_in) {
+            if (h_in) (void)hipHostFree(h_in); if (d_in) (void)hipFree(d_in);
+            h_in = d_in = nullptr; cap_in = need_in;
+            if (hipHostMalloc((void **)&h_in, cap_in, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_in, cap_in) != hipSuccess) { rc = NGSC_ERR_NOMEM; break; }
+        }
+        if (need_text > cap_text) {
+            if (h_text) (void)hipHostFree(h_text); if (d_text) (void)hipFree(d_text);
+            h_text = d_text = nullptr; cap_text = need_text;
+            if (hipHostMalloc((void **)&h_text, cap_text, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_text, cap_text) != hipSuccess) { rc = NGSC_ERR_NOMEM; break; }
+        }
+        tr = dsec();
+        std::vector<uint64_t> off(nb), toff(nb + 1);
+        std::vector<uint32_t> len(nb);
+        uint64_t pos = 0;
+        memset(h_in, 0, need_in);
+        for (uint32_t k = 0; k < nb && !rc; ++k) {
+            const SubIn &x = *order[b0 + k];
+            off[k] = pos; len[k] = x.bytes;
+            uint64_t q = pos;
+            for (const Piece &pc : x.pieces) { if (!pread_all(fd, h_in + q, pc.len, pc.off)) { rc = NGSC_ERR_IO; break; } q += pc.len; }
+            pos += (x.bytes + 15u) & ~15ull;
+        }
+        t_read += dsec() - tr;
+        if (rc) break;
+        tr = dsec();
+        if (hipMemcpy(d_in, h_in, need_in, hipMemcpyHostToDevice) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        rc = ngsc_decompress_device(c, d_in, off.data(), len.data(), nb, d_text, cap_text, toff.data(), nullptr, nullptr);
+        if (rc) break;
+        if (hipMemcpy(h_text, d_text, toff[nb], hipMemcpyDeviceToHost) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        t_dev += dsec() - tr;
+        tr = dsec();
+        for (uint32_t k = 0; k < nb; ++k) {   // (consecutive sub-blocks of a rank are consecutive in the text: one write per run)
+            const uint32_t w = order[b0 + k]->rank;
+            uint32_t k2 = k;
+            while (k2 + 1 < nb && order[b0 + k2 + 1]->rank == w) ++k2;
+            const uint64_t have = toff[k2 + 1] - toff[k], room = s_at[w + 1] - s_at[w] - std::min(written[w], s_at[w + 1] - s_at[w]);
+            const uint64_t n = std::min(have, room);
+            if (n && !pwrite_all_at(ofd, h_text + toff[k], n, s_at[w] + written[w])) { rc = NGSC_ERR_IO; break; }
+            written[w] += n;
+            k = k2;
+        }
+        t_write += dsec() - tr;
+        b0 = b1;
+    }
+    if (!rc)   // every rank must have filled its stretch of the file
+        for (uint32_t w = 0; w < F.PS; ++w) if (written[w] != s_at[w + 1] - s_at[w]) { rc = NGSC_ERR_FORMAT; break; }
+    if (!rc && ftruncate(ofd, (off_t)F.FS) != 0) rc = NGSC_ERR_IO;
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_text) (void)hipHostFree(h_text);
+    if (d_in) (void)hipFree(d_in);
+    if (d_text) (void)hipFree(d_text);
+    close(fd);
+    if (close(ofd) != 0 && !rc) rc = NGSC_ERR_IO;
+    if (seconds_out) { seconds_out[0] = t_read; seconds_out[1] = t_dev; seconds_out[2] = t_write; }
+    if (getenv("NGSC_VERBOSE"))
+        fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks: read %.3f s, H2D+decode+D2H %.3f s, write %.3f s, total %.3f s\n", F.PS, F.BS,
+                order.size(), t_read, t_dev, t_write, dsec() - t0);
     return rc;
 }
 

@@ -5,7 +5,8 @@
 // default 8): the output is what the reference writes with P processes, up to block order.  The
 // <threads> argument is accepted and ignored (the output never depended on it).  `--devices 0,1,2,3` spreads
 // the ranks over several GPUs from this one process (P must be a multiple of the device count); the file
-// does not depend on how many devices worked on it.
+// does not depend on how many devices worked on it.  `ngsc -d <in.ngsc> <out.fastq> [--device D]` is the way back
+// (ngsc_decompress_file; the reference has no decompressor).
 #include "../../include/ngsc.h"
 
 #include <cstdio>
@@ -18,9 +19,11 @@ int main(int argc, char **argv)
     const char *in = nullptr, *out = nullptr;
     unsigned P = 8;
     int npos = 0;
+    bool decode = false;
     std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) P = (unsigned)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-d") || !strcmp(argv[i], "--decompress")) decode = true;
         else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) {   // the first N devices
             devices.clear();
             for (int d = 0, n = atoi(argv[++i]); d < n; ++d) devices.push_back(d);
@@ -40,15 +43,15 @@ int main(int argc, char **argv)
     }
     if (npos < 2 || npos > 3) {
         fprintf(stderr, "\n[E] ERROR: Incorrect number of arguments. Usage:\n");
-        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--gpus N | --devices D[,D..]]\n");
+        fprintf(stderr, "\n           ngsc input_filename.fastq output_filename.ngsc [num_threads] [--ranks P] [--gpus N | --devices D[,D..]]\n           ngsc -d input_filename.ngsc output_filename.fastq [--device D]\n");
         return 1;
     }
-    if (P < 2) {
+    if (!decode && P < 2) {
         fprintf(stderr, "\n[E] ERROR: Number of ranks (--ranks) is less than 2.\n");
         return 1;
     }
     if (devices.empty()) devices.push_back(0);
-    if (P % devices.size()) {
+    if (!decode && P % devices.size()) {
         fprintf(stderr, "\n[E] ERROR: Number of ranks (%u) is not a multiple of the number of devices (%zu).\n", P, devices.size());
         return 1;
     }
@@ -64,9 +67,10 @@ int main(int argc, char **argv)
         }
         ctxs.push_back(ctx);
     }
-    printf("\n[I] INFO: Processing <<%s>> with %u virtual ranks on %zu GPU context(s).\n", in, P, ctxs.size());
     double sec[3] = {0, 0, 0};
-    int rc = ngsc_compress_file_multi(ctxs.data(), (uint32_t)ctxs.size(), in, out, P, sec);
+    if (decode) printf("\n[I] INFO: Decompressing <<%s>> on GPU %d.\n", in, devices[0]);
+    else printf("\n[I] INFO: Processing <<%s>> with %u virtual ranks on %zu GPU context(s).\n", in, P, ctxs.size());
+    int rc = decode ? ngsc_decompress_file(ctxs[0], in, out, sec) : ngsc_compress_file_multi(ctxs.data(), (uint32_t)ctxs.size(), in, out, P, sec);
     if (rc) {
         fprintf(stderr, "\n[E] ERROR: %s\n", ngsc_strerror(rc));
         if (rc == NGSC_ERR_HIP)
@@ -82,8 +86,13 @@ int main(int argc, char **argv)
     // (a context's result tables describe its last job only: report the file that was written)
     unsigned long long out_bytes = 0;
     if (FILE *f = fopen(out, "rb")) { fseek(f, 0, SEEK_END); out_bytes = (unsigned long long)ftell(f); fclose(f); }
-    printf("\nRANKS\tREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tOUT_BYTES\n");
-    printf("%u\t%f\t%f\t%f\t%llu\n", P, sec[0], sec[1], sec[2], out_bytes);
+    if (decode) {
+        printf("\nREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tOUT_BYTES\n");
+        printf("%f\t%f\t%f\t%llu\n", sec[0], sec[1], sec[2], out_bytes);
+    } else {
+        printf("\nRANKS\tREAD\t\tH2D+DEVICE+D2H\tWRITE\t\tOUT_BYTES\n");
+        printf("%u\t%f\t%f\t%f\t%llu\n", P, sec[0], sec[1], sec[2], out_bytes);
+    }
     destroy_all();
     return 0;
 }

@@ -531,6 +531,51 @@ def test_gpu_round_trip(eng, cfg, size, P):
         assert used == lens[k] and host[toff[k]:toff[k + 1]].tobytes() == want
 
 
+@pytest.mark.parametrize("ngsc_path", REVERSIBLE, ids=[os.path.basename(p) for p in REVERSIBLE])
+def test_decompress_file_on_reference_outputs(eng, ngsc_path, tmp_path):
+    """`ngsc -d` (ngsc_decompress_file: footer, block headers and sub-block pieces read back in C++) on the committed
+    outputs of the unmodified reference - its block order is arrival order - gives the FASTQ files they were made from,
+    to the byte (also for the file whose last line has no newline)."""
+    m = re.match(r"(.*)\.p(\d+)\.ngsc$", ngsc_path)
+    with open(m.group(1) + ".fastq", "rb") as f:
+        want = f.read()
+    outp = tmp_path / "back.fastq"
+    eng.decompress_file(ngsc_path, str(outp))
+    assert outp.read_bytes() == want
+
+
+def test_decompress_file_shared_records_and_cli(eng, tmp_path):
+    """(a) A record two ranks both stored (test_record_shared_by_two_ranks) comes back once: every rank's text is placed
+    by the footer's sync distances.  (b) The command line both ways on a file of several groups' worth of blocks with
+    sub-blocks that continue over block borders; a container of the wrong size is refused with exit code 4."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i in range(40):
+        L = rnd.randint(36, 536)
+        recs.append(b"@%d\n%s\n+\n%s\n" % (10 ** 9 + rnd.randrange(10 ** 9), bytes(rnd.choice(b"ACGT") for _ in range(L)),
+                                            bytes(rnd.choice(b"(=") for _ in range(L))))
+    data = b"".join(recs)
+    for P in (8, 12, 16, 20, 24):
+        _, out = _gpu(eng, data, P)
+        (tmp_path / "s.ngsc").write_bytes(out)
+        eng.decompress_file(str(tmp_path / "s.ngsc"), str(tmp_path / "s.fastq"))
+        assert (tmp_path / "s.fastq").read_bytes() == data, P
+    big = fastq_gen.generate(fastq_gen.CFG5_300, target_bytes=150_000_000)
+    inp, mid, back = tmp_path / "a.fastq", tmp_path / "a.ngsc", tmp_path / "a.back"
+    big.tofile(inp)
+    exe = os.path.join(ROOT, "phyngsc_amd", "bin", "ngsc")
+    assert subprocess.run([exe, str(inp), str(mid), "--ranks", "6"], capture_output=True).returncode == 0
+    r = subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert back.read_bytes() == big.tobytes()
+    raw = mid.read_bytes()
+    mid.write_bytes(raw[:len(raw) // 2])          # (the format has no checksums: what can be refused is a broken structure)
+    assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
+    mid.write_bytes(raw[:8 << 20] + raw[(8 << 20) + 5:])
+    assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
+
+
 def test_gpu_decoder_refuses_garbage(eng):
     data = fastq_gen.generate(fastq_gen.CFG1, target_bytes=2_000_000)
     res, _ = _gpu(eng, data, 2)
