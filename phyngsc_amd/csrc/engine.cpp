@@ -545,9 +545,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
 
     // ---- stage C: statistics, trees, measure.  The title chain and the sequence/quality chain share nothing
     // until the trees are built and can run on two streams. ----
-    // NGSC_OVERLAP=1: the title chain on a second stream beside the sequence/quality chain.  Worth 2-3 % on the bench
-    // workload (both chains are limited by the same per-CU resources), so the default keeps everything on the
-    // caller's stream, where per-kernel timings mean what they say.
+    // Two streams.  Default ("staggered", also NGSC_OVERLAP=2): the title chain and the sequence/quality chain are forked
+    // behind the sequence/quality statistics kernel, so that the latency-bound kernels of one chain (sub-block finalisation,
+    // the Huffman waves, later headers and length tables) run beside a throughput kernel of the other instead of alone on the
+    // GPU; the payload pack kernel, the longest of all, runs alone.  3 % on the 1 GB bench job, 10-17 % on 400 MB jobs, which
+    // is the size the file driver works in.  NGSC_OVERLAP=0: everything on the caller's stream - also taken whenever every
+    // kernel is being timed (ngsc_set_profiling without ngsc_profile_only), so that per-kernel durations mean what they say.
+    // NGSC_OVERLAP=1: round 1's form, the title chain beside the sequence/quality chain with a join before the Huffman kernels.
     // Colour-space sub-blocks (found by the statistics kernels of a first run, which then ends with ERR_COLORSPACE): the job
     // runs on a copy of its input in which they are decoded to bases as the reference decodes them (kernels_cs.hip)
     if (c->cs_retry) {
@@ -561,7 +565,22 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     const char *ov_env = getenv("NGSC_OVERLAP");
     const bool overlap = ov_env && !strcmp(ov_env, "1");
+    const bool time_all = c->profiling && c->profile_only.empty();
+    const bool stagger = (ov_env ? !strcmp(ov_env, "2") : !time_all) && (sq_reg || sq_chunk) && !c->debug_sync;
     hipStream_t st2 = overlap ? c->side_stream : st;
+    hipStream_t sts = stagger ? c->side_stream : st;   // the sequence/quality chain's stream behind its statistics kernel
+    auto fork_s = [&]() -> int {
+        if (!stagger) return NGSC_OK;
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(sts, c->ev_fork, 0));
+        return NGSC_OK;
+    };
+    auto join_s = [&]() -> int {
+        if (!stagger) return NGSC_OK;
+        HIPCHK(c, hipEventRecord(c->ev_join, sts));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+        return NGSC_OK;
+    };
     auto fork = [&]() -> int {
         if (!overlap) return NGSC_OK;
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -577,6 +596,24 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // titles of at most 128 bytes take the word-parallel kernels, with one or two 64-bit mask words (NGSC_TITLE_PATH=reg forces the byte-serial ones)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
     const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
+    if (stagger) {
+        { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
+        if (sq_chunk) { KScope k(c, st, "k_ck_stats"); launch_ck_stats(st, A, max_rec, TR, max_rec_bytes); }
+        else { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
+        if ((rc = fork_s())) return rc;
+        { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
+        { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
+        if (sq_chunk) { KScope k(c, sts, "k_ck_measure"); launch_ck_measure(sts, A, max_rec, TR, max_rec_bytes); }
+        else { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
+        if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
+        else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+        { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
+        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
+        { KScope k(c, st, "k_huffman_fields"); launch_huffman_fields(st, A); }
+        { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
+        { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
+        if ((rc = join_s())) return rc;
+    } else {
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_rec0_fields"); launch_rec0_fields(st2, A); }
     if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec); }
@@ -603,6 +640,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
     }
     if ((rc = join())) return rc;
+    }
     if (R) { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
     else { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
@@ -611,10 +649,12 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, st));
     // ---- pack ----
     { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap); }
-    { KScope k(c, st, "k_write_headers"); launch_write_headers(st, A, d_qrowoff); }
-    { KScope k(c, st, "k_pack_lentable"); launch_pack_lentable(st, A, max_rec); }
+    if ((rc = fork_s())) return rc;   // (staggered: headers and length tables beside the title pack kernel)
+    { KScope k(c, sts, "k_write_headers"); launch_write_headers(sts, A, d_qrowoff); }
+    { KScope k(c, sts, "k_pack_lentable"); launch_pack_lentable(sts, A, max_rec); }
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
+    if ((rc = join_s())) return rc;
     if (sq_reg || sq_chunk) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
         // length, + 25 % (from the record count: no stream size has to come back to the host first; a tile that needs

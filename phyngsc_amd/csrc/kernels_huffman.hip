@@ -59,12 +59,12 @@ __device__ void build_tree_wave(Tree &T, uint32_t n)
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_huffman_sb(Arena A)
+__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0)
 {
     if (*A.err) return;
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     __shared__ Tree T;
-    const uint32_t s = blockIdx.y, t = blockIdx.x;
+    const uint32_t s = blockIdx.y, t = blockIdx.x + t0;
     const int lane = threadIdx.x;
     const SbState &sb = A.sb[s];
     const bool fits_small = sb.nqual <= SMALL_TREE && sb.nsym <= SMALL_TREE;
@@ -146,8 +146,20 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A)
 
 void launch_huffman_sb(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A);
-    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1 + MAX_FIELDS, A.n_sb), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
+    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1 + MAX_FIELDS, A.n_sb), dim3(64), 0, st, A, 0u);
+}
+
+// The same trees in two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
+// sequence/quality statistics only, the numeric title field trees the title statistics only.
+void launch_huffman_sq(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
+    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
+}
+void launch_huffman_fields(hipStream_t st, const Arena &A)
+{
+    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(MAX_FIELDS, A.n_sb), dim3(64), 0, st, A, A.qrows + 1);
 }
 
 void launch_huffman_text(hipStream_t st, const Arena &A)

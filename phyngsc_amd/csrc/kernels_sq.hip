@@ -352,18 +352,21 @@ struct SqTabs {
 constexpr uint32_t SQ_QS = SR_HCOLS + 1;
 constexpr uint32_t SQ_QPAD = 0x51515151u;        // 33 + 48 in every byte
 constexpr uint32_t SQ_QROWS_EXTRA = 17;          // pad bytes of the last chunk, and the (q - 33) & 63 reach of the general path
+// (row_lo: the table holds the rows row_lo .. row_lo + lds_rows - 1 of the sub-block's table - the pack kernel walks long
+// reads window by window with a table of one window's rows, see k_sq_pack_reg)
 template <class T>
-__device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const SbState &sb, T *s_qtab, uint32_t lds_rows)
+__device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const SbState &sb, T *s_qtab, uint32_t lds_rows, uint32_t row_lo = 0)
 {
     const uint32_t nq = sb.nqual;
     const uint32_t *qg = A.qcodes + (size_t)s * A.qrows * 256;
     for (uint32_t k = threadIdx.x; k < (lds_rows + SQ_QROWS_EXTRA) * SQ_QS; k += SR_THREADS) s_qtab[k] = 0;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < lds_rows * nq; k += SR_THREADS) {
+    const uint32_t have = A.qrows > row_lo ? (A.qrows - row_lo < lds_rows ? A.qrows - row_lo : lds_rows) : 0;
+    for (uint32_t k = threadIdx.x; k < have * nq; k += SR_THREADS) {
         const uint32_t row = k / nq, ci = k % nq;
         const uint32_t col = (uint32_t)sb.qualities[ci] - 33u;
         if (col < SR_HCOLS) {
-            const uint32_t e = qg[(size_t)row * 256 + ci];
+            const uint32_t e = qg[(size_t)(row_lo + row) * 256 + ci];
             s_qtab[row * SQ_QS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
         }
     }
@@ -372,7 +375,7 @@ __device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const S
 // May the lean paths run on this sub-block?  Every alphabet symbol below 128 has a table column (the symbols from 128 on are
 // transferred qualities, or raw bytes with the high bit set, which the lean paths test for per chunk) and every row is in
 // the table.  Whole workgroup; thread = alphabet index.
-__device__ __forceinline__ bool sq_lean_alphabet(const SbState &sb, uint32_t lds_rows, uint32_t *s_flag)
+__device__ __forceinline__ bool sq_lean_alphabet(const SbState &sb, uint32_t lds_rows, uint32_t *s_flag, bool windowed = false)
 {
     if (threadIdx.x == 0) *s_flag = 0;
     __syncthreads();
@@ -381,7 +384,7 @@ __device__ __forceinline__ bool sq_lean_alphabet(const SbState &sb, uint32_t lds
         if (q < 128 && (q < 33 || q > 32 + SR_HCOLS)) atomicOr(s_flag, 1u);
     }
     __syncthreads();
-    return *s_flag == 0 && lds_rows > sb.max_q;
+    return *s_flag == 0 && (windowed || lds_rows > sb.max_q);
 }
 
 // entry (code << 5 | len) of quality byte q at position row-1, any q, any row
@@ -576,8 +579,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 
 // ---- pack ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw)
+__global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
 {
+    // win != 0 (long reads): the table holds one WINDOW of win positions (rows r0 .. r0 + win, lds_rows = win + 1), refilled
+    // window after window for every tile - a [301][49] table plus staging left room for two workgroups per CU, a window
+    // of 48 rows leaves room for four, and the lean path no longer needs the whole table to fit.
     if (*A.err) return;
     extern __shared__ __align__(16) uint32_t s_dynw[];   // [lds_rows][64] quality entries | staging (quality sw_q, DNA sw_d words)
     __shared__ uint32_t s_dcode[256];
@@ -597,9 +603,10 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
     s_qcode[tid] = sb.qua_code[tid];
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
-    sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
+    if (!win) sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
+    const uint32_t n_win = win ? (sb.max_q + win - 1) / win : 1u, win_chunks = win ? win / 16 : ~0u;   // (uniform over the workgroup)
     const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
     const uint32_t eA = s_dcode['A'], eC = s_dcode['C'], eT = s_dcode['T'], eG = s_dcode['G'];
     const uint32_t ltab = (eA & 31u) | ((eC & 31u) << 8) | ((eT & 31u) << 16) | ((eG & 31u) << 24);
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     __syncthreads();
     const bool short_codes = !s_longcode;
     __shared__ uint32_t s_leanflag;
-    const bool lean_wg = sq_lean_alphabet(sb, lds_rows, &s_leanflag);
+    const bool lean_wg = sq_lean_alphabet(sb, lds_rows, &s_leanflag, win != 0);
     uint32_t *outw = reinterpret_cast<uint32_t *>(A.out);
     const uint64_t qbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_hdr) * 8;
     const uint64_t dbase = (sb.out_off + sb.info_len + sb.title_len + sb.qual_len + sb.dna_hdr) * 8;
@@ -659,7 +666,14 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
             Sn = load16_unaligned(A.buf, s0, A.buf_len);
             Qn = load16_unaligned(A.buf, q0, A.buf_len);
         }
-        for (uint32_t grp = 0; __any(16 * NBX * grp < L); ++grp) {
+        for (uint32_t w = 0; w < n_win; ++w) {
+        const uint32_t r0 = w * win;
+        if (win) {   // (whole workgroup: n_win comes from the sub-block's longest read)
+            __syncthreads();
+            sq_fill_qtab(A, s, sb, s_qtab, lds_rows, r0);
+            __syncthreads();
+        }
+        for (uint32_t grp = w * (win_chunks / NBX); (!win || grp < (w + 1) * (win_chunks / NBX)) && __any(16 * NBX * grp < L); ++grp) {
             uint4 Sb[NBX], Qb[NBX];
             if constexpr (BURST) {
 #pragma unroll
@@ -683,6 +697,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
             for (uint32_t kb = 0; kb < NBX; ++kb) {
                 if (kb == 0 || __any(16 * (NBX * grp + kb) < L)) {
                     const uint32_t ch = NBX * grp + kb;
+                    const uint32_t lrow0 = 16 * ch + 1 - r0;   // row of the chunk's first position inside the table
                     const uint4 S = Sb[kb], Q = Qb[kb];
                     const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
                     const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                         const uint32_t qpatch = xfer ? ambm : 0u;
                         const bool masked = tails || __any(qpatch != 0);
                         // quality: 16 entries in flight together (bytes without an entry read the zero column)
-                        const uint32_t rbase = (16 * ch + 1) * SQ_QS - 33u;
+                        const uint32_t rbase = lrow0 * SQ_QS - 33u;
                         uint32_t e[16];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
@@ -809,7 +824,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                         }
                         qbm &= validm;
                     }
-                    const uint32_t rows_left = lds_rows > 16 * ch + 1 ? lds_rows - (16 * ch + 1) : 0;   // table rows for this chunk's positions
+                    const uint32_t rows_left = lds_rows > lrow0 ? lds_rows - lrow0 : 0;   // table rows for this chunk's positions
                     const uint32_t rowm = rows_left >= 16 ? 0xffffu : ((1u << rows_left) - 1u);
                     // quality bytes whose entry is not in the LDS table: odd bytes, transferred ones, rows past the table
                     const uint32_t qpatch = (qbm | (xfer ? ambm : 0u) | (validm & ~rowm));
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
 #pragma unroll
                             for (uint32_t b = 0; b < 4; ++b) {
                                 const uint32_t u = 4 * k + b;
-                                const uint32_t row = row0 + u < lds_rows ? row0 + u : lds_rows - 1;
+                                const uint32_t row = lrow0 + u < lds_rows ? lrow0 + u : lds_rows - 1;
                                 e[b] = s_qtab[row * SQ_QS + ((sr_byte(qw, u) - 33u) & 63u)];
                             }
                             if (__any((qpatch >> (4 * k)) & 15u)) {
@@ -897,6 +912,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                 }
             }
         }
+        }   // (windows)
         if (L) { wq_.finish(); wd_.finish(); }
         __syncthreads();
         if (q_lds) {
@@ -970,9 +986,19 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw);
 }
 
+// Long reads: a table of one window of positions (NGSC_SQ_WINDOW rows, a multiple of 16; 0 = never) once the whole table
+// would be well beyond a window (reads of 65 bases and more at the default of 48).
+static uint32_t sr_pack_window(const Arena &A)
+{
+    const char *e = getenv("NGSC_SQ_WINDOW");
+    const uint32_t win = e ? (uint32_t)atoi(e) / 16 * 16 : 48;
+    return win && A.qrows > win + 1 + 16 ? win : 0;
+}
+
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
 {
-    const uint32_t rows = sr_rows_for(A.qrows, 4, 48u << 10);
+    const uint32_t win = sr_pack_window(A);
+    const uint32_t rows = win ? win + 1 : sr_rows_for(A.qrows, 4, 48u << 10);
     if (sw_q > 8192) sw_q = 8192;
     if (sw_d > 6144) sw_d = 6144;
     const uint32_t tpw = sr_records_per_wg(A, max_rec) / SR_THREADS;
@@ -982,7 +1008,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     // is bound by its bit writers, not by the loads), so only that variant is built
     auto kern = k_sq_pack_reg<false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win);
 }
 
 }  // namespace ngsc

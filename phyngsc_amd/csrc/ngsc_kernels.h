@@ -44,6 +44,8 @@ void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool us
 
 // ---- kernels_huffman.hip ----
 void launch_huffman_sb(hipStream_t st, const Arena &A);
+void launch_huffman_sq(hipStream_t st, const Arena &A);
+void launch_huffman_fields(hipStream_t st, const Arena &A);
 void launch_huffman_text(hipStream_t st, const Arena &A);
 
 // ---- kernels_pack.hip ----
