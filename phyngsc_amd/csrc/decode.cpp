@@ -25,6 +25,7 @@ size_t dec_sub_bytes();
 int32_t dec_sub_err(const void *h, uint32_t s);
 uint64_t dec_sub_text(const void *h, uint32_t s);
 uint32_t dec_sub_records(const void *h, uint32_t s);
+void dec_sub_ticks(const void *h, uint32_t s, uint64_t *t);
 }
 
 extern "C" {
@@ -62,6 +63,12 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
             break;
         }
         std::vector<uint64_t> toff(nb);
+        if (getenv("NGSC_VERBOSE")) {   // the slowest sub-block of the batch, phase by phase (100 MHz ticks)
+            uint64_t mx[3] = {0, 0, 0};
+            for (uint32_t k = 0; k < nb; ++k) { uint64_t t[3]; dec_sub_ticks(h_res.data(), k, t); for (int q = 0; q < 3; ++q) mx[q] = std::max(mx[q], t[q]); }
+            fprintf(stderr, "[ngsc decode] %u sub-blocks: header + titles %.1f ms, qualities %.1f ms, bases %.1f ms (slowest of the batch)\n", nb,
+                    mx[0] / 1e5, mx[1] / 1e5, mx[2] / 1e5);
+        }
         for (uint32_t k = 0; k < nb && !rc; ++k) {
             if (dec_sub_err(h_res.data(), k)) { rc = dec_sub_err(h_res.data(), k); break; }
             toff[k] = text_pos;

@@ -31,7 +31,7 @@ struct BitIn {
     uint32_t bad;          // 1 malformed stream, 2 scratch pool exhausted, 3 text capacity
     __device__ void init(const uint8_t *ptr, uint64_t nbytes) { p = ptr; nbits = nbytes * 8; pos = 0; win = 0; have = 0; bad = 0; }
     __device__ void seek(uint64_t bitpos) { pos = bitpos; win = 0; have = 0; }
-    __device__ void fill()
+    __device__ __noinline__ void fill()
     {
         if (have == 0 && (pos & 7) && pos < nbits) {   // open the window in the middle of a byte
             win = ((uint64_t)p[pos >> 3] << 56) << (pos & 7);
@@ -49,7 +49,7 @@ struct BitIn {
             } else break;
         }
     }
-    __device__ uint32_t bits(uint32_t n)   // n <= 32
+    __device__ __forceinline__ uint32_t bits(uint32_t n)   // n <= 32
     {
         if (!n) return 0;
         if (pos + n > nbits) { bad = bad ? bad : 1; pos = nbits; have = 0; win = 0; return 0; }
@@ -60,12 +60,12 @@ struct BitIn {
         pos += n;
         return v;
     }
-    __device__ uint32_t peek(uint32_t n)   // the next n <= 16 bits without moving (zeros behind the end of the stream)
+    __device__ __forceinline__ uint32_t peek(uint32_t n)   // the next n <= 16 bits without moving (zeros behind the end of the stream)
     {
         if (have < n) fill();
         return (uint32_t)(win >> (64 - n));
     }
-    __device__ void skip(uint32_t n)       // n bits that peek() has shown
+    __device__ __forceinline__ void skip(uint32_t n)       // n bits that peek() has shown
     {
         if (!n) return;
         if (pos + n > nbits) { bad = bad ? bad : 1; pos = nbits; have = 0; win = 0; return; }
@@ -73,7 +73,7 @@ struct BitIn {
         have -= n;
         pos += n;
     }
-    __device__ uint32_t bit() { return bits(1); }
+    __device__ __forceinline__ uint32_t bit() { return bits(1); }
     __device__ void align()
     {
         const uint32_t r = (uint32_t)(pos & 7);
@@ -94,7 +94,8 @@ constexpr uint32_t DEC_K = 9;
 
 // Decode table of a loaded tree: a dependent load per SYMBOL instead of one per code bit (a lone lane pays the full
 // latency of each).  Depth-first over the codes of at most DEC_K bits; entry = node | len << 10 | code << 14.
-__device__ void tree_table(DTree &t, uint16_t *tab, uint32_t K = DEC_K)
+// (map: entries carry map[symbol] instead of the symbol - the symbol streams' tables, whose consumers want the byte)
+__device__ void tree_table(DTree &t, uint16_t *tab, uint32_t K = DEC_K, const uint8_t *map = nullptr)
 {
     t.tab = K == DEC_K ? tab : nullptr;   // (tree_get() reads DEC_K-bit tables; the quality loop addresses its own)
     if (!tab) return;
@@ -107,7 +108,7 @@ __device__ void tree_table(DTree &t, uint16_t *tab, uint32_t K = DEC_K)
         const uint32_t node = e & 1023u, len = (e >> 10) & 15u, code = e >> 14;
         if (node < t.n) {
             const uint32_t span = 1u << (K - len), first = code << (K - len);
-            const uint16_t v = (uint16_t)((len << 12) | node);
+            const uint16_t v = (uint16_t)((len << 12) | (map ? map[node & 0xffu] : node));
             for (uint32_t x = 0; x < span; ++x) tab[first + x] = v;
         } else if (len < K) {
             const uint32_t idx = node - t.n;
@@ -205,6 +206,7 @@ struct DecSub {
     int32_t err;
     uint64_t dna_bitpos;        // where the DNA payload starts in the sub-block (plain DNA is decoded by the assembly kernel)
     uint64_t text_bytes;
+    uint64_t t_head, t_qual, t_dna;   // wall_clock64 ticks (100 MHz) of the three phases, for NGSC_VERBOSE
     uint8_t dsym[256];
 };
 
@@ -244,30 +246,164 @@ __device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, ui
     return D;
 }
 
-// One wave per sub-block; lane 0 decodes the serial streams.
-__global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
-                                                    uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
-                                                    DecSub *out, uint32_t lds_entries)
-{
-    const uint32_t s = blockIdx.x;
-    if (s >= n_sb || threadIdx.x != 0) return;
-    DecSub &O = out[s];
-    O.err = OK; O.text_bytes = 0; O.n_rec = 0;
-    BitIn r;
-    r.init(sub + sb_off[s], sb_len[s]);
-    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, qcap);
-    Pool pool = {D.pool, 0, D.pool_cap};
-    uint16_t *stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
+// ---- the long symbol streams (qualities; Huffman-coded bases): lane 0 decodes, the wave feeds it ------------------------
+// A lone lane issues one dependent instruction every few cycles and waits a full memory latency for every byte of the
+// stream it fetches itself and for every record length - the first version spent ~2000 cycles per symbol that way.  Here
+// the WAVE stages the next DEC_IN_DW dwords of the bit string in LDS (byte-swapped: a dword = 32 stream bits, MSB first),
+// lane 0 decodes from that with a 64-bit window - per symbol: index, one LDS table read, shift - into an LDS output buffer,
+// and the wave writes the buffer out, coalesced.  Rounds end when the staged input or the output buffer is used up.
+constexpr uint32_t DEC_IN_DW = 512;      // 2 KB of bit string per round (+ 2 dwords of look-ahead)
+constexpr uint32_t DEC_OUT = 6144;       // symbols per round at most
 
+struct DecCtl {   // lane 0 -> wave
+    int32_t err;
+    uint32_t n, max_q, Kq, q_lds, nqual;
+    uint64_t pos;            // bit position behind what lane 0 has consumed
+    uint64_t qual_total, text;
+    const uint16_t *qtab;    // global table when it does not fit LDS
+    const DTree *qt;
+    uint32_t wi, ko, i, done;
+};
+
+// lens[i] symbols for record i = 0..n-1; PER_POS: symbol j of a record uses table row j + 1 (tasks.cpp:609-619) and its
+// tree trees[j + 1]; else one table / trees[0].  map: symbol index -> output byte (LDS).  kept (nullable): per record, the
+// number of output bytes below 128.  Returns through C.pos / C.err; all lanes call it.
+template <bool PER_POS>
+__device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const uint16_t *tab, uint32_t K, const DTree *trees,
+                                                 const uint32_t *lens, uint32_t n, uint8_t *dst, uint32_t *kept, const uint8_t *map, uint32_t *s_in,
+                                                 uint8_t *s_out, uint32_t nrows)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);   // (sub-blocks start 16-byte aligned and are padded to 16)
+    const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
+    // lane 0's decoder state
+    uint64_t win = 0;
+    // (values that come from memory go through readfirstlane: that is what tells the compiler they are wave-uniform)
+    auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    const uint32_t pos_lo = U((uint32_t)C.pos), pos_hi = U((uint32_t)(C.pos >> 32));
+    const uint64_t pos0 = ((uint64_t)pos_hi << 32) | pos_lo;
+    uint32_t have = 0, wi = (uint32_t)(pos0 >> 5), i = 0, j = 0, L = 0, kc = 0, bad = 0, Lnext = 0;
+    uint64_t kbase = 0;
+    const uint32_t skip0 = (uint32_t)(pos0 & 31);   // the stream starts inside dword wi
+    n = U(n); K = U(K);
+    bool opened = false;
+    // roles of the lanes in the four-symbol lookup: symbol index inside the group (lane_d) and bit offset in the window (lane_s)
+    const uint32_t lane_d = lane == 0 ? 0u : (lane <= 16 ? 1u : (lane <= 39 ? 2u : 3u));
+    const uint32_t lane_s = lane == 0 ? 0u : (lane <= 16 ? lane : (lane <= 39 ? lane - 15u : lane - 37u));
+    // Every lane runs the decoder, on the same data: nothing in the loop depends on the lane, so its values are wave-uniform,
+    // the compiler keeps them in scalar registers and branches without exec-mask bookkeeping (a loop under `if (lane == 0)`
+    // was ~190 instructions per symbol, most of them mask handling); stores of identical values to one address are harmless.
+    if (n) { L = U(lens[0]); Lnext = n > 1 ? U(lens[1]) : 0; }
+    for (;;) {
+        const uint32_t base = wi;
+        for (uint32_t t = lane; t < DEC_IN_DW + 4; t += 64) s_in[t] = base + t < ndw ? __builtin_bswap32(p32[base + t]) : 0u;
+        __syncthreads();
+        uint32_t ko = 0;
+        {
+            const uint32_t limit = base + DEC_IN_DW;
+            if (!opened) {   // first dword: drop the bits in front of the stream
+                win = (uint64_t)U(s_in[0]) << 32 << skip0;
+                have = 32 - skip0;
+                ++wi;
+                win |= (uint64_t)U(s_in[1]) << (32 - have); have += 32; ++wi;   // (the loop keeps more than 32 bits in the window)
+                opened = true;
+            }
+            while (i < n && wi < limit && ko + 4 <= DEC_OUT && !bad) {
+                if (j == L) {   // next record (also the empty ones)
+                    if (kept) kept[i] = kc;
+                    kc = 0; j = 0; ++i;
+                    L = Lnext;
+                    Lnext = i + 1 < n ? U(lens[i + 1]) : 0;
+                    continue;
+                }
+                // Up to four symbols per table access.  The lanes look up, in ONE LDS instruction, every entry the next four
+                // symbols can need: lane 0 the entry of this symbol at bit 0 of the window, lanes 1-16 the entries of the next
+                // symbol for every bit it can start at, lanes 17-39 and 40-63 the same for the two after it (lane_d / lane_s
+                // below).  The chain is then resolved with scalar reads of the right lanes: each entry's code length names the
+                // lane that holds its successor.  (A lone lane waits a full LDS latency per symbol.)
+                const uint32_t nxv = s_in[wi - base];                                   // next window dword, in flight with the table read
+                const uint32_t bitsv = (uint32_t)((win << lane_s) >> (64 - K));
+                const uint32_t rowv = PER_POS ? (j + 1 + lane_d < nrows ? j + 1 + lane_d : nrows - 1) : 0;   // (lanes past the read's end are not used)
+                const uint32_t ev = tab[((size_t)rowv << K) + bitsv];
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, 0) & 0xffffu;
+                uint32_t used = 0, cnt = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+                if (e0) {
+                    used = e0 >> 12; o0 = e0 & 0xffu; cnt = 1;
+                    if (j + 1 < L && used >= 1 && used <= 16) {
+                        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)used) & 0xffffu;
+                        const uint32_t u1 = used + (e1 >> 12);
+                        if (e1 && u1 <= have) {
+                            used = u1; o1 = e1 & 0xffu; cnt = 2;
+                            if (j + 2 < L && used >= 2 && used <= 24) {
+                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(15 + used)) & 0xffffu;
+                                const uint32_t u2 = used + (e2 >> 12);
+                                if (e2 && u2 <= have) {
+                                    used = u2; o2 = e2 & 0xffu; cnt = 3;
+                                    if (j + 3 < L && used >= 3 && used <= 26) {
+                                        const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(37 + used)) & 0xffffu;
+                                        const uint32_t u3 = used + (e3 >> 12);
+                                        if (e3 && u3 <= have) { used = u3; o3 = e3 & 0xffu; cnt = 4; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    win <<= used; have -= used;
+                } else {   // a code longer than K bits: walk the tree
+                    const DTree &T = trees[PER_POS ? j + 1 : 0];
+                    const uint32_t tn = U(T.n);
+                    uint32_t node = U(T.root), steps = 0;
+                    while (node >= tn) {
+                        if (have <= 32 && wi <= limit + 1) { win |= (uint64_t)U(s_in[wi - base]) << (32 - have); have += 32; ++wi; }
+                        if (!have || ++steps > 64) { bad = 1; break; }
+                        const uint32_t idx = node - tn;
+                        node = U((win >> 63) ? T.rc[idx] : T.lc[idx]);
+                        win <<= 1; --have;
+                    }
+                    o0 = U(map[node & 0xffu]);
+                    cnt = 1;
+                }
+                s_out[ko] = (uint8_t)o0;
+                kc += o0 < 128;
+                if (cnt > 1) { s_out[ko + 1] = (uint8_t)o1; kc += o1 < 128; }
+                if (cnt > 2) { s_out[ko + 2] = (uint8_t)o2; kc += o2 < 128; }
+                if (cnt > 3) { s_out[ko + 3] = (uint8_t)o3; kc += o3 < 128; }
+                ko += cnt; j += cnt;
+                if (have <= 32) {   // (the tree walk refills by itself and may have moved wi: then nxv is stale)
+                    const uint32_t nx = e0 ? U(nxv) : U(s_in[wi - base]);
+                    win |= (uint64_t)nx << (32 - have); have += 32; ++wi;
+                }
+            }
+            if (i < n && j == L && i + 1 == n) { if (kept) kept[i] = kc; ++i; }   // the last record closes without a successor
+            const uint64_t pos = (uint64_t)wi * 32 - have;
+            if (pos > nbits) bad = 1;
+            if (lane == 0) {
+                C.pos = pos;
+                if (bad) C.err = ERR_FORMAT;
+            }
+        }
+        __syncthreads();
+        for (uint32_t t = lane; t < ko; t += 64) dst[kbase + t] = s_out[t];
+        kbase += ko;
+        const bool done = i >= n || bad;   // (computed by every lane alike: a value read back from LDS would count as divergent)
+        __syncthreads();
+        if (done) break;   // (else: lane 0 keeps its window; wi points behind it, and the next round stages from wi)
+    }
+}
+
+// Lane 0: info header, title header and body, quality alphabet and trees.  Returns an error code (0: go on).
+__device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *F, uint8_t *qsym, uint16_t *s_qtab, uint32_t lds_entries,
+                        uint32_t rec_cap, DecCtl &C, uint16_t *stack)
+{
     // ---- info header phyNGSC.cpp:719-742 ----
     const uint32_t n = r.u32(), max_q = r.u32();
     (void)r.u32();
     const uint32_t nsym = r.u8();
     (void)r.u8();
     const uint32_t nqual = r.u8(), flags = r.u32();
-    if (r.bad || n == 0 || n > rec_cap || !nsym || !nqual || max_q > (1u << 24)) { O.err = ERR_FORMAT; return; }
+    if (r.bad || n == 0 || n > rec_cap || !nsym || !nqual || max_q > (1u << 24)) return ERR_FORMAT;
     uint64_t qual_total = 0;
-    if (flags & F_USE_DELTA) { O.err = ERR_COLORSPACE; return; }   // colour space is stored lossily (phyNGSC.cpp:531): nothing to give back
+    if (flags & F_USE_DELTA) return ERR_COLORSPACE;   // colour space is stored lossily (phyNGSC.cpp:531): nothing to give back
     O.n_rec = n; O.max_q = max_q; O.flags = flags; O.nsym = nsym; O.plain = (flags & F_DNA_PLAIN) ? 1u : 0u;
     {
         const uint32_t b = bit_length(max_q);
@@ -279,15 +415,13 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             if (L > max_q) r.bad = 1;
         }
         r.align();
-        if (r.bad || 2 * tot > D.tcap) { O.err = r.bad ? ERR_FORMAT : ERR_CAPACITY; return; }
+        if (r.bad || 2 * tot > D.tcap) return r.bad ? ERR_FORMAT : ERR_CAPACITY;
         qual_total = tot;
     }
 
     // ---- title header (cf. FetchTitleHeader tasks.cpp:625-735; value-coding trees as the encoder stores them, Q2b) ----
     const uint32_t nf = r.u32();
-    if (r.bad || nf == 0 || nf > DEC_MAX_FIELDS) { O.err = r.bad ? ERR_FORMAT : ERR_UNSUPPORTED; return; }
-    __shared__ DField s_F[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
-    DField *F = s_F;
+    if (r.bad || nf == 0 || nf > DEC_MAX_FIELDS) return r.bad ? ERR_FORMAT : ERR_UNSUPPORTED;
     const uint32_t keep_from = num_values_kept_from(nf);
     for (uint32_t f = 0; f < nf && !r.bad; ++f) {
         DField &fd = F[f];
@@ -341,7 +475,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             tree_table(fd.l[MAX_STAT_LEN], (uint16_t *)pool.take(2u << DEC_K));
         r.align();
     }
-    if (r.bad) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
+    if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
 
     // ---- title body (cf. FetchTitleBody tasks.cpp:738-954): groups of 32 records, byte aligned ----
     {
@@ -395,72 +529,108 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
         }
         D.toff[n] = (uint32_t)tn;
     }
-    if (r.bad) { O.err = r.bad == 3 ? ERR_CAPACITY : ERR_FORMAT; return; }
+    if (r.bad) return r.bad == 3 ? ERR_CAPACITY : ERR_FORMAT;
 
-    // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees, codes by position ----
-    uint64_t text = D.toff[n];
+    // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees; the codes are decoded by the wave ----
+    const uint64_t text = D.toff[n];
     const uint64_t q_at = (text + 15) & ~15ull, s_at = q_at + ((qual_total + 15) & ~15ull);
-    if (s_at + qual_total > D.tcap) { O.err = ERR_CAPACITY; return; }
+    if (s_at + qual_total > D.tcap) return ERR_CAPACITY;
     D.lay[0] = q_at; D.lay[1] = s_at;
-    uint8_t *d_qual = D.titles + q_at, *d_seq = D.titles + s_at;
-    {
-        __shared__ uint8_t qsym[256];
-        r.align();
-        for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
-        DTree *qt = (DTree *)pool.take(sizeof(DTree) * ((uint64_t)max_q + 1));
-        if (!qt) { O.err = ERR_NOMEM; return; }
-        // the per-position tables: in LDS while they fit (the quality codes are most of the sub-block's symbols)
-        extern __shared__ __align__(16) uint16_t s_qtab[];
-        uint32_t Kq = DEC_K;   // the widest tables that fit (codes longer than Kq bits walk their tree)
-        while (Kq > 5 && (((uint64_t)max_q + 1) << Kq) > lds_entries) --Kq;
-        const bool q_lds = (((uint64_t)max_q + 1) << Kq) <= lds_entries;
-        uint16_t *qtab = q_lds ? s_qtab : (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
-        if (!qtab) { O.err = ERR_NOMEM; return; }
-        for (uint32_t p = 0; p <= max_q && !r.bad; ++p)
-            if (tree_load(r, nqual, pool, qt[p], stack)) tree_table(qt[p], qtab + ((size_t)p << Kq), Kq);
-        r.align();
-        if (r.bad) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
-        uint64_t k = 0;
-        for (uint32_t i = 0; i < n && !r.bad; ++i) {
-            const uint32_t L = D.qlen[i];
-            uint32_t kept = 0;
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t e = qtab[((size_t)(j + 1) << Kq) + r.peek(Kq)];
-                uint32_t sym;
-                if (e) { r.skip(e >> 12); sym = e & 0xfffu; }
-                else sym = tree_get(qt[j + 1], r);
-                const uint8_t q = qsym[sym];
-                d_qual[k++] = q;
-                kept += q < 128;   // (a byte from 128 on is a transferred ambiguity code: no base in the DNA stream)
-            }
-            D.slen[i] = kept;
-            text += 2ull * L + 4;
-        }
-        r.align();
+    r.align();
+    for (uint32_t i = 0; i < 256; ++i) qsym[i] = 0;
+    for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
+    DTree *qt = (DTree *)pool.take(sizeof(DTree) * ((uint64_t)max_q + 1));
+    if (!qt) return ERR_NOMEM;
+    // the per-position tables: in LDS while they fit (the quality codes are most of the sub-block's symbols)
+    uint32_t Kq = DEC_K;   // the widest tables that fit (codes longer than Kq bits walk their tree)
+    while (Kq > 5 && (((uint64_t)max_q + 1) << Kq) > lds_entries) --Kq;
+    const bool q_lds = (((uint64_t)max_q + 1) << Kq) <= lds_entries;
+    uint16_t *qtab = q_lds ? s_qtab : (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
+    if (!qtab) return ERR_NOMEM;
+    for (uint32_t p = 0; p <= max_q && !r.bad; ++p) {
+        qt[p].n = 0;
+        if (tree_load(r, nqual, pool, qt[p], stack)) tree_table(qt[p], qtab + ((size_t)p << Kq), Kq, qsym);
     }
-    if (r.bad) { O.err = ERR_FORMAT; return; }
+    r.align();
+    if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
+    C.n = n; C.max_q = max_q; C.Kq = Kq; C.q_lds = q_lds ? 1u : 0u; C.nqual = nqual; C.qtab = qtab; C.qt = qt;
+    C.pos = r.pos; C.qual_total = qual_total; C.text = text;
+    return OK;
+}
 
-    // ---- DNA (cf. FetchDNA tasks.cpp:957-1033): alphabet; a Huffman-coded alphabet is decoded here, two-bit codes by all lanes ----
-    for (uint32_t i = 0; i < nsym; ++i) O.dsym[i] = (uint8_t)r.bits(8);
-    if (!O.plain) {
-        DTree dt;
-        if (!tree_load(r, nsym, pool, dt, stack)) { O.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT; return; }
-        tree_table(dt, (uint16_t *)pool.take(2u << DEC_K));
-        uint64_t k = 0;
-        for (uint32_t i = 0; i < n && !r.bad; ++i)
-            for (uint32_t j = 0; j < D.slen[i]; ++j) {
-                const uint32_t c = tree_get(dt, r);
-                if (c >= nsym) { r.bad = 1; break; }
-                d_seq[k++] = O.dsym[c];
-            }
-        if (r.bad) { O.err = ERR_FORMAT; return; }
-    } else {
-        uint64_t bases = 0;
-        for (uint32_t i = 0; i < n; ++i) bases += D.slen[i];
-        if (r.pos + 2 * bases > r.nbits) { O.err = ERR_FORMAT; return; }
+// One wave per sub-block: lane 0 walks the header and the titles, the wave decodes the two symbol streams.
+__global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
+                                                    uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
+                                                    DecSub *out, uint32_t lds_entries)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= n_sb) return;
+    const uint32_t lane = threadIdx.x;
+    __shared__ DField s_F[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
+    __shared__ uint8_t s_map[256];
+    __shared__ uint32_t s_in[DEC_IN_DW + 4];
+    __shared__ uint8_t s_out[DEC_OUT];
+    __shared__ DecCtl C;
+    __shared__ uint16_t s_dtab[1u << DEC_K];
+    extern __shared__ __align__(16) uint16_t s_qtab[];
+    DecSub &O = out[s];
+    BitIn r;
+    r.init(sub + sb_off[s], sb_len[s]);
+    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, qcap);
+    Pool pool = {D.pool, 0, D.pool_cap};
+    uint16_t *stack = nullptr;
+    const uint64_t t0 = wall_clock64();
+    if (lane == 0) {
+        O.err = OK; O.text_bytes = 0; O.n_rec = 0;
+        stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
+        C.err = dec_head(r, D, pool, O, s_F, s_map, s_qtab, lds_entries, rec_cap, C, stack);
+        if (C.err) O.err = C.err;
     }
-    O.dna_bitpos = r.pos;
-    O.text_bytes = text;
+    __syncthreads();
+    if (C.err) return;
+    const uint32_t n = C.n;
+    const uint64_t t1 = wall_clock64();
+    uint8_t *d_qual = D.titles + D.lay[0], *d_seq = D.titles + D.lay[1];
+    if (C.q_lds) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+    else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+    __syncthreads();
+    if (C.err) { if (lane == 0) O.err = C.err; return; }
+
+    // ---- DNA (cf. FetchDNA tasks.cpp:957-1033): alphabet; a Huffman-coded alphabet is decoded here, two-bit codes by the assembly kernel ----
+    const uint64_t t2 = wall_clock64();
+    __shared__ DTree s_dt;
+    if (lane == 0) {
+        r.seek(C.pos);
+        r.align();
+        const uint32_t nsym = O.nsym;
+        for (uint32_t i = 0; i < 256; ++i) s_map[i] = 0;
+        for (uint32_t i = 0; i < nsym; ++i) { const uint8_t c = (uint8_t)r.bits(8); O.dsym[i] = c; s_map[i] = c; }
+        if (!O.plain) {
+            if (!tree_load(r, nsym, pool, s_dt, stack)) C.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
+            else tree_table(s_dt, s_dtab, DEC_K, s_map);
+        } else {
+            uint64_t bases = 0;
+            for (uint32_t i = 0; i < n; ++i) bases += D.slen[i];
+            if (r.bad || r.pos + 2 * bases > r.nbits) C.err = ERR_FORMAT;
+        }
+        if (r.bad && !C.err) C.err = ERR_FORMAT;
+        C.pos = r.pos;
+        if (C.err) O.err = C.err;
+    }
+    __syncthreads();
+    if (C.err) return;
+    if (!O.plain) {
+        dec_symbols_wave<false>(r.p, r.nbits, C, s_dtab, DEC_K, &s_dt, D.slen, n, d_seq, nullptr, s_map, s_in, s_out, 1);
+        __syncthreads();
+        if (C.err) { if (lane == 0) O.err = C.err; return; }
+    }
+    if (lane == 0) {
+        O.dna_bitpos = C.pos;
+        uint64_t text = C.text;
+        text += 2ull * C.qual_total + 4ull * n;
+        O.text_bytes = text;
+        O.t_head = t1 - t0; O.t_qual = t2 - t1; O.t_dna = wall_clock64() - t2;
+    }
 }
 
 // One workgroup per sub-block: the four lines of every record, records dealt to the threads.
@@ -557,5 +727,6 @@ size_t dec_sub_bytes() { return sizeof(DecSub); }
 int32_t dec_sub_err(const void *h, uint32_t s) { return ((const DecSub *)h)[s].err; }
 uint64_t dec_sub_text(const void *h, uint32_t s) { return ((const DecSub *)h)[s].text_bytes; }
 uint32_t dec_sub_records(const void *h, uint32_t s) { return ((const DecSub *)h)[s].n_rec; }
+void dec_sub_ticks(const void *h, uint32_t s, uint64_t *t) { const DecSub &d = ((const DecSub *)h)[s]; t[0] = d.t_head; t[1] = d.t_qual; t[2] = d.t_dna; }
 
 }  // namespace ngsc
