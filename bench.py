@@ -275,11 +275,30 @@ def run_distributed(args, world: int):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev   # where the (tiny) collective tensors live
+    coll = "gloo rehearsal on one device" if rehearse else "RCCL all-gather of block sizes"
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # The collectives carry a few hundred bytes (block sizes, the max of the times); compression itself never
+            # touches them.  Should RCCL fail to come up on a node, the run goes on with gloo for those bytes and SAYS so in
+            # config.launch instead of leaving the scaling point unmeasured.
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                t = torch.ones(1, device=dev)
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+                if int(t.item()) != world:
+                    raise RuntimeError(f"all_reduce of ones gave {t.item()}")
+            except Exception as e:   # noqa: BLE001
+                reason = f"{type(e).__name__}: {e}".splitlines()[0][:160]
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                dist.init_process_group("gloo")
+                cdev = torch.device("cpu")
+                coll = f"gloo all-gather of block sizes (RCCL unusable here: {reason})"
     sh = Share(world, rank, local_rank, args.size_mb * 1_000_000)
 
     def barrier():
@@ -312,8 +331,7 @@ def run_distributed(args, world: int):
     else:
         total_raw, total_out = sh.file_size, sh.res.total_bytes
     if rank == 0:
-        mode = ("one process per GPU (torch.distributed.run), " + ("gloo rehearsal on one device" if rehearse else
-                "RCCL all-gather of block sizes")) if world > 1 else "one process, one context"
+        mode = ("one process per GPU (torch.distributed.run), " + coll) if world > 1 else "one process, one context"
         report(sh, args, world, dt, total_raw, total_out, ktimes_all, dom, mode)
     if world > 1:
         dist.barrier()
