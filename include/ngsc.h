@@ -45,7 +45,7 @@ enum {
     NGSC_ERR_RANGE = -5,       /* numeric title field >= 2^31 (reference: int32 wrap) */
     NGSC_ERR_NOMEM = -6,
     NGSC_ERR_ARG = -7,
-    NGSC_ERR_UNSUPPORTED = -8, /* engine limit: > 32 title fields, text field > 256 B, code > 26 bits */
+    NGSC_ERR_UNSUPPORTED = -8, /* engine limit: > 64 title fields, text field > 256 B, code > 26 bits */
     NGSC_ERR_HIP = -9,         /* HIP runtime / device failure (ngsc_last_hip_error()) */
     NGSC_ERR_CAPACITY = -10,   /* output buffer too small: ngsc_result_bytes() tells the size needed */
     NGSC_ERR_IO = -11

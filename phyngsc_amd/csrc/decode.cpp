@@ -5,6 +5,7 @@
 #include "ngsc_kernels.h"
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -240,7 +241,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     for (uint32_t w = 0; w < F.PS; ++w) if (s_at[w + 1] < s_at[w]) { close(fd); return NGSC_ERR_FORMAT; }
     const int ofd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (ofd < 0) { close(fd); return NGSC_ERR_IO; }
-    // batches: at most 256 sub-blocks or 1 GiB of compressed bytes
+    // batches: at most 512 sub-blocks (two decoder waves per CU) or 2 GiB of compressed bytes
     std::vector<const SubIn *> order;
     for (uint32_t w = 0; w < F.PS; ++w) for (const SubIn &x : subs[w]) order.push_back(&x);
     const uint64_t text_per_sb = 10ull << 20;
@@ -250,7 +251,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     uint64_t cap_in = 0, cap_text = 0;
     for (size_t b0 = 0; b0 < order.size() && !rc;) {
         size_t b1 = b0; uint64_t bytes = 0;
-        while (b1 < order.size() && b1 - b0 < 256 && bytes + order[b1]->bytes + 32 <= (1ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
+        while (b1 < order.size() && b1 - b0 < 512 && bytes + order[b1]->bytes + 32 <= (2ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
         if (b1 == b0) { bytes = (order[b1]->bytes + 15u) & ~15ull; ++b1; }
         const uint32_t nb = (uint32_t)(b1 - b0);
         const uint64_t need_in = bytes + 64, need_text = nb * text_per_sb;
@@ -291,7 +292,12 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
             while (k2 + 1 < nb && order[b0 + k2 + 1]->rank == w) ++k2;
             const uint64_t have = toff[k2 + 1] - toff[k], room = s_at[w + 1] - s_at[w] - std::min(written[w], s_at[w + 1] - s_at[w]);
             const uint64_t n = std::min(have, room);
-            if (n && !pwrite_all_at(ofd, h_text + toff[k], n, s_at[w] + written[w])) { rc = NGSC_ERR_IO; break; }
+            if (n && !pwrite_all_at(ofd, h_text + toff[k], n, s_at[w] + written[w])) {
+                fprintf(stderr, "[ngsc -d] write of %llu bytes at offset %llu of %s failed: %s\n", (unsigned long long)n,
+                        (unsigned long long)(s_at[w] + written[w]), out_path, strerror(errno));
+                rc = NGSC_ERR_IO;
+                break;
+            }
             written[w] += n;
             k = k2;
         }

@@ -398,7 +398,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
     Carver cr2;
     size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * slot_cap), o_doff = cr2.take(4 * slot_cap);
-    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(4 * grp_cap), o_tbits = cr2.take(4 * slot_cap);
+    size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(sizeof(fmask_t) * grp_cap), o_tbits = cr2.take(4 * slot_cap);
     const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
     const uint32_t tsep_words = max_title <= 64 ? 1u : 2u;
     size_t o_tsep = cr2.take(8 * tsep_words * rec_cap), o_apos = cr2.take(8 * rec_cap);
@@ -482,7 +482,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.tsep = (uint64_t *)(rb2 + o_tsep);
     A.tsep_words = tsep_words;
     A.apos = (AmbPos *)(rb2 + o_apos);
-    A.gflags = (uint32_t *)(rb2 + o_gflags);
+    A.gflags = (fmask_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);
     A.ubits = (uint32_t *)(pb + p_ubits);

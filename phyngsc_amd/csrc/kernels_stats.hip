@@ -223,22 +223,23 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
     __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
     __shared__ uint32_t s_th[TH_TEXT][TH_ROWS][128];   // two 16-bit counters per word: character c -> word c >> 1, half c & 1
-    __shared__ uint32_t s_need;          // bit f: field needs a histogram
+    __shared__ fmask_t s_need;           // bit f: field needs a histogram
     __shared__ uint32_t s_walk;          // some needed field is text or has no LDS slot: field boundaries are needed
     __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields / text fields (0xff: global atomics)
 
     for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
     for (uint32_t k = tid; k < TH_TEXT * TH_ROWS * 128; k += TS_THREADS) (&s_th[0][0][0])[k] = 0;
     if (tid == 0) {
-        uint32_t need = 0, kk = 0, kt = 0, walk = 0;
+        uint32_t kk = 0, kt = 0, walk = 0;
+        fmask_t need = 0;
         for (uint32_t f = 0; f < nf; ++f) {
             s_k[f] = 0xff;
             if (fd[f].kind == KIND_NUM && fd[f].has_huff && fd[f].n_sym > 1) {
-                need |= 1u << f;
+                need |= (fmask_t)1 << f;
                 if (kk < NH_LDS_FIELDS) s_k[f] = (uint8_t)kk++;
                 else walk = 1;
             } else if (fd[f].kind == KIND_TEXT) {
-                need |= 1u << f;
+                need |= (fmask_t)1 << f;
                 walk = 1;
                 if (kt < TH_TEXT) s_k[f] = (uint8_t)kt++;
             }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
         s_walk = walk;
     }
     __syncthreads();
-    const uint32_t need = s_need;
+    const fmask_t need = s_need;
     if (!need) return;
     const bool walk = s_walk != 0;
 

@@ -29,6 +29,12 @@ __device__ __forceinline__ uint32_t t_g32_or(uint32_t v)
     for (int d = 16; d >= 1; d >>= 1) v |= __shfl_xor(v, d);
     return v;
 }
+__device__ __forceinline__ fmask_t t_g32_or(fmask_t v)   // (field masks: the high word only when some title has more than 32 fields)
+{
+    uint32_t lo = t_g32_or((uint32_t)v), hi = (uint32_t)(v >> 32);
+    if (__any(hi != 0)) hi = t_g32_or(hi);
+    return ((fmask_t)hi << 32) | lo;
+}
 __device__ __forceinline__ uint32_t t_g32_sum(uint32_t v)
 {
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
 
     __shared__ uint32_t s_stat[MAX_FIELDS * 24];
     __shared__ uint32_t s_val[NUM_CAND_CAP][TT_THREADS];
-    __shared__ uint32_t s_nummask[TT_THREADS];
+    __shared__ fmask_t s_nummask[TT_THREADS];
     __shared__ Rec0Tab s_r0;
 
     for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
@@ -211,7 +217,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
 
     // parser state in integer registers; st bit0: non-digit seen, bit1: leading zero,
     // bit3: differs from record 0
-    uint32_t f = 0, k = 0, nummask = 0, v = 0, stf = 0;
+    uint32_t f = 0, k = 0, v = 0, stf = 0;
+    fmask_t nummask = 0;
     uint32_t f0len = nf0 ? s_r0.len[0] : 0, f0start = nf0 ? s_r0.start[0] : 0;
     for_each_title_byte(A.buf, A.buf_len, ls, te, valid, [&](uint32_t c, uint32_t act, uint32_t) {
         const uint32_t sepb = act & t_sep(c);
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
                     }
                     const uint32_t kk = s_r0.kmap[f];
                     if (kk < NUM_CAND_CAP) s_val[kk][tid] = v;
-                    nummask |= (uint32_t)isn << f;
+                    nummask |= (fmask_t)isn << f;
                 }
                 ++f; k = 0; v = 0; stf = 0;
                 f0len = f < nf0 ? s_r0.len[f] : 0;
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
     s_nummask[tid] = nummask;
     __syncthreads();
     if (owned && i >= 1) {
-        const uint32_t both = nummask & s_nummask[tid - 1];
+        const fmask_t both = nummask & s_nummask[tid - 1];
         const uint32_t ncand = s_r0.ncand;
         for (uint32_t kk = 0; kk < ncand; ++kk) {
             const uint32_t ff = s_r0.cand_f[kk];
@@ -305,7 +312,7 @@ struct CachedTitle {
 template <class Sink>
 __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Arena &A, uint32_t s, const FieldDesc *fd,
                                                   const uint8_t *kf_field, uint32_t ncf, bool first,
-                                                  const CachedTitle &C, uint32_t gconst, Sink &w)
+                                                  const CachedTitle &C, fmask_t gconst, Sink &w)
 {
 #pragma unroll
     for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
@@ -373,7 +380,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     const uint32_t gsize = valid ? ((gstart + 32 <= nt) ? 32u : nt - gstart) : 0u;
     const uint32_t g = valid ? i0 + tid : i0;
     const uint32_t ls = A.ls[g], te = A.te[g];
-    uint32_t bits = 0, gconst = 0;
+    uint32_t bits = 0;
+    fmask_t gconst = 0;
     if (ncf <= NCF_CAP) {
         // one pass over the title: cache the non-constant fields of this record
         if constexpr (SWAR) {
@@ -422,14 +430,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
                 const uint32_t wp = s_w[kf][tid - 1], wf = s_w[kf][gstart];
                 C.prev[kf] = wp;
                 if (s_fd[ff].kind == KIND_NUM) {
-                    if (wc != wf) d.val |= 1u << ff;
-                    if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= 1u << ff;
+                    if (wc != wf) d.val |= (fmask_t)1 << ff;
+                    if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= (fmask_t)1 << ff;
                 } else {
                     const uint32_t lc = wc >> 16;
                     const uint8_t *mine = A.buf + ls + (wc & 0xffffu), *frst = A.buf + A.ls[i0 + gstart] + (wf & 0xffffu);
                     bool same = lc == (wf >> 16);
                     for (uint32_t j = 0; same && j < lc; ++j) same = mine[j] == frst[j];
-                    if (!same) d.txt |= 1u << ff;
+                    if (!same) d.txt |= (fmask_t)1 << ff;
                 }
             }
         }
@@ -551,7 +559,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
     }
     if (valid) {
         const uint32_t grp = A.grp_lo[s] + (t0 + gstart) / GROUP;
-        const uint32_t gconst = A.gflags[grp];
+        const fmask_t gconst = A.gflags[grp];
         TLaneWriter w;
         w.init(t_lds ? s_stage : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
         if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     // value deltas between neighbouring records (tasks.cpp:149-166): inside a wave by shuffle, across the three wave
     // boundaries of the workgroup through these (last lane's value / first lane's value, per numeric candidate)
     __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
-    __shared__ uint32_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
+    __shared__ fmask_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
     __shared__ uint32_t s_w[TS_ROWS<W>][TT_THREADS];
     __shared__ Rec0Tab s_r0;
 
@@ -679,7 +687,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     }
     if (valid && nsep != s_r0.nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
 
-    uint32_t pos = 0, nummask = 0;
+    uint32_t pos = 0;
+    fmask_t nummask = 0;
     for (uint32_t f = 0; f < nf0; ++f) {
         const uint32_t len0 = s_r0.len[f], kk = s_r0.kmap[f], wo = s_r0.woff[f];
         const uint32_t len = t_next_set<W>(sepmask, pos);
@@ -737,7 +746,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             v = s_r0.val0[f];
             ovf = s_r0.ovf0[f] != 0;
             if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;
-            nummask |= 1u << f;
+            nummask |= (fmask_t)1 << f;
         } else if (kk != 0xff) {
             isn = len > 0 && t_all_set<W>(digmask, pos, len) && !(len > 1 && (w0 & 0xffu) == '0');
             v = t_parse8(w0, w1, len);
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                 }
             }
             if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;   // k_title_measure_reg<true> and k_title_hist read it back
-            nummask |= (uint32_t)isn << f;
+            nummask |= (fmask_t)isn << f;
         }
         if (kk < NUM_CAND_CAP) {   // (uniform) delta to the previous record, both numeric
             const uint32_t pv = (uint32_t)__shfl_up((int)v, 1);
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         pos += len + 1;
     }
     if (lane == 63) s_nm_last[tid >> 6] = nummask;
-    if (lane == 0) s_nm_first[tid >> 6] = (owned && i >= 1) ? nummask : 0u;
+    if (lane == 0) s_nm_first[tid >> 6] = (owned && i >= 1) ? nummask : (fmask_t)0;
     __syncthreads();
     {
         // the first lanes of waves 1..3 against the last lanes of waves 0..2

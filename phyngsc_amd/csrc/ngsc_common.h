@@ -29,7 +29,8 @@ constexpr uint32_t MAX_STAT_LEN = 128;      // MAX_FIELD_STAT_LEN, tasks.cpp:25
 constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
 
 // ---- engine limits (inputs beyond them get NGSC_ERR_UNSUPPORTED, never a wrong stream) ------------
-constexpr uint32_t MAX_FIELDS = 32;         // separators per title
+constexpr uint32_t MAX_FIELDS = 64;         // separators per title (one bit each in the field masks, fmask_t)
+typedef uint64_t fmask_t;                   // a bit per title field
 constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant text field (Hamming mask bits)
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
 constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
@@ -267,7 +268,7 @@ struct Arena {
     uint32_t *goff;         // per title group: bytes, then exclusive offsets
     uint32_t *grp_lo;       // per sub-block: first title group index
     uint32_t *tbits;        // per record: title bits (tiled path)
-    uint32_t *gflags;       // per title group: flag bits (tiled path)
+    fmask_t *gflags;        // per title group: flag bits (tiled path)
     uint32_t *wq, *wd;      // per tile: quality / DNA payload bits, then exclusive offsets (tiled path)
     uint32_t *ubits;        // per (tile, thread): quality bits | DNA bits << 16 of the thread's record slice
     uint64_t *tsep;         // per record: separator mask of the title, tsep_words words of 64 title bytes (word-parallel path)
@@ -485,7 +486,7 @@ NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
 // kernel can hand in an LDS-resident tile (pointer rebased by the tile's first offset).
 
 struct TitleDiffs {
-    uint32_t txt, val, dlt;  // bit f set: field f of this record breaks the group's constancy
+    fmask_t txt, val, dlt;   // bit f set: field f of this record breaks the group's constancy
 };
 
 // Record at p_cur (not the group's first record) against the group's first record (p_first) and its
@@ -500,15 +501,15 @@ NGSC_HD TitleDiffs title_record_diffs(const uint8_t *buf, const FieldDesc *fd, u
         uint32_t ef = field_end(buf, pf), ep = field_end(buf, pp), ec = field_end(buf, pc);
         const FieldDesc &d = fd[f];
         if (d.kind == KIND_TEXT) {
-            if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) r.txt |= 1u << f;
+            if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) r.txt |= (fmask_t)1 << f;
         } else if (d.kind == KIND_NUM) {
             uint32_t vf = 0, vp = 0, vc = 0;
             bool o;
             parse_num(buf, pf, ef, vf, o);
             parse_num(buf, pp, ep, vp, o);
             parse_num(buf, pc, ec, vc, o);
-            if (vc != vf) r.val |= 1u << f;
-            if ((int32_t)(vc - vp) != d.min_d) r.dlt |= 1u << f;
+            if (vc != vf) r.val |= (fmask_t)1 << f;
+            if ((int32_t)(vc - vp) != d.min_d) r.dlt |= (fmask_t)1 << f;
         }
         pf = ef + 1; pp = ep + 1; pc = ec + 1;
     }
@@ -516,9 +517,9 @@ NGSC_HD TitleDiffs title_record_diffs(const uint8_t *buf, const FieldDesc *fd, u
 }
 
 // Group flag bits from the OR of its records' diffs.  bit f = the flag written for field f (1 = constant).
-NGSC_HD uint32_t title_group_const(const FieldDesc *fd, uint32_t nf, TitleDiffs g, uint32_t group_size)
+NGSC_HD fmask_t title_group_const(const FieldDesc *fd, uint32_t nf, TitleDiffs g, uint32_t group_size)
 {
-    uint32_t gconst = 0;
+    fmask_t gconst = 0;
     for (uint32_t f = 0; f < nf; ++f) {
         const FieldDesc &d = fd[f];
         if (d.kind == KIND_CONST) continue;
@@ -528,23 +529,23 @@ NGSC_HD uint32_t title_group_const(const FieldDesc *fd, uint32_t nf, TitleDiffs 
             // a one-record group keeps block_delta_constant == 0, which must equal min_delta (tasks.cpp:415)
             flag = group_size == 1 ? (d.min_d == 0) : !((g.dlt >> f) & 1);
         } else flag = !((g.val >> f) & 1);
-        gconst |= flag << f;
+        gconst |= (fmask_t)flag << f;
     }
     return gconst;
 }
 
 // The group's flag bits: one per non-constant field, in field order (tasks.cpp:401-425).
 template <class Sink>
-NGSC_HD void title_put_flags(const FieldDesc *fd, uint32_t nf, uint32_t gconst, Sink &w)
+NGSC_HD void title_put_flags(const FieldDesc *fd, uint32_t nf, fmask_t gconst, Sink &w)
 {
     for (uint32_t f = 0; f < nf; ++f)
-        if (fd[f].kind != KIND_CONST) w.put((gconst >> f) & 1, 1);
+        if (fd[f].kind != KIND_CONST) w.put((uint32_t)((gconst >> f) & 1), 1);
 }
 
 // One record's title bits (tasks.cpp:427-507).  first: it is the group's first record.
 template <class Sink>
 NGSC_HD void title_record_emit(const uint8_t *buf, const Arena &A, uint32_t s, const FieldDesc *fd, uint32_t nf,
-                               bool first, uint32_t p_prev, uint32_t p_cur, uint32_t gconst, Sink &w)
+                               bool first, uint32_t p_prev, uint32_t p_cur, fmask_t gconst, Sink &w)
 {
     uint32_t pp = p_prev, pc = p_cur;
     for (uint32_t f = 0; f < nf; ++f) {
@@ -596,7 +597,7 @@ NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, S
         TitleDiffs d = title_record_diffs(buf, fd, nf, A.ls[g0], A.ls[r - 1], A.ls[r]);
         acc.txt |= d.txt; acc.val |= d.val; acc.dlt |= d.dlt;
     }
-    const uint32_t gconst = title_group_const(fd, nf, acc, g1 - g0);
+    const fmask_t gconst = title_group_const(fd, nf, acc, g1 - g0);
     title_put_flags(fd, nf, gconst, w);
     for (uint32_t r = g0; r < g1; ++r)
         title_record_emit(buf, A, s, fd, nf, r == g0, r > g0 ? A.ls[r - 1] : A.ls[r], A.ls[r], gconst, w);

@@ -96,6 +96,20 @@ def build():
         t = b"run" + b"Z" * (70 + i % 5) + b"/" + b"%d" % i        # one text field longer than 64 bytes
         recs.append((t, b"ACGT" * 9, bytes(rnd.choice(b"ABCDEFGHI") for _ in range(36))))
     cases["title_field_longer_than_64"] = (_fq(recs), 3)
+    # 40 and 64 title fields (the field masks of the title kernels are 64 bits wide; the first versions stopped at 32):
+    # numeric fields that vary, stay constant and switch between the two by group, with text fields between them -
+    # titles below 128 bytes (word-parallel kernels, two mask words) and above (byte-serial kernels)
+    for nfields, width in ((40, 1), (64, 1), (48, 3)):
+        recs = []
+        for i in range(5000):
+            parts = []
+            for k in range(nfields):
+                if k % 7 == 3: parts.append(b"t" if (i // 64 + k) % 3 else b"u")                      # text, constant over stretches
+                elif k % 5 == 0: parts.append(b"%d" % ((i * (k + 1)) % 10 ** width))                   # varying
+                elif k % 5 == 1: parts.append(b"%d" % ((i // 32) % 10 ** width))                       # constant inside a group
+                else: parts.append(b"%d" % (k % 10 ** width))                                          # constant
+            recs.append((b":".join(parts), bytes(rnd.choice(b"ACGT") for _ in range(36)), bytes(rnd.choice(b"5?IJ") for _ in range(36))))
+        cases["title_fields_%d_w%d" % (nfields, width)] = (_fq(recs), 3)
     # the smallest records there are: '@' alone as the title and an empty read (6 bytes), next to one-base reads
     recs = [(b"", b"", b"") if i % 3 else (b"", b"A", b"I") for i in range(9000)]
     cases["six_byte_records"] = (_fq(recs), 2)

@@ -343,6 +343,11 @@ def test_colorspace_reads(eng):
     _expect_error(eng, _fq(400, seq="T0123A1230", qual="IIIIIIIIII"), 2, -1)
 
 
+def test_error_more_than_64_title_fields(eng):
+    # engine limit: 64 separators per title; the reference has none
+    _expect_error(eng, _fq(400, title=lambda i: "@" + ":".join(str((i + k) % 10) for k in range(66))), 2, -8)
+
+
 def test_error_numeric_overflow(eng):
     _expect_error(eng, _fq(400, title=lambda i: f"@r:{3_000_000_000 + i}"), 2, -5)
 
