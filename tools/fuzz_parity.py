@@ -39,6 +39,8 @@ def main():
                     help="files of 20..200 KB split over 8..24 ranks: rank regions of a record's size, records owned by two ranks")
     ap.add_argument("--driver", action="store_true",
                     help="also push every accepted file through ngsc_compress_file_multi (two contexts, small jobs)")
+    ap.add_argument("--decode", action="store_true",
+                    help="also read every container back with the GPU decoder (ngsc_decompress_file) and compare with the input")
     a = ap.parse_args()
 
     eng = None
@@ -56,7 +58,7 @@ def main():
         from phyngsc_amd import api
         assert torch.cuda.is_available(), "needs the MI355X (or --cpu-only)"
         eng = api.Engine(0)
-        if a.driver:
+        if a.driver or a.decode:
             import tempfile
             eng2 = api.Engine(0)
             dtmp = tempfile.mkdtemp(prefix="ngsc_fuzz_drv_")
@@ -155,6 +157,20 @@ def main():
                 except api.NgscError as e:
                     verdict = f"file driver rc {e.code} (NGSC_JOB_BYTES={os.environ['NGSC_JOB_BYTES']})"
                 del os.environ["NGSC_JOB_BYTES"]
+        if verdict == "ok" and eng is not None and a.decode and o_rc == 0 and not d["vary_sep"] and d["tail"] == "ok":
+            # the way back: the ORACLE's container (so that a decoder fault is not hidden by a matching encoder fault)
+            # through the container reader and the GPU decoder; colour space is stored lossily and refused
+            ng, back = os.path.join(dtmp, "d.ngsc"), os.path.join(dtmp, "d.fastq")
+            with open(ng, "wb") as f:
+                f.write(ref)
+            try:
+                eng.decompress_file(ng, back)
+                with open(back, "rb") as f:
+                    if f.read() != data:
+                        verdict = "GPU decoder: decoded file differs from the input"
+            except api.NgscError as e:
+                if e.code != -4:
+                    verdict = f"GPU decoder rc {e.code}"
         if verdict == "ok":
             if o_rc:
                 n_rej += 1

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Developer tool (GPU box): memory-path counters per kernel (texture addresser / L1 busy and stalls, LDS), ONE hardware
-# block per rocprofv3 pass: several TA_/TCP_ counters in one pass exceed what the hardware can collect, and rocprofv3
-# then aborts and hangs in its finaliser.  Every pass runs under its own timeout.
+# block per rocprofv3 pass.  Observed in round 1 (no log of it was kept, so the cause is not proven): a pass that asked for
+# several TA_/TCP_ counters at once did not finish - presumably more than the block's counter registers - whereas one
+# block per pass always has.  Every pass runs under its own timeout.  PMC_SCRIPT / PMC_ARGS as in pmc_pass.sh.
 #   tools/pmc_mem.sh <tag>   -> gpurun_out/pmc_<tag>_m*.json
 tag=${1:-x}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
@@ -11,7 +12,7 @@ run() {
     sfx=$1; shift
     echo "pass $sfx: $*" >> $out/pmc_${tag}_progress.txt
     timeout -k 5 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_${tag}_$sfx -- \
-        python3 $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $out/pmc_${tag}_$sfx.log 2>&1 || { echo "pass $sfx failed" >> $out/pmc_${tag}_progress.txt; return 1; }
+        python3 $repo/${PMC_SCRIPT:-bench.py} ${PMC_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-verify} > $out/pmc_${tag}_$sfx.log 2>&1 || { echo "pass $sfx failed" >> $out/pmc_${tag}_progress.txt; return 1; }
     python3 $repo/tools/pmc_summary.py $out/pmc_${tag}_$sfx > $out/pmc_${tag}_$sfx.json
     find $out/pmc_${tag}_$sfx -name "*.csv" -size +8M -delete
 }
