@@ -326,13 +326,15 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
         for (uint32_t a = g0; a < g1;) {
             uint64_t lo, hi;
             job_range(FS, P, a, a + 1, lo, hi);
-            if (hi - lo > limit) {   // one rank alone is more than a job: walk it in parts
+            // (a part has to hold a window and a record beyond its predecessor's: job sizes below three such overlaps - only
+            // test settings ask for them - still cut whole ranks, but parts no smaller than that)
+            const uint64_t part_limit = std::max<uint64_t>(limit, 3 * PART_OVERLAP);
+            if (hi - lo > part_limit) {   // one rank alone is more than a job: walk it in parts
                 const uint64_t rank_hi = hi;
                 const uint64_t rank_end = std::min<uint64_t>(FS, (uint64_t)rank_geometry(FS, P, a).wr_end + 1);
                 bool first = true;
-                if (limit <= 2 * PART_OVERLAP) { w->rc = NGSC_ERR_ARG; sink->abort(); return; }
-                for (uint64_t p = lo;; p = (p + limit - PART_OVERLAP) & ~15ull) {
-                    uint64_t e = std::min<uint64_t>(rank_hi, p + limit);
+                for (uint64_t p = lo;; p = (p + part_limit - PART_OVERLAP) & ~15ull) {
+                    uint64_t e = std::min<uint64_t>(rank_hi, p + part_limit);
                     if (e >= rank_end) e = rank_hi;   // the part that reaches the end of the region finishes the rank
                     jobs.push_back({g, a, a + 1, p, e, true, first, false, g1 - g0 == 1, e == rank_hi});
                     max_len = std::max(max_len, e - p);

@@ -56,7 +56,7 @@ struct ngsc_ctx {
     std::vector<hipEvent_t> event_pool;
 
     // workspace
-    DevBuf small, tiles, recs, recs2, persb, zero, slots, misc, cscopy;
+    DevBuf small, tiles, recs, recs2, persb, zero, slots, misc, cscopy, dense;
     // pinned host staging
     void *h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -212,7 +212,7 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc, &c->cscopy})
+    for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc, &c->cscopy, &c->dense})
         if (b->p) (void)hipFree(b->p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     collect_times(c);
@@ -516,6 +516,22 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.tblob_len = (uint32_t *)(tb + t_blen);
     A.qrows = qrows;
     A.n_sb = S;
+    // Chunk-major copies of every record's bases and qualities, filled by the statistics kernel and read by
+    // measure and pack - when they stay within 2.5x the job (address space; only real chunks are touched).  NGSC_SQ_DENSE=0:
+    // measure and pack read the file themselves, as in round 1
+    A.dense_s = A.dense_q = nullptr;
+    A.dstride = 0;
+    {
+        const char *de = getenv("NGSC_SQ_DENSE");
+        const uint64_t stride = ((uint64_t)max_q + 15) & ~15ull, need = 2 * stride * (uint64_t)n_rec_total;
+        if (!(de && !strcmp(de, "0")) && sq_reg && stride && need <= (uint64_t)len * 5 / 2) {
+            rc = ensure(c, c->dense, (size_t)need + 64);
+            if (rc) return rc;
+            A.dense_s = (uint8_t *)c->dense.p;
+            A.dense_q = A.dense_s + stride * (uint64_t)n_rec_total;
+            A.dstride = n_rec_total;
+        }
+    }
     A.out = (uint8_t *)d_out;
     uint32_t *d_qrowoff = (uint32_t *)(pb + p_qrowoff);
 

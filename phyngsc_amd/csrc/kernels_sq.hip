@@ -21,6 +21,20 @@
 
 namespace ngsc {
 
+// one 16-byte chunk of a record's bases or qualities: from the chunk-major copy the statistics kernel leaves (Arena::dstride) or the file
+__device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *dense, uint32_t g, uint32_t off, uint32_t file_pos)
+{
+    if (A.dstride) return *reinterpret_cast<const uint4 *>(dense + ((size_t)(off >> 4) * A.dstride + g) * 16);
+    return load16_unaligned(A.buf, file_pos + off, A.buf_len);
+}
+__device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32_t off, const uint4 &S, const uint4 &Q)
+{
+    if (A.dstride) {
+        *reinterpret_cast<uint4 *>(A.dense_s + ((size_t)(off >> 4) * A.dstride + g) * 16) = S;
+        *reinterpret_cast<uint4 *>(A.dense_q + ((size_t)(off >> 4) * A.dstride + g) * 16) = Q;
+    }
+}
+
 template <bool BURST>
 __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw)
 {
@@ -101,6 +115,12 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                         Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
                     }
                 }
+                // (the copies for measure / pack: behind all four loads, so that the loads stay in flight together)
+#pragma unroll
+                for (uint32_t k = 0; k < NBX; ++k) {
+                    const uint32_t off = 16 * NBX * grp + 16 * k;
+                    if (L > off) sq_chunk_keep(A, g, off, Sb[k], Qb[k]);
+                }
             } else {
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
@@ -108,6 +128,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                     Sn = load16_unaligned(A.buf, s0 + 16 * grp + 16, A.buf_len);
                     Qn = load16_unaligned(A.buf, q0 + 16 * grp + 16, A.buf_len);
                 }
+                if (L > 16 * grp) sq_chunk_keep(A, g, 16 * grp, Sb[0], Qb[0]);   // (the chunk that has arrived, not the one in flight)
             }
 #pragma unroll
             for (uint32_t kb = 0; kb < NBX; ++kb) {
@@ -419,6 +440,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
+    __shared__ uint32_t s_leanflag;
+    const bool lean_wg = sq_lean_alphabet(sb, lds_rows, &s_leanflag);
     // code lengths of A, C, T, G (the order of (c >> 1) & 3) as a v_perm table
     const uint32_t ltab = (s_dcode['A'] & 31u) | ((s_dcode['C'] & 31u) << 8) | ((s_dcode['T'] & 31u) << 16) | ((s_dcode['G'] & 31u) << 24);
 
@@ -449,6 +472,26 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         auto chunk = [&](const uint32_t ch, const uint4 S, const uint4 Q) __attribute__((always_inline)) {
             const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            // ---- lean path (as in k_sq_pack_reg): the alphabet lies inside the table, two-bit bases (their bits are known from
+            // the record's length), no record of the wave scans its bases for transferred positions, no byte with the high bit
+            // set: sixteen straight-line lookups; bytes behind the read's end become the pad byte, which reads the zero column ----
+            if (lean_wg && plain && !__any(xfer) && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
+                const bool tails = __any(nv != 16);
+                const uint32_t rbase = (16 * ch + 1) * SQ_QS - 33u;
+                uint32_t acc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    uint32_t qm = qw[k];
+                    if (tails) {
+                        const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                        qm = (qw[k] & vm) | (SQ_QPAD & ~vm);
+                    }
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) acc += s_qlen[rbase + (4 * k + b) * SQ_QS + ((qm >> (8 * b)) & 0xffu)];
+                }
+                qb += acc;
+                return;
+            }
             uint32_t qbad = 0, dacc = 0, idx[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k) {
@@ -530,8 +573,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     const uint32_t off = 16 * NB * c4 + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
-                        if (need_s) Sb[k] = load16_unaligned(A.buf, s0 + off, A.buf_len);
+                        Qb[k] = sq_chunk_load(A, A.dense_q, g, off, q0);
+                        if (need_s) Sb[k] = sq_chunk_load(A, A.dense_s, g, off, s0);
                     }
                 }
 #pragma unroll
@@ -541,15 +584,15 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         } else {
             uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
             if (L) {
-                if (need_s) Sn = load16_unaligned(A.buf, s0, A.buf_len);
-                Qn = load16_unaligned(A.buf, q0, A.buf_len);
+                if (need_s) Sn = sq_chunk_load(A, A.dense_s, g, 0, s0);
+                Qn = sq_chunk_load(A, A.dense_q, g, 0, q0);
             }
             for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
                 const uint4 S = Sn, Q = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * ch + 16) {
-                    if (need_s) Sn = load16_unaligned(A.buf, s0 + 16 * ch + 16, A.buf_len);
-                    Qn = load16_unaligned(A.buf, q0 + 16 * ch + 16, A.buf_len);
+                    if (need_s) Sn = sq_chunk_load(A, A.dense_s, g, 16 * ch + 16, s0);
+                    Qn = sq_chunk_load(A, A.dense_q, g, 16 * ch + 16, q0);
                 }
                 chunk(ch, S, Q);
             }
@@ -663,8 +706,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
         constexpr uint32_t NBX = BURST ? NB : 1u;   // chunks per trip, see k_sq_stats_reg
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
         if (!BURST && L) {
-            Sn = load16_unaligned(A.buf, s0, A.buf_len);
-            Qn = load16_unaligned(A.buf, q0, A.buf_len);
+            Sn = sq_chunk_load(A, A.dense_s, g, 0, s0);
+            Qn = sq_chunk_load(A, A.dense_q, g, 0, q0);
         }
         for (uint32_t w = 0; w < n_win; ++w) {
         const uint32_t r0 = w * win;
@@ -681,16 +724,16 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                     const uint32_t off = 16 * NBX * grp + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Sb[k] = load16_unaligned(A.buf, s0 + off, A.buf_len);
-                        Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
+                        Sb[k] = sq_chunk_load(A, A.dense_s, g, off, s0);
+                        Qb[k] = sq_chunk_load(A, A.dense_q, g, off, q0);
                     }
                 }
             } else {
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * grp + 16) {
-                    Sn = load16_unaligned(A.buf, s0 + 16 * grp + 16, A.buf_len);
-                    Qn = load16_unaligned(A.buf, q0 + 16 * grp + 16, A.buf_len);
+                    Sn = sq_chunk_load(A, A.dense_s, g, 16 * grp + 16, s0);
+                    Qn = sq_chunk_load(A, A.dense_q, g, 16 * grp + 16, q0);
                 }
             }
 #pragma unroll

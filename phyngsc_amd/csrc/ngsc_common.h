@@ -306,6 +306,12 @@ struct Arena {
     uint32_t qrows;         // job max quality length + 1
     uint32_t n_sb;
     uint32_t cs_mode;       // the job runs on a copy of its input in which colour-space reads are decoded (kernels_cs.hip)
+    // NGSC_SQ_DENSE: the statistics kernel leaves every record's bases and qualities as 16-byte chunks in CHUNK-MAJOR arrays
+    // (chunk c of record g at dense_x + (c * dstride + g) * 16, dstride = records of the job), and measure / pack read them
+    // there: the 64 lanes of a wave - 64 consecutive records - store and load 1 KB of consecutive memory per instruction
+    // instead of 16 bytes each at addresses a whole record apart.  dstride == 0: off
+    uint8_t *dense_s, *dense_q;
+    uint32_t dstride;
     uint8_t *out;           // output buffer
 };
 

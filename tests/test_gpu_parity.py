@@ -107,11 +107,16 @@ def test_against_oracle(eng, name, cfg, size, P):
 
 @pytest.mark.parametrize("name,cfg,size,P", ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
 def test_chunk_path_against_oracle(eng, monkeypatch, name, cfg, size, P):
-    """The chunk-per-lane sequence/quality kernels (NGSC_SQ_PATH=chunk) on the generated cases."""
-    monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
+    """The chunk-per-lane sequence/quality kernels (NGSC_SQ_PATH=chunk) on the generated cases, and the
+    default kernels without the chunk-major copies of bases and qualities (NGSC_SQ_DENSE=0: measure and pack read the file)."""
     data = fastq_gen.generate(cfg, target_bytes=size // 2)
-    _, out = _gpu(eng, data, P)
     want, _ = orc.compress_file(data, P, threads=8)
+    monkeypatch.setenv("NGSC_SQ_DENSE", "0")
+    _, out = _gpu(eng, data, P)
+    assert out == want, "NGSC_SQ_DENSE=0"
+    monkeypatch.delenv("NGSC_SQ_DENSE")
+    monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
+    _, out = _gpu(eng, data, P)
     assert out == want
 
 
@@ -119,7 +124,7 @@ PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "tit
               "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
 
 
-@pytest.mark.parametrize("tile_records", ["reg", "chunk", "chunk16", "chunk32", "1", "64", "128", "256"])
+@pytest.mark.parametrize("tile_records", ["reg", "dense", "chunk", "chunk16", "chunk32", "1", "64", "128", "256"])
 def test_kernel_paths_agree(eng, monkeypatch, tile_records):
     """The sequence/quality kernels exist in four forms: register-streaming (one lane per record, the default for
     records up to 2 KB), one lane per 16-byte chunk out of LDS-staged wave tiles (NGSC_SQ_PATH=chunk; 16..64 records
@@ -130,8 +135,10 @@ def test_kernel_paths_agree(eng, monkeypatch, tile_records):
         monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
         if tile_records != "chunk":
             monkeypatch.setenv("NGSC_CHUNK_TILE_RECORDS", tile_records[5:])
+    elif tile_records == "dense":   # (the default) the statistics kernel leaves chunk-major copies of bases and qualities
+        monkeypatch.setenv("NGSC_SQ_DENSE", "1")   # for measure / pack; "reg" = they read the file themselves
     elif tile_records == "reg":
-        pass
+        monkeypatch.setenv("NGSC_SQ_DENSE", "0")
     else:
         monkeypatch.setenv("NGSC_SQ_PATH", "tile")
         monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
