@@ -244,6 +244,12 @@ def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, la
                                  ("two chains" if os.environ.get("NGSC_OVERLAP") == "1" else "staggered two-stream"),
                      "raw_GBps_over_kernel_time": sh.my_raw / (kernel_sum_ms * 1e-3) / 1e9 if kernel_sum_ms else None,
                      "frac_of_hbm_read_roofline": total_raw / world * args.steps / dt / 1e9 / HBM_PEAK_GBS},
+        # the same roofline figure for the other throughput kernels, each timed ALONE in the untimed profile pass (the
+        # dominant one: inside the timed region): algorithmic bytes / launch duration / 8 TB/s
+        "roofline_by_kernel": {k: {"ms": round(v["ms_avg"], 4), "algorithmic_bytes": alg[k],
+                                   "frac": round(alg[k] / (v["ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                               for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])[:8]
+                               if alg.get(k) and v["ms_avg"] > 0},
         "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])},
     }
     if world == 1 and not args.no_verify:

@@ -582,7 +582,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const char *ov_env = getenv("NGSC_OVERLAP");
     const bool overlap = ov_env && !strcmp(ov_env, "1");
     const bool time_all = c->profiling && c->profile_only.empty();
-    const bool stagger = (ov_env ? !strcmp(ov_env, "2") : !time_all) && (sq_reg || sq_chunk) && !c->debug_sync;
+    const bool stagger = (ov_env ? (!strcmp(ov_env, "2") || !strcmp(ov_env, "3")) : !time_all) && (sq_reg || sq_chunk) && !c->debug_sync;
     hipStream_t st2 = overlap ? c->side_stream : st;
     hipStream_t sts = stagger ? c->side_stream : st;   // the sequence/quality chain's stream behind its statistics kernel
     auto fork_s = [&]() -> int {
@@ -613,10 +613,15 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const char *tp_env = getenv("NGSC_TITLE_PATH");
     const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
     if (stagger) {
+        // NGSC_OVERLAP=3 (experiment): the fork in front of the statistics kernels - the issue-bound title statistics beside
+        // the texture-path-bound sequence/quality statistics
+        const bool early = ov_env && !strcmp(ov_env, "3");
         { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
-        if (sq_chunk) { KScope k(c, st, "k_ck_stats"); launch_ck_stats(st, A, max_rec, TR, max_rec_bytes); }
-        else { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
-        if ((rc = fork_s())) return rc;
+        if (early && (rc = fork_s())) return rc;
+        hipStream_t sq0 = early ? sts : st;
+        if (sq_chunk) { KScope k(c, sq0, "k_ck_stats"); launch_ck_stats(sq0, A, max_rec, TR, max_rec_bytes); }
+        else { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec); }
+        if (!early && (rc = fork_s())) return rc;
         { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
         { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
         if (sq_chunk) { KScope k(c, sts, "k_ck_measure"); launch_ck_measure(sts, A, max_rec, TR, max_rec_bytes); }

@@ -30,6 +30,7 @@ __device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *de
 __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32_t off, const uint4 &S, const uint4 &Q)
 {
     if (A.dstride) {
+        // (plain stores: with the non-temporal hint the kernel is no faster and the readers lose what the caches kept)
         *reinterpret_cast<uint4 *>(A.dense_s + ((size_t)(off >> 4) * A.dstride + g) * 16) = S;
         *reinterpret_cast<uint4 *>(A.dense_q + ((size_t)(off >> 4) * A.dstride + g) * 16) = Q;
     }
