@@ -263,12 +263,33 @@ struct WaveSearch {
         pair(a, n, key, a, 0, 0, 0, n, r0, r1);
         return r0;
     }
+    // hint: where both bounds are expected, as a distance from lo (the previous window's record count; windows of one
+    // file hold nearly the same number of records).  The first round then probes 64 positions around lo + hint, a
+    // 1/2048 of hint apart: if the bound lies between two of them - it nearly always does - one more round finishes
+    // (two dependent memory latencies per window instead of four); if not, the probes still narrow the range from one side.
     __device__ void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
-                         uint32_t span, uint32_t &ra, uint32_t &rb) const
+                         uint32_t span, uint32_t &ra, uint32_t &rb, uint32_t hint = 0) const
     {
         const uint32_t lane = threadIdx.x & 63;
         uint32_t la = lo < na ? lo : na, ha = (uint64_t)lo + span < na ? lo + span : na;
         uint32_t lb = lo < nb ? lo : nb, hb = (uint64_t)lo + span < nb ? lo + span : nb;
+        if (hint > 64 && la < ha && lb < hb) {
+            const uint32_t step = hint / 2048 + 1;
+            const uint64_t c0 = (uint64_t)lo + hint;
+            const uint64_t p64 = c0 + (uint64_t)lane * step;
+            const uint64_t pp = p64 > 32ull * step ? p64 - 32ull * step : 0;                // lo + hint + (lane - 32) * step
+            const uint32_t pa = (uint32_t)(pp < la ? la : (pp >= ha ? ha - 1 : pp)), pb = (uint32_t)(pp < lb ? lb : (pp >= hb ? hb - 1 : pp));
+            const uint32_t va = a[pa], vb = b[pb];
+            const uint64_t ma = __ballot((uint64_t)va < ka), mb = __ballot((uint64_t)vb < kb);   // sorted arrays: a run of ones from lane 0
+            const uint32_t ca = (uint32_t)__popcll(ma), cb = (uint32_t)__popcll(mb);
+            // bound in (probe[c-1], probe[c]]: the probes' positions come back through the lanes that hold them
+            const uint32_t pa_lo = (uint32_t)__shfl((int)pa, ca ? (int)ca - 1 : 0), pa_hi = (uint32_t)__shfl((int)pa, ca < 64 ? (int)ca : 63);
+            const uint32_t pb_lo = (uint32_t)__shfl((int)pb, cb ? (int)cb - 1 : 0), pb_hi = (uint32_t)__shfl((int)pb, cb < 64 ? (int)cb : 63);
+            if (ca) la = pa_lo + 1;
+            if (ca < 64) ha = pa_hi;
+            if (cb) lb = pb_lo + 1;
+            if (cb < 64) hb = pb_hi;
+        }
         while (la < ha || lb < hb) {
             const uint32_t sa = (ha - la + 63) >> 6, sb = (hb - lb + 63) >> 6;
             const uint32_t pa = la + lane * sa, pb = lb + lane * sb;

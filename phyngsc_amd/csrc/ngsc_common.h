@@ -738,7 +738,7 @@ NGSC_HD RankGeom rank_geometry(uint64_t file_size, uint32_t P, uint32_t r)
 struct ScalarSearch {
     NGSC_HD uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const { return lower_bound_u32(a, n, key); }
     NGSC_HD void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
-                      uint32_t span, uint32_t &ra, uint32_t &rb) const
+                      uint32_t span, uint32_t &ra, uint32_t &rb, uint32_t /* hint */ = 0) const
     {
         lower_bound_pair(a, na, ka, b, nb, kb, lo, span, ra, rb);
     }
@@ -771,6 +771,7 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
     const uint64_t rank_end = (uint64_t)g.wr_end + 1 < file_size ? (uint64_t)g.wr_end + 1 : file_size;
     const bool whole = buf_end_abs == 0 || buf_end_abs >= rank_end;       // the buffer reaches the end of the rank's region
     const uint64_t indexed_end = (uint64_t)ls[n_rec_total] + buf_off;     // behind the last complete record of the buffer
+    uint32_t hint = 0;   // records of the previous window: where this window's bounds are expected (a search hint, nothing else)
     while (bytes_read < g.region) {
         if (!whole && (uint64_t)(win_pos + bsize) > indexed_end) {        // this window waits for the next part
             plan->next_pos = (uint64_t)win_pos; plan->bytes_read = (uint64_t)bytes_read; plan->bsize = (uint64_t)bsize;
@@ -786,7 +787,7 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
         int64_t wend_rel = wend - (int64_t)buf_off, stop_rel = stop_at - (int64_t)buf_off;
         uint32_t m, lb;
         search.pair(te, n_rec_total, wend_rel > 0 ? (uint64_t)wend_rel : 0, ls, n_rec_total + 1,
-                    stop_rel > 0 ? (uint64_t)stop_rel : 0, cur, (1u << 21) + 4, m, lb);  // te[m-1] < wend
+                    stop_rel > 0 ? (uint64_t)stop_rel : 0, cur, (1u << 21) + 4, m, lb, hint);  // te[m-1] < wend
         if (m > cur + 1) {
             // first record (other than `cur`, which is never tested: :295-300) whose next offset >= stop_at
             uint32_t j = lb > 0 ? lb - 1 : 0;
@@ -794,6 +795,7 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
             last = j < m - 1 ? j : m - 1;
         }
         uint32_t cnt = last - cur + 1;
+        hint = cnt;
         if (cnt > MAX_RECORDS) return ERR_TOOMANY;
         if (plan->n_cuts >= max_cuts) return ERR_NOMEM;
         Cut &c = cuts[plan->n_cuts++];
