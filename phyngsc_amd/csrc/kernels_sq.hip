@@ -1050,6 +1050,8 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     const size_t lds = ((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + sw_q + sw_d) * 4;
     // one chunk per trip: with NB chunks fetched back to back this kernel is 8-10 % slower on every configuration (it
     // is bound by its bit writers, not by the loads), so only that variant is built
+    // (measured again with the chunks coming from the chunk-major copies: NB chunks per trip change nothing on 150-base and
+    // mixed reads - 0.340 against 0.334 ms, 0.530 / 0.530 - and cost 16 % at 36 bases)
     auto kern = k_sq_pack_reg<false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win);
