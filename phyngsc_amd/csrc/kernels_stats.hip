@@ -313,9 +313,10 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
 #pragma unroll
                         for (int dd = 32; dd >= 1; dd >>= 1) { uint32_t o2 = __shfl_xor(wmax, dd); wmax = o2 > wmax ? o2 : wmax; }
                         uint32_t *ch = A.chist + (size_t)d.slot * TEXT_TREES * 256;
+                        const uint2 f8 = len ? load8_unaligned(buf, pc, A.buf_len) : make_uint2(0, 0);   // the first eight characters with one load
                         for (uint32_t x = 0; x < wmax; ++x) {
                             bool act = x < len;
-                            const uint32_t c = act ? buf[pc + x] : 0x100u;
+                            const uint32_t c = !act ? 0x100u : (x < 4 ? (f8.x >> (8 * x)) & 0xffu : (x < 8 ? (f8.y >> (8 * (x - 4))) & 0xffu : buf[pc + x]));
                             if (kt != 0xff && x < TH_ROWS) {   // LDS counters (wave-uniform condition)
                                 if (act) atomicAdd(&s_th[kt][x][c >> 1], 1u << (16 * (c & 1)));
                                 continue;

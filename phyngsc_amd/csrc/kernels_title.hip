@@ -337,9 +337,13 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
                 const uint32_t start = wc & 0xffffu, len = wc >> 16;
                 if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
                 const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
+                // (the field's first eight bytes with one load: short text fields - a filter flag, a barcode - cost a memory
+                // round trip per CHARACTER otherwise, in measure and in pack)
+                const uint2 f8 = len ? load8_unaligned(A.buf, (uint32_t)(rec - A.buf) + start, A.buf_len) : make_uint2(0, 0);
                 for (uint32_t j = 0; j < len; ++j) {
                     if (!ham_bit(d, j)) {
-                        const uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + rec[start + j]];
+                        const uint32_t c = j < 4 ? (f8.x >> (8 * j)) & 0xffu : (j < 8 ? (f8.y >> (8 * (j - 4))) & 0xffu : rec[start + j]);
+                        const uint32_t e = tc[(j < MAX_STAT_LEN ? j : MAX_STAT_LEN) * 256 + c];
                         w.put(e >> 5, e & 31);
                     }
                 }
@@ -436,7 +440,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
                     const uint32_t lc = wc >> 16;
                     const uint8_t *mine = A.buf + ls + (wc & 0xffffu), *frst = A.buf + A.ls[i0 + gstart] + (wf & 0xffffu);
                     bool same = lc == (wf >> 16);
-                    for (uint32_t j = 0; same && j < lc; ++j) same = mine[j] == frst[j];
+                    if (same && lc) {   // eight bytes at a time (short fields: one step)
+                        for (uint32_t j = 0; same && j < lc; j += 8) {
+                            const uint2 m8 = load8_unaligned(A.buf, (uint32_t)(mine - A.buf) + j, A.buf_len);
+                            const uint2 f8 = load8_unaligned(A.buf, (uint32_t)(frst - A.buf) + j, A.buf_len);
+                            const uint64_t km = t_lowbytes(lc - j < 8 ? lc - j : 8);
+                            same = (((m8.x ^ f8.x) & (uint32_t)km) | ((m8.y ^ f8.y) & (uint32_t)(km >> 32))) == 0;
+                        }
+                    }
                     if (!same) d.txt |= (fmask_t)1 << ff;
                 }
             }
