@@ -667,7 +667,10 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
 
-    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
+    // field statistics in LDS: the 18 words of a FieldStat that this kernel updates (scalars 0..9, Hamming words 10..17), not
+    // its 24-word global layout - with 64 fields the difference is what lets a sixth workgroup onto the CU
+    constexpr uint32_t SW = 18;
+    __shared__ uint32_t s_stat[MAX_FIELDS * SW];
     // value deltas between neighbouring records (tasks.cpp:149-166): inside a wave by shuffle, across the three wave
     // boundaries of the workgroup through these (last lane's value / first lane's value, per numeric candidate)
     __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
 
     for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
         reinterpret_cast<uint32_t *>(&s_r0)[k] = reinterpret_cast<const uint32_t *>(A.rec0 + s)[k];
-    for (uint32_t k = tid; k < MAX_FIELDS * 24; k += TT_THREADS) s_stat[k] = 0;
+    for (uint32_t k = tid; k < MAX_FIELDS * SW; k += TT_THREADS) s_stat[k] = 0;
     __syncthreads();
     const uint32_t nf0 = s_r0.nf0 < MAX_FIELDS ? s_r0.nf0 : MAX_FIELDS;
 
@@ -716,8 +719,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             diff = (fd & t_lowbits(len0)) != 0 ? 1u : 0u;
             const uint64_t hm = fd & t_lowbits(minlen);   // Hamming mask: tasks.cpp:187-193
             if (__any(valid && hm != 0)) {
-                if (owned && (uint32_t)hm) t_lds_or(&s_stat[f * 24 + 10], (uint32_t)hm);
-                if (owned && (uint32_t)(hm >> 32)) t_lds_or(&s_stat[f * 24 + 11], (uint32_t)(hm >> 32));
+                if (owned && (uint32_t)hm) t_lds_or(&s_stat[f * SW + 10], (uint32_t)hm);
+                if (owned && (uint32_t)(hm >> 32)) t_lds_or(&s_stat[f * SW + 11], (uint32_t)(hm >> 32));
             }
             if (kk != 0xff && __any(valid && !(len == len0 && diff == 0))) {   // the value parser below wants the field's first bytes
                 t_field8<W>(s_w, tid, pos, w0, w1);
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             if (__any(d0 | d1)) {
                 const uint64_t hm = t_lowbytes(minlen > 8 * c8 ? minlen - 8 * c8 : 0);   // Hamming mask: tasks.cpp:187-193
                 const uint32_t hb = t_movemask(t_nonzero01(d0 & (uint32_t)hm)) | (t_movemask(t_nonzero01(d1 & (uint32_t)(hm >> 32))) << 4);
-                if (hb && owned && c8 < 32) t_lds_or(&s_stat[f * 24 + 10 + (c8 >> 2)], hb << (8 * (c8 & 3)));
+                if (hb && owned && c8 < 32) t_lds_or(&s_stat[f * SW + 10 + (c8 >> 2)], hb << (8 * (c8 & 3)));
             }
             ++c8;
         } while (__any(len > 8 * c8) || 8 * c8 < len0);
@@ -782,8 +785,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             if (lane == 0) s_first[kk][tid >> 6] = v;
             if (owned && i >= 1 && lane >= 1 && isn && pisn) {
                 const uint32_t bd = bias((int32_t)(v - pv));
-                if (bd > s_stat[f * 24 + 8]) atomicMax(&s_stat[f * 24 + 8], bd);
-                if (~bd > s_stat[f * 24 + 9]) atomicMax(&s_stat[f * 24 + 9], ~bd);
+                if (bd > s_stat[f * SW + 8]) atomicMax(&s_stat[f * SW + 8], bd);
+                if (~bd > s_stat[f * SW + 9]) atomicMax(&s_stat[f * SW + 9], ~bd);
             }
         }
 
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         const bool upd = owned && (!same || i == 0);
         if (__any(upd)) {
             if (upd) {
-                uint32_t *st = s_stat + f * 24;
+                uint32_t *st = s_stat + f * SW;
                 const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5], a6 = st[6], a7 = st[7];
                 const uint32_t bv = bias((int32_t)v);
                 const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3, n4 = !isn && !a4,
@@ -821,19 +824,19 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             const uint32_t ff = s_r0.cand_f[kk];
             if (((s_nm_first[w] & s_nm_last[w - 1]) >> ff) & 1) {
                 const uint32_t bd = bias((int32_t)(s_first[kk][w] - s_last[kk][w - 1]));
-                if (bd > s_stat[ff * 24 + 8]) atomicMax(&s_stat[ff * 24 + 8], bd);
-                if (~bd > s_stat[ff * 24 + 9]) atomicMax(&s_stat[ff * 24 + 9], ~bd);
+                if (bd > s_stat[ff * SW + 8]) atomicMax(&s_stat[ff * SW + 8], bd);
+                if (~bd > s_stat[ff * SW + 9]) atomicMax(&s_stat[ff * SW + 9], ~bd);
             }
         }
     }
     __syncthreads();
     uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
-    for (uint32_t kx = tid; kx < nf0 * 24; kx += TT_THREADS) {
+    for (uint32_t kx = tid; kx < nf0 * SW; kx += TT_THREADS) {
         uint32_t x = s_stat[kx];
         if (!x) continue;
-        uint32_t w = kx % 24;
-        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
-        else if (w < 10) atomicMax(gst + kx, x);
+        const uint32_t w = kx % SW, gx = kx / SW * 24 + w;   // (FieldStat is 24 words in global memory)
+        if (w >= 10) atomicOr(gst + gx, x);
+        else atomicMax(gst + gx, x);
     }
 }
 
