@@ -1011,7 +1011,11 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     if (rows > max_rows) rows = max_rows;
     const uint32_t rpw = sr_records_per_wg(A, max_rec);
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
-    const size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
+    // at least 24 KB, i.e. at most six workgroups per CU: with the eight that a short-read histogram (7.5 KB) allows, the
+    // kernel is 3-4 % SLOWER (0.494 against 0.476 ms; measured with 8 / 16 / 24 KB of padding - the lanes' scattered loads
+    // share the CU's 32 KB L1, and four to six workgroups' worth of them fit it better); below four it loses again
+    size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
+    if (lds < (24u << 10)) lds = 24u << 10;
     auto kern = sr_burst(A) ? k_sq_stats_reg<true> : k_sq_stats_reg<false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
