@@ -678,10 +678,12 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if ((rc = join_s())) return rc;
     if (sq_reg || sq_chunk) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
-        // length, + 25 % (from the record count: no stream size has to come back to the host first; a tile that needs
+        // length, + 10 % (from the record count: no stream size has to come back to the host first; a tile that needs
         // more writes straight to the zeroed output)
         // (average read length from the record count: a record is a title, two lines of the read's length and four more bytes)
-        const uint64_t trec = (uint64_t)R * 5 / 4;
+        // (+ 10 %, not 25: with long reads the staging is most of the kernel's LDS, and 46 KB against 42 is three workgroups per CU
+        // against four - pack 0.335 -> 0.309 ms per 400 MB of 150-base reads; a tile that overflows is still written, directly)
+        const uint64_t trec = (uint64_t)R * 11 / 10;
         // ... and, once a call has been through, from the bits per base it saw: jobs of one file look alike)
         const uint64_t avg_l = std::min<uint64_t>(max_q, (uint64_t)len / n_rec_total / 2 + 1);
         const uint64_t qx = c->qbits_x16 ? c->qbits_x16 + 4 : 80, dx = c->dbits_x16 ? c->dbits_x16 + 2 : 40;
