@@ -203,6 +203,26 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
                              double *seconds_out);
 
 /*
+ * The reading side of the two bit layouts above (host, no GPU): ReadFooter (tasks.cpp:1203-1292) and the block header as
+ * MakeHeader (tasks.cpp:1179-1200) wrote it.  footer: the footer_len bytes in front of the file's last two bytes (which hold
+ * footer_len, big endian).  overlaps / lb_sizes: P entries (lb_sizes all zero when the footer stores none: LBES, every last
+ * block then has the same size); cbo: n_blocks entries, the WRID of every block in file order.  Arrays may be NULL to fetch
+ * the scalars first.  NGSC_ERR_FORMAT: not a footer / header; NGSC_ERR_CAPACITY: an array is too small.
+ */
+typedef struct {
+    uint32_t P, n_blocks, n_subblocks, lbes;
+    uint64_t fastq_size;
+} ngsc_footer_t;
+int ngsc_read_footer(const uint8_t *footer, uint64_t footer_len, ngsc_footer_t *out, int32_t *overlaps, uint32_t *lb_sizes,
+                     uint32_t cap_ranks, uint32_t *cbo, uint32_t cap_blocks);
+typedef struct {
+    uint32_t wrid, header_len, n_subblocks, bcss; /* bcss bit 1: the first sub-block continues the previous block's last; bit 0:
+                                                   * the last one continues in the rank's next block */
+    uint32_t sb_len[63];                          /* bytes of each sub-block (piece) in this block */
+} ngsc_block_header_t;
+int ngsc_read_header(const uint8_t *block, uint64_t avail, uint32_t P, ngsc_block_header_t *out);
+
+/*
  * `<in.ngsc> <out.fastq>`: the container read back (ReadFooter tasks.cpp:1203-1292; block headers as MakeHeader
  * tasks.cpp:1179-1200 wrote them; the reference has the fragments but no caller).  Ranks ascending, each rank's sub-blocks
  * through ngsc_decompress_device() in batches; rank r's text is written at r * (FS / P) + OV[r], so a record that two

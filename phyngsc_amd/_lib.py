@@ -18,7 +18,7 @@ EXPORTS = [
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
     "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
-    "ngsc_decompress_file",
+    "ngsc_decompress_file", "ngsc_read_footer", "ngsc_read_header",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -47,6 +47,18 @@ class RankPart(ctypes.Structure):
     _fields_ = [("next_pos", ctypes.c_uint64), ("bytes_read", ctypes.c_uint64), ("bsize", ctypes.c_uint64),
                 ("overlap", ctypes.c_uint32), ("done", ctypes.c_uint32), ("overlap_used", ctypes.c_int32),
                 ("resume", ctypes.c_uint32)]
+
+
+class FooterInfo(ctypes.Structure):
+    """ngsc_footer_t"""
+    _fields_ = [("P", ctypes.c_uint32), ("n_blocks", ctypes.c_uint32), ("n_subblocks", ctypes.c_uint32), ("lbes", ctypes.c_uint32),
+                ("fastq_size", ctypes.c_uint64)]
+
+
+class BlockHeaderInfo(ctypes.Structure):
+    """ngsc_block_header_t"""
+    _fields_ = [("wrid", ctypes.c_uint32), ("header_len", ctypes.c_uint32), ("n_subblocks", ctypes.c_uint32), ("bcss", ctypes.c_uint32),
+                ("sb_len", ctypes.c_uint32 * 63)]
 
 
 class Block(ctypes.Structure):
@@ -99,6 +111,11 @@ def lib():
     L.ngsc_decompress_device.restype = ctypes.c_int
     L.ngsc_decompress_device.argtypes = [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u32), u32, vp, u64, ctypes.POINTER(u64),
                                          ctypes.POINTER(u32), vp]
+    L.ngsc_read_footer.restype = ctypes.c_int
+    L.ngsc_read_footer.argtypes = [vp, u64, ctypes.POINTER(FooterInfo), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(u32), u32,
+                                   ctypes.POINTER(u32), u32]
+    L.ngsc_read_header.restype = ctypes.c_int
+    L.ngsc_read_header.argtypes = [vp, u64, u32, ctypes.POINTER(BlockHeaderInfo)]
     L.ngsc_decompress_file.restype = ctypes.c_int
     L.ngsc_decompress_file.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
     L.ngsc_result_bytes.restype = u64

@@ -164,6 +164,37 @@ double dsec() { return std::chrono::duration<double>(std::chrono::steady_clock::
 
 }  // namespace
 
+int ngsc_read_footer(const uint8_t *footer, uint64_t footer_len, ngsc_footer_t *out, int32_t *overlaps, uint32_t *lb_sizes,
+                     uint32_t cap_ranks, uint32_t *cbo, uint32_t cap_blocks)
+{
+    if (!footer || !out) return NGSC_ERR_ARG;
+    FooterIn F;
+    if (!parse_footer(footer, footer_len, F)) return NGSC_ERR_FORMAT;
+    out->P = F.PS; out->n_blocks = F.BS; out->n_subblocks = F.SS; out->lbes = F.LBES; out->fastq_size = F.FS;
+    if ((overlaps || lb_sizes) && cap_ranks < F.PS) return NGSC_ERR_CAPACITY;
+    if (cbo && cap_blocks < F.BS) return NGSC_ERR_CAPACITY;
+    for (uint32_t i = 0; i < F.PS; ++i) {
+        if (overlaps) overlaps[i] = (int32_t)F.OV[i];
+        if (lb_sizes) lb_sizes[i] = F.LBES ? 0u : F.LBS[i];
+    }
+    if (cbo) for (uint32_t j = 0; j < F.BS; ++j) cbo[j] = F.CBO[j];
+    return NGSC_OK;
+}
+
+int ngsc_read_header(const uint8_t *block, uint64_t avail, uint32_t P, ngsc_block_header_t *out)
+{
+    if (!block || !out || P < 1) return NGSC_ERR_ARG;
+    BitRd r(block, avail);
+    out->wrid = r.get(ceil_log2_u32(P));
+    out->header_len = r.get(12);
+    out->n_subblocks = r.get(6);
+    const uint32_t beso = r.get(5);
+    out->bcss = r.get(2);
+    if (!r.ok || out->wrid >= P || out->n_subblocks > 63) return NGSC_ERR_FORMAT;
+    for (uint32_t i = 0; i < 63; ++i) out->sb_len[i] = i < out->n_subblocks ? r.get(beso) : 0u;
+    return r.ok ? NGSC_OK : NGSC_ERR_FORMAT;
+}
+
 // `.ngsc` -> FASTQ.  Footer, then every block's header (blocks lie in the footer's CBO order, 8 MiB each except a rank's
 // last), which gives each rank's sub-blocks as pieces of the file (a sub-block may continue over block borders: BCSS bits,
 // tasks.cpp:1179-1200); ranks ascending, their sub-blocks go through ngsc_decompress_device() in batches and the text of

@@ -119,3 +119,36 @@ def test_make_footer_matches_oracle():
         fs = int(rng.integers(1 << 20, 1 << 40))
         want = orc.make_footer(P, fs, 3 * nb, ov, cbo, lb)
         assert api.make_footer(P, fs, 3 * nb, ov, [int(x) for x in cbo], lb) == want
+
+
+@pytest.mark.parametrize("ngsc_path", sorted(glob.glob(os.path.join(GOLDEN, "small", "*.ngsc"))), ids=os.path.basename)
+def test_read_footer_and_headers_of_reference_outputs(ngsc_path):
+    """The reading side of the container (ngsc_read_footer = ReadFooter tasks.cpp:1203-1292, ngsc_read_header = the block header
+    of tasks.cpp:1179-1200 read back) on the committed outputs of the reference binary: same scalars, overlaps, block order,
+    last-block sizes and sub-block lengths as the independent Python reader of phyngsc_amd/ngsc_format.py."""
+    L = _lib.lib()
+    with open(ngsc_path, "rb") as f:
+        data = f.read()
+    want = nf.read_footer(data)
+    flen = (data[-2] << 8) | data[-1]
+    foot = (ctypes.c_uint8 * flen).from_buffer_copy(data[len(data) - 2 - flen:len(data) - 2])
+    info = _lib.FooterInfo()
+    assert L.ngsc_read_footer(foot, flen, ctypes.byref(info), None, None, 0, None, 0) == 0
+    assert (info.P, info.n_blocks, info.n_subblocks, info.lbes, info.fastq_size) == (want.PS, want.BS, want.SS, want.LBES, want.FS)
+    ov = (ctypes.c_int32 * info.P)()
+    lbs = (ctypes.c_uint32 * info.P)()
+    cbo = (ctypes.c_uint32 * info.n_blocks)()
+    assert L.ngsc_read_footer(foot, flen, ctypes.byref(info), ov, lbs, info.P, cbo, info.n_blocks) == 0
+    assert list(ov)[1:] == list(want.OV) and list(cbo) == list(want.CBO)
+    if not want.LBES:
+        assert list(lbs) == list(want.LBS)
+    assert L.ngsc_read_footer(foot, flen, ctypes.byref(info), ov, lbs, info.P - 1, cbo, info.n_blocks) == -10   # NGSC_ERR_CAPACITY
+    assert L.ngsc_read_footer(foot, max(flen // 2, 1), ctypes.byref(info), None, None, 0, None, 0) != 0 or flen < 4
+    _, blocks = nf.split_blocks(data)
+    for w, blk in blocks:
+        hdr = nf.read_block_header(blk, 0, want.PS)
+        got = _lib.BlockHeaderInfo()
+        buf = (ctypes.c_uint8 * len(blk)).from_buffer_copy(blk)
+        assert L.ngsc_read_header(buf, len(blk), want.PS, ctypes.byref(got)) == 0
+        assert (got.wrid, got.header_len, got.n_subblocks, got.bcss) == (w, hdr.BHS, hdr.NOSB, hdr.BCSS)
+        assert list(got.sb_len)[:hdr.NOSB] == list(hdr.SBOL)
