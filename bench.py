@@ -78,16 +78,9 @@ def algorithmic_bytes(res: api.DeviceResult, raw: int) -> dict:
         "k_sq_stats_reg": 2 * bases,
         "k_sq_measure_reg": bases,
         "k_sq_pack_reg": 2 * bases + q_out + d_out,
-        "k_seq_qual_stats_tile": 2 * bases,
-        "k_measure_sq_tile": 2 * bases,
-        "k_pack_sq_tile": 2 * bases + q_out + d_out,
         "k_seq_qual_stats": 2 * bases,
         "k_measure_sq": 2 * bases,
         "k_pack_sq": 2 * bases + q_out + d_out,
-        # chunk-per-lane path (kernels_chunk.hip, NGSC_SQ_PATH=chunk)
-        "k_ck_stats": 2 * bases,
-        "k_ck_measure": bases,
-        "k_ck_pack": 2 * bases + q_out + d_out,
         "k_zero_output": sum(sb.size for sb in res.subblocks),
     }
 

@@ -41,7 +41,7 @@ enum {
     NGSC_ERR_FORMAT = -1,      /* not 4-line FASTQ with bare '+' lines / quality length != sequence length */
     NGSC_ERR_FIELDS = -2,      /* title separator count differs inside a sub-block (reference: warning, then UB) */
     NGSC_ERR_TOOMANY = -3,     /* > 100000 records in one sub-block (reference: warning + overflow) */
-    NGSC_ERR_COLORSPACE = -4,  /* SOLiD colour-space reads (phyNGSC.cpp:473-547): out of scope */
+    NGSC_ERR_COLORSPACE = -4,  /* decoder only: a colour-space (SOLiD) sub-block, which the format stores lossily (phyNGSC.cpp:531); the compressor handles such reads */
     NGSC_ERR_RANGE = -5,       /* numeric title field >= 2^31 (reference: int32 wrap) */
     NGSC_ERR_NOMEM = -6,
     NGSC_ERR_ARG = -7,

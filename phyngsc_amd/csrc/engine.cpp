@@ -178,7 +178,7 @@ const char *ngsc_strerror(int code)
     case NGSC_ERR_FORMAT: return "input is not 4-line FASTQ with bare '+' lines and equal sequence/quality lengths";
     case NGSC_ERR_FIELDS: return "title separator count differs inside a sub-block";
     case NGSC_ERR_TOOMANY: return "more than 100000 records in one sub-block";
-    case NGSC_ERR_COLORSPACE: return "colour-space (SOLiD) reads are not supported";
+    case NGSC_ERR_COLORSPACE: return "colour-space (SOLiD) sub-block: stored lossily by the format, cannot be decoded";
     case NGSC_ERR_RANGE: return "numeric title field out of int32 range";
     case NGSC_ERR_NOMEM: return "out of memory";
     case NGSC_ERR_ARG: return "invalid argument";
@@ -437,19 +437,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_ncodes = cp.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
     size_t p_nblob = cp.take((size_t)S * MAX_FIELDS * BLOB_SLOT_512);
     size_t p_nblen = cp.take(4 * (size_t)S * MAX_FIELDS);
-    // tiled fast path: R records per tile (0 = records too long for the LDS budget -> untiled kernels)
-    uint32_t r_max = 256;
-    if (const char *ev = getenv("NGSC_TILE_RECORDS")) r_max = (uint32_t)atoi(ev);
-    // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile"
-    // (NGSC_SQ_PATH=tile keeps the LDS-tiled kernels)
-    // NGSC_SQ_PATH=chunk: one lane per 16-byte chunk out of LDS-staged wave tiles of TR records (kernels_chunk.hip) - coalesced
-    // loads, no divergence over read lengths, but 15-50 % slower than the lane-per-record kernels on every configuration
-    // measured: kept as a tested alternative, not the default
+    // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile" (kernels_sq.hip);
+    // longer records, or NGSC_SQ_PATH=wave: the wave-per-record kernels of kernels_stats.hip / kernels_pack.hip (R = 0).
+    // (The LDS-tiled and chunk-per-lane families of rounds 1-2 were slower on every configuration and are gone;
+    // DESIGN.md section 4 keeps their measurements.)
     const char *sq_env = getenv("NGSC_SQ_PATH");
-    const uint32_t TR = chunk_tile_records(max_rec_bytes);
-    const bool sq_chunk = TR != 0 && sq_env && !strcmp(sq_env, "chunk");
-    const bool sq_reg = !sq_chunk && max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "tile"));
-    const uint32_t R = sq_chunk ? TR : (sq_reg ? 256u : tile_records_for(max_rec_bytes, r_max));
+    const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "wave"));
+    const uint32_t R = sq_reg ? 256u : 0u;
     uint32_t n_tiles = 0;
     std::vector<uint32_t> tile_lo(S);
     for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
@@ -582,7 +576,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const char *ov_env = getenv("NGSC_OVERLAP");
     const bool overlap = ov_env && !strcmp(ov_env, "1");
     const bool time_all = c->profiling && c->profile_only.empty();
-    const bool stagger = (ov_env ? (!strcmp(ov_env, "2") || !strcmp(ov_env, "3")) : !time_all) && (sq_reg || sq_chunk) && !c->debug_sync;
+    const bool stagger = (ov_env ? (!strcmp(ov_env, "2") || !strcmp(ov_env, "3")) : !time_all) && sq_reg && !c->debug_sync;
     hipStream_t st2 = overlap ? c->side_stream : st;
     hipStream_t sts = stagger ? c->side_stream : st;   // the sequence/quality chain's stream behind its statistics kernel
     auto fork_s = [&]() -> int {
@@ -619,13 +613,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
         if (early && (rc = fork_s())) return rc;
         hipStream_t sq0 = early ? sts : st;
-        if (sq_chunk) { KScope k(c, sq0, "k_ck_stats"); launch_ck_stats(sq0, A, max_rec, TR, max_rec_bytes); }
-        else { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec); }
+        { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec); }
         if (!early && (rc = fork_s())) return rc;
         { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
         { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
-        if (sq_chunk) { KScope k(c, sts, "k_ck_measure"); launch_ck_measure(sts, A, max_rec, TR, max_rec_bytes); }
-        else { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
+        { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
         if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
         else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
         { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
@@ -641,9 +633,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
     { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
     { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec, t_swar); }
-    if (sq_chunk) { KScope k(c, st, "k_ck_stats"); launch_ck_stats(st, A, max_rec, TR, max_rec_bytes); }
-    else if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
-    else if (R) { KScope k(c, st, "k_seq_qual_stats_tile"); launch_seq_qual_stats_tile(st, A, max_rec, R, max_rec_bytes); }
+    if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
     if ((rc = join())) return rc;
@@ -651,12 +641,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
     if ((rc = fork())) return rc;
     { KScope k(c, st2, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st2, A, max_rec, t_swar); }
-    if (sq_chunk) {
-        { KScope k(c, st, "k_ck_measure"); launch_ck_measure(st, A, max_rec, TR, max_rec_bytes); }
-    } else if (sq_reg) {
+    if (sq_reg) {
         { KScope k(c, st, "k_sq_measure_reg"); launch_sq_measure_reg(st, A, max_rec); }
-    } else if (R) {
-        { KScope k(c, st, "k_measure_sq_tile"); launch_measure_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     } else {
         { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
     }
@@ -676,7 +662,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
     if ((rc = join_s())) return rc;
-    if (sq_reg || sq_chunk) {
+    if (sq_reg) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
         // length, + 10 % (from the record count: no stream size has to come back to the host first; a tile that needs
         // more writes straight to the zeroed output)
@@ -689,10 +675,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         const uint64_t qx = c->qbits_x16 ? c->qbits_x16 + 4 : 80, dx = c->dbits_x16 ? c->dbits_x16 + 2 : 40;
         const uint32_t sw_q = (uint32_t)(trec * avg_l * qx / 16 / 32) + 64;
         const uint32_t sw_d = (uint32_t)(trec * avg_l * dx / 16 / 32) + 64;
-        if (sq_chunk) { KScope k(c, st, "k_ck_pack"); launch_ck_pack(st, A, max_rec, TR, max_rec_bytes, sw_q, sw_d); }
-        else { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
+        { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
-    else if (R) { KScope k(c, st, "k_pack_sq_tile"); launch_pack_sq_tile(st, A, max_rec, R, max_rec_bytes); }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
     if ((rc = join())) return rc;
     // ---- the one sync behind the cut list: error word, sizes, result tables ----

@@ -145,6 +145,20 @@ __global__ __launch_bounds__(1024) void k_scan_sb(Arena A)
     if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
 }
 
+// The same for the lane-per-record kernels (kernels_sq.hip), which leave payload bits per tile of R records.
+__global__ __launch_bounds__(1024) void k_scan_tile(Arena A, uint32_t R)
+{
+    if (*A.err) return;
+    __shared__ uint32_t s_wave[17];
+    const uint32_t s = blockIdx.x;
+    SbState &sb = A.sb[s];
+    const uint32_t ntiles = (sb.n_rec + R - 1) / R;
+    uint32_t tq = wg_scan_excl(A.wq + A.tile_lo[s], ntiles, s_wave);
+    uint32_t td = wg_scan_excl(A.wd + A.tile_lo[s], ntiles, s_wave);
+    uint32_t tg = wg_scan_excl(A.goff + A.grp_lo[s], (sb.n_rec + GROUP - 1) / GROUP, s_wave);
+    if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
+}
+
 // One wave per sub-block: stream sizes.  qrow_off[s][row] = byte offset of tree `row` inside the quality header (a
 // prefix sum over up to max_q + 1 tree blobs: as a serial loop of one thread it was 150 dependent loads for 150-base reads).
 __global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
@@ -393,6 +407,11 @@ void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec)
 void launch_scan_sb(hipStream_t st, const Arena &A)
 {
     hipLaunchKernelGGL(k_scan_sb, dim3(A.n_sb), dim3(1024), 0, st, A);
+}
+
+void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
+{
+    hipLaunchKernelGGL(k_scan_tile, dim3(A.n_sb), dim3(1024), 0, st, A, R);
 }
 
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out)

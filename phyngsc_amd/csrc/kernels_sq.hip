@@ -9,7 +9,7 @@
 //   k_sq_pack_reg     StoreQuality and StoreDNA payloads (tasks.cpp:544-557, 609-619): every lane merges up to
 //                     four codes per put, ORs whole words into LDS staging; one coalesced copy-out per stream
 //
-// The LDS-tiled kernels of kernels_tile.hip spent ~23 VALU instructions per input byte and wave on per-byte
+// The LDS-tiled kernels of round 1 (removed in round 3) spent ~23 VALU instructions per input byte and wave on per-byte
 // index arithmetic; here the common case (all lanes inside their read, only A/C/G/T, qualities '!'..'`') costs
 // ~3: bases are classified with one v_perm_b32 per dword and counted with popcounts of two bit planes, a
 // quality byte costs a bit-field extract, a shift-add and one ds_add_u32 with an immediate row offset.

@@ -53,7 +53,7 @@ enum : int {
     ERR_FORMAT = -1,       // not 4-line FASTQ with a bare '+' line / quality length != sequence length
     ERR_FIELDS = -2,       // title with a different separator count than the sub-block's first record
     ERR_TOOMANY = -3,      // > 100000 records in one sub-block
-    ERR_COLORSPACE = -4,   // SOLiD colour-space reads (phyNGSC.cpp:473-547): out of scope
+    ERR_COLORSPACE = -4,   // inside the engine: "run the job again on a decoded copy" (kernels_cs.hip); to callers: only from the decoder
     ERR_RANGE = -5,        // numeric title value that the reference's uint32 parse leaves >= 2^31, or delta range >= 2^31
     ERR_NOMEM = -6,
     ERR_ARG = -7,

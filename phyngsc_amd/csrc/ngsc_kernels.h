@@ -26,13 +26,6 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t stage_q_words, uint32_t stage_d_words);
 
-// ---- kernels_chunk.hip (one lane per 16-byte chunk of a read, LDS-staged tiles) ----
-uint32_t chunk_tile_records(uint32_t max_rec_bytes);
-void launch_ck_stats(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes);
-void launch_ck_measure(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes);
-void launch_ck_pack(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t TR, uint32_t max_rec_bytes, uint32_t stage_q_words,
-                    uint32_t stage_d_words);
-
 // ---- kernels_cs.hip (colour-space reads decoded into a copy of the job's input) ----
 void launch_cs(hipStream_t st, const Arena &A, uint32_t max_rec, const uint8_t *orig, uint8_t *copy, uint32_t *se_w);
 
@@ -51,6 +44,7 @@ void launch_huffman_text(hipStream_t st, const Arena &A);
 // ---- kernels_pack.hip ----
 void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_scan_sb(hipStream_t st, const Arena &A);
+void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R);   // (lane-per-record path: per-tile bit counts)
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out);
 void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap);
 void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off);
@@ -63,12 +57,5 @@ void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar);
 void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
-
-// ---- kernels_tile.hip (LDS-tiled sequence / quality path) ----
-uint32_t tile_records_for(uint32_t max_rec_bytes, uint32_t r_max);
-void launch_seq_qual_stats_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
-void launch_measure_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
-void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R);
-void launch_pack_sq_tile(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t R, uint32_t max_rec_bytes);
 
 }  // namespace ngsc

@@ -1,5 +1,5 @@
-// ngsc_sq.h - device helpers shared by the sequence / quality kernels (kernels_sq.hip: one lane per record from
-// global memory; kernels_chunk.hip: one lane per 16-byte chunk from an LDS-staged tile): SWAR base / quality
+// ngsc_sq.h - device helpers of the sequence / quality kernels (kernels_sq.hip: one lane per record from
+// global memory): SWAR base / quality
 // classification, wave reductions, the per-lane MSB-first bit writer and the 256-thread exclusive scan.
 #pragma once
 #include "ngsc_swar.h"

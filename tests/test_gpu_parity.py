@@ -105,43 +105,33 @@ def test_against_oracle(eng, name, cfg, size, P):
     assert out == want
 
 
-@pytest.mark.parametrize("name,cfg,size,P", ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
-def test_chunk_path_against_oracle(eng, monkeypatch, name, cfg, size, P):
-    """The chunk-per-lane sequence/quality kernels (NGSC_SQ_PATH=chunk) on the generated cases, and the
-    default kernels without the chunk-major copies of bases and qualities (NGSC_SQ_DENSE=0: measure and pack read the file)."""
+@pytest.mark.parametrize("name,cfg,size,P", ORACLE_CASES[:4], ids=[c[0] for c in ORACLE_CASES[:4]])
+def test_no_dense_copies_against_oracle(eng, monkeypatch, name, cfg, size, P):
+    """The default kernels without the chunk-major copies of bases and qualities (NGSC_SQ_DENSE=0: measure and pack read
+    the file themselves, which is also what jobs whose copies would not fit do)."""
     data = fastq_gen.generate(cfg, target_bytes=size // 2)
     want, _ = orc.compress_file(data, P, threads=8)
     monkeypatch.setenv("NGSC_SQ_DENSE", "0")
     _, out = _gpu(eng, data, P)
     assert out == want, "NGSC_SQ_DENSE=0"
-    monkeypatch.delenv("NGSC_SQ_DENSE")
-    monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
-    _, out = _gpu(eng, data, P)
-    assert out == want
 
 
 PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "title_numeric.p3", "title_long.p2",
               "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
 
 
-@pytest.mark.parametrize("tile_records", ["reg", "dense", "chunk", "chunk16", "chunk32", "1", "64", "128", "256"])
-def test_kernel_paths_agree(eng, monkeypatch, tile_records):
-    """The sequence/quality kernels exist in four forms: register-streaming (one lane per record, the default for
-    records up to 2 KB), one lane per 16-byte chunk out of LDS-staged wave tiles (NGSC_SQ_PATH=chunk; 16..64 records
-    per tile), LDS-tiled (NGSC_SQ_PATH=tile: 64/128/256 records per tile, 4/2/1 threads per record) and
-    wave-per-record (records above 2 KB; forced here with NGSC_TILE_RECORDS=1 = no tile size allowed): every form
-    must reproduce the reference."""
-    if tile_records.startswith("chunk"):
-        monkeypatch.setenv("NGSC_SQ_PATH", "chunk")
-        if tile_records != "chunk":
-            monkeypatch.setenv("NGSC_CHUNK_TILE_RECORDS", tile_records[5:])
-    elif tile_records == "dense":   # (the default) the statistics kernel leaves chunk-major copies of bases and qualities
-        monkeypatch.setenv("NGSC_SQ_DENSE", "1")   # for measure / pack; "reg" = they read the file themselves
-    elif tile_records == "reg":
+@pytest.mark.parametrize("sq_path", ["reg", "dense", "wave"])
+def test_kernel_paths_agree(eng, monkeypatch, sq_path):
+    """The sequence/quality kernels exist in two forms: register-streaming (one lane per record, the default for
+    records up to 2 KB; "dense" = with the chunk-major copies the statistics kernel leaves for measure and pack, "reg" =
+    measure and pack read the file themselves) and wave-per-record (records above 2 KB; forced here with
+    NGSC_SQ_PATH=wave): every form must reproduce the reference."""
+    if sq_path == "dense":
+        monkeypatch.setenv("NGSC_SQ_DENSE", "1")
+    elif sq_path == "reg":
         monkeypatch.setenv("NGSC_SQ_DENSE", "0")
     else:
-        monkeypatch.setenv("NGSC_SQ_PATH", "tile")
-        monkeypatch.setenv("NGSC_TILE_RECORDS", tile_records)
+        monkeypatch.setenv("NGSC_SQ_PATH", "wave")
     for name in PATH_CASES:
         stem, P = name.rsplit(".p", 1)
         with open(os.path.join(GOLDEN, "small", stem + ".fastq"), "rb") as f:
@@ -150,7 +140,7 @@ def test_kernel_paths_agree(eng, monkeypatch, tile_records):
             ref = f.read()
         _, out = _gpu(eng, data, int(P))
         ok, msg = nf.equivalent(ref, out)
-        assert ok, f"{name} (tile_records={tile_records}): {msg}"
+        assert ok, f"{name} (sq_path={sq_path}): {msg}"
 
 
 @pytest.mark.parametrize("title_path", ["reg", "swar"])
@@ -612,13 +602,6 @@ def test_edge_cases(eng, name):
     want, _ = orc.compress_file(data, P)
     assert out == want
     assert orc.decompress(out) == data
-    import os as _os
-    _os.environ["NGSC_SQ_PATH"] = "chunk"      # ... and through the chunk-per-lane sequence/quality kernels
-    try:
-        _, out2 = _gpu(eng, data, P)
-    finally:
-        del _os.environ["NGSC_SQ_PATH"]
-    assert out2 == want
 
 
 @pytest.mark.parametrize("seed", range(0, 64))
