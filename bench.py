@@ -13,14 +13,17 @@ generator so that every GPU's share can be produced on its own), 8 virtual ranks
 Two ways to run N > 1, same work per GPU, same JSON line:
   * under torch.distributed.run (WORLD_SIZE set): one process per GPU; the only collective is the all-gather of
     block sizes that assigns file offsets (RCCL over xGMI; replaces MPI_Gather/Gatherv, phyNGSC.cpp:964, 994);
-  * plain `python bench.py --gpus N`: ONE process, N contexts, one host thread per GPU calling
-    ngsc_compress_device on its own device (ctypes releases the GIL) - the north-star's "single-process host that
-    partitions sub-blocks across the GPUs of one node"; the block sizes meet in host memory.
+  * plain `python bench.py --gpus N`: ONE process, a team (ngsc.h: ngsc_team_*): one C++ host thread per GPU calling
+    ngsc_compress_device on its own device, then an RCCL all-gather of the per-rank block rows through a communicator
+    created inside this process (ncclCommInitAll) - the north-star's "single-process host that partitions sub-blocks
+    across the GPUs of one node ... only a tiny RCCL prefix-sum over xGMI"; config.rccl_ranks / config.collective say
+    what the communicator was.
 Prints ONE JSON line (rank 0 / the main thread).
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import hashlib
 import json
 import os
@@ -189,7 +192,7 @@ def profile_pass(sh: Share):
     return ktimes_all, dom
 
 
-def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, launch_mode):
+def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, launch_mode, extra_config=None):
     res, eng = sh.res, sh.eng
     ktimes = eng.kernel_times()
     alg = algorithmic_bytes(res, sh.my_raw)
@@ -245,6 +248,8 @@ def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, la
                                if alg.get(k) and v["ms_avg"] > 0},
         "kernels_ms": {k: round(v["ms_avg"], 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_avg"])},
     }
+    if extra_config:
+        line["config"].update(extra_config)
     if world == 1 and not args.no_verify:
         out = api.assemble_container(res, sh.P, sh.file_size)
         man_path = os.path.join(ROOT, "tests", "golden", "manifest_cfg2_1GB.json")
@@ -274,30 +279,34 @@ def run_distributed(args, world: int):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev   # where the (tiny) collective tensors live
+    pg = None                                            # the RCCL group of the exchange (None: the default group)
     coll = "gloo rehearsal on one device" if rehearse else "RCCL all-gather of block sizes"
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            # The collectives carry a few hundred bytes (block sizes, the max of the times); compression itself never
-            # touches them.  Should RCCL fail to come up on a node, the run goes on with gloo for those bytes and SAYS so in
-            # config.launch instead of leaving the scaling point unmeasured.
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                t = torch.ones(1, device=dev)
-                dist.all_reduce(t)
-                torch.cuda.synchronize()
-                if int(t.item()) != world:
-                    raise RuntimeError(f"all_reduce of ones gave {t.item()}")
-            except Exception as e:   # noqa: BLE001
-                reason = f"{type(e).__name__}: {e}".splitlines()[0][:160]
+            # gloo is the agreement channel (barriers, and the decision below); the block-size exchange itself goes over an
+            # RCCL group when EVERY rank got one.  The decision is collective: a rank that fell back on its own would
+            # leave its peers waiting inside an RCCL call (a rank stuck there comes back with the group's timeout).
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            ok, reason = 1, ""
+            if os.environ.get("NGSC_BENCH_COLL") == "gloo":
+                ok, reason = 0, "NGSC_BENCH_COLL=gloo"
+            else:
                 try:
-                    dist.destroy_process_group()
-                except Exception:   # noqa: BLE001
-                    pass
-                dist.init_process_group("gloo")
-                cdev = torch.device("cpu")
-                coll = f"gloo all-gather of block sizes (RCCL unusable here: {reason})"
+                    pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                    t = torch.ones(1, device=dev)
+                    dist.all_reduce(t, group=pg)
+                    torch.cuda.synchronize()
+                    if int(t.item()) != world:
+                        raise RuntimeError(f"all_reduce of ones gave {t.item()}")
+                except Exception as e:   # noqa: BLE001
+                    ok, reason = 0, f"{type(e).__name__}: {e}".splitlines()[0][:160]
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                pg, cdev = None, torch.device("cpu")
+                coll = f"gloo all-gather of block sizes (RCCL unusable on some rank{': ' + reason if reason else ''})"
     sh = Share(world, rank, local_rank, args.size_mb * 1_000_000)
 
     def barrier():
@@ -319,88 +328,72 @@ def run_distributed(args, world: int):
     if world > 1:
         # the one (data-path-free) collective: block sizes -> file offsets (RCCL all-gather over xGMI)
         sizes_local, meta_local = sh.block_sizes()
-        sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=cdev)
+        sizes_all, _ = api.exchange_block_sizes(sizes_local, meta_local, dist, device=cdev, group=pg)
         api.file_offsets(sizes_all, api.ranks_per_group(sh.file_size, sh.P))
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
         dt = float(t.item())
         tot = torch.tensor([sh.my_raw, sh.res.total_bytes], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=pg)
         total_raw, total_out = int(tot[0].item()), int(tot[1].item())
     else:
         total_raw, total_out = sh.file_size, sh.res.total_bytes
     if rank == 0:
         mode = ("one process per GPU (torch.distributed.run), " + coll) if world > 1 else "one process, one context"
-        report(sh, args, world, dt, total_raw, total_out, ktimes_all, dom, mode)
+        extra = None
+        if world > 1:
+            extra = {"rccl_ranks": dist.get_world_size(pg) if pg is not None else 0, "collective": coll, "collective_per_step": False}
+        report(sh, args, world, dt, total_raw, total_out, ktimes_all, dom, mode, extra)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-# ---- one process, N contexts, one host thread per GPU --------------------------------------------------------------
-def run_threads(args):
+# ---- one process, N GPUs: a team (one host thread per GPU inside the library + an in-process RCCL communicator) ----------
+def run_team(args):
+    """`python bench.py --gpus N` without a launcher: the north star's single-process host.  Every step is ONE call of
+    ngsc_team_compress: each GPU compresses its 8 virtual ranks on its own host thread (C++, no GIL), then the per-rank block
+    rows are all-gathered with RCCL over xGMI (ncclCommInitAll inside this process) and every GPU holds what it needs for
+    the file offsets.  config.rccl_ranks is what the communicator reports; 0 means the rows met in host memory and
+    config.collective says why."""
     n = args.gpus
     ndev = torch.cuda.device_count()
-    rehearse = os.environ.get("NGSC_BENCH_REHEARSE") == "1"   # all contexts on device 0 (one-GPU box)
+    rehearse = os.environ.get("NGSC_BENCH_REHEARSE") == "1"   # all contexts on device 0 (one-GPU box): no RCCL there
     if ndev < n and not rehearse:
         raise SystemExit(f"--gpus {n} but this node shows {ndev} GPU(s)")
-    shares = [None] * n
-    errors = []
-    gate = threading.Barrier(n + 1)
-    dts = [0.0] * n
-    prof = {}
-
-    def worker(i):
-        try:
-            dev = 0 if rehearse else i
-            sh = Share(n, i, dev, args.size_mb * 1_000_000)
-            shares[i] = sh
-            for _ in range(args.warmup):
-                sh.step()
-            if i == 0:
-                prof["k"], prof["dom"] = profile_pass(sh)
-            else:
-                for _ in range(2):
-                    sh.step()
-            torch.cuda.synchronize(dev)
-            gate.wait()                      # barrier + synchronize, then exactly K steps, then the same again
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                sh.step()
-            torch.cuda.synchronize(dev)
-            dts[i] = time.perf_counter() - t0
-            gate.wait()
-        except BaseException as e:  # noqa: BLE001
-            errors.append((i, e))
-            gate.abort()
-
-    threads = [threading.Thread(target=worker, args=(i,), name=f"gpu{i}") for i in range(n)]
-    for t in threads:
-        t.start()
-    try:
-        gate.wait()
-        t0 = time.perf_counter()
-        gate.wait()
-        dt_wall = time.perf_counter() - t0
-    except threading.BrokenBarrierError:
-        dt_wall = 0.0
-    for t in threads:
-        t.join()
-    if errors:
-        raise SystemExit(f"worker {errors[0][0]} failed: {errors[0][1]!r}")
-    dt = max(max(dts), dt_wall)              # MAX over the GPUs' own clocks and the main thread's
-    # block sizes of all ranks meet in host memory: same offsets computation as the RCCL path (api.file_offsets)
-    sizes_all = []
-    for sh in shares:
-        s, _ = sh.block_sizes()
-        sizes_all.extend(s)
-    api.file_offsets(sizes_all, api.ranks_per_group(shares[0].file_size, shares[0].P))
-    total_raw = sum(sh.my_raw for sh in shares)
-    total_out = sum(sh.res.total_bytes for sh in shares)
+    shares = [Share(n, i, 0 if rehearse else i, args.size_mb * 1_000_000) for i in range(n)]
+    team = api.Team([sh.eng for sh in shares])
     sh0 = shares[0]
+    P, fs = sh0.P, sh0.file_size
+    row_len = 3 + int(fs // P * 0.6 // (8 << 20)) + 4
+    shards = [(sh.d_in, sh.buf_off, sh.lo_rank, sh.hi_rank, sh.d_out) for sh in shares]
+
+    def sync_all():
+        for sh in shares:
+            torch.cuda.synchronize(sh.device)
+
+    rows, ms = None, None
+    for _ in range(args.warmup):
+        rows, ms = team.compress(shards, fs, P, row_len)
+    ktimes_all, dom = profile_pass(sh0)         # per-kernel table from GPU 0 alone (untimed)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows, ms = team.compress(shards, fs, P, row_len)
+    sync_all()
+    dt = time.perf_counter() - t0
+    # the offsets every GPU derives from the gathered rows, against the Python statement of the same order
+    sizes_all, _ = api.sizes_from_rows(rows)
+    assert api.rows_to_offsets(rows, fs) == api.file_offsets(sizes_all, api.ranks_per_group(fs, P))
+    sh0.res = sh0.step()                        # (report() reads GPU 0's result tables)
+    total_raw = sum(sh.my_raw for sh in shares)
+    total_out = sum(int(sh.eng._L.ngsc_result_bytes(sh.eng._h)) for sh in shares)
     sh0.eng.set_profiling(False)
-    mode = f"one process, {n} contexts on {n} host threads" + (" (rehearsal: all on device 0)" if rehearse else "")
-    report(sh0, args, n, dt, total_raw, total_out, prof["k"], prof["dom"], mode)
+    mode = f"one process, team of {n} host threads / contexts" + (" (rehearsal: all on device 0)" if rehearse else "")
+    extra = {"rccl_ranks": team.rccl_ranks, "collective": team.describe, "collective_per_step": True,
+             "member_ms_last_step": [round(x, 3) for x in ms]}
+    report(sh0, args, n, dt, total_raw, total_out, ktimes_all, dom, mode, extra)
+    team.close()
 
 
 def main():
@@ -420,7 +413,7 @@ def main():
     elif args.gpus == 1:
         run_distributed(args, 1)
     else:
-        run_threads(args)
+        run_team(args)
 
 
 if __name__ == "__main__":

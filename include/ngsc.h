@@ -203,6 +203,45 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
                              double *seconds_out);
 
 /*
+ * ---- one process, several GPUs, one collective ---------------------------------------------------------------------
+ * A team = one host thread per context (one context per GPU) + an RCCL communicator created INSIDE this process
+ * (ncclCommInitAll over the contexts' devices; ranks talk over xGMI, no launcher).  It replaces the reference's only two
+ * exchanges, MPI_Gather of {n_blocks, n_subblocks, last_block_size, wr_overlap} (phyNGSC.cpp:934-964) and MPI_Gatherv
+ * of the block timestamps (:994): after compressing its shard of virtual ranks - no data-path collective - every
+ * member all-gathers one row of u64 per virtual rank,
+ *     row = { n_blocks, n_subblocks, overlap_used (sign-extended), size of block 0, 1, ... }   (row_len words, zero padded)
+ * and every member then holds all P rows; file offsets follow from a local prefix sum over the deterministic block
+ * order (ngsc_rows_to_offsets).  RCCL is bound at run time (dlopen librccl.so.1; NGSC_RCCL=0 or NGSC_RCCL_LIB=path
+ * override).  Without it, or when two contexts share a device, the team still works: ngsc_team_rccl_ranks() == 0,
+ * ngsc_team_describe() says why, and the rows meet in host memory.
+ */
+typedef struct ngsc_team ngsc_team;
+typedef struct {
+    const void *d_buf;          /* file bytes [buf_off, buf_off + buf_len) on the member's GPU */
+    uint64_t buf_len, buf_off;
+    uint32_t rank_lo, rank_hi;  /* member i of n owns the virtual ranks [i * P / n, (i + 1) * P / n) */
+    void *d_out;
+    uint64_t out_cap;
+} ngsc_shard_t;
+int ngsc_team_create(ngsc_ctx **ctxs, uint32_t n_ctx, ngsc_team **out);
+void ngsc_team_destroy(ngsc_team *team);
+uint32_t ngsc_team_size(ngsc_team *team);
+uint32_t ngsc_team_rccl_ranks(ngsc_team *team);   /* ncclCommCount() of the communicator; 0 = no RCCL, host memory */
+const char *ngsc_team_describe(ngsc_team *team);  /* which collective a step uses, and why if it is not RCCL */
+/* One step: member i compresses shards[i] on its own thread and GPU (ngsc_compress_device; the results stay in its
+ * context), plans its ranks' 8 MiB blocks, then the rows are all-gathered.  rows: P x row_len words, identical on every
+ * member (checked).  row_len >= 3 + the largest block count of a rank, else NGSC_ERR_CAPACITY.  shard_ms (nullable):
+ * host time of each member's part. */
+int ngsc_team_compress(ngsc_team *team, const ngsc_shard_t *shards, uint64_t file_size, uint32_t P, uint64_t *rows,
+                       uint32_t row_len, double *shard_ms);
+/* The bare collective: member i contributes send[i * count .. ), receives all n * count words; recv: n x (n * count). */
+int ngsc_team_allgather_u64(ngsc_team *team, const uint64_t *send, uint32_t count, uint64_t *recv);
+/* Offsets from rows (host): offsets[r * (row_len - 3) + k] = file offset of rank r's k-th block; cbo: WRID of every block
+ * in file order (nullable); *end: where the footer goes. */
+int ngsc_rows_to_offsets(const uint64_t *rows, uint32_t P, uint32_t row_len, uint64_t file_size, uint64_t *offsets, uint32_t *cbo,
+                         uint32_t cbo_cap, uint32_t *n_blocks, uint64_t *end);
+
+/*
  * The reading side of the two bit layouts above (host, no GPU): ReadFooter (tasks.cpp:1203-1292) and the block header as
  * MakeHeader (tasks.cpp:1179-1200) wrote it.  footer: the footer_len bytes in front of the file's last two bytes (which hold
  * footer_len, big endian).  overlaps / lb_sizes: P entries (lb_sizes all zero when the footer stores none: LBES, every last

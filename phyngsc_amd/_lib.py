@@ -19,6 +19,8 @@ EXPORTS = [
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
     "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
     "ngsc_decompress_file", "ngsc_read_footer", "ngsc_read_header",
+    "ngsc_team_create", "ngsc_team_destroy", "ngsc_team_size", "ngsc_team_rccl_ranks", "ngsc_team_describe",
+    "ngsc_team_compress", "ngsc_team_allgather_u64", "ngsc_rows_to_offsets",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -64,6 +66,12 @@ class BlockHeaderInfo(ctypes.Structure):
 class Block(ctypes.Structure):
     _fields_ = [("wrid", ctypes.c_uint32), ("size", ctypes.c_uint32), ("header_len", ctypes.c_uint32),
                 ("payload", ctypes.c_uint32), ("stream_off", ctypes.c_uint64), ("header", ctypes.c_uint8 * 288)]
+
+
+class Shard(ctypes.Structure):
+    """ngsc_shard_t: one team member's share of a step."""
+    _fields_ = [("d_buf", ctypes.c_void_p), ("buf_len", ctypes.c_uint64), ("buf_off", ctypes.c_uint64),
+                ("rank_lo", ctypes.c_uint32), ("rank_hi", ctypes.c_uint32), ("d_out", ctypes.c_void_p), ("out_cap", ctypes.c_uint64)]
 
 
 class KernelTime(ctypes.Structure):
@@ -142,5 +150,22 @@ def lib():
                                            ctypes.POINTER(ctypes.c_double)]
     L.ngsc_ctx_device.restype = ctypes.c_int
     L.ngsc_ctx_device.argtypes = [vp]
+    L.ngsc_team_create.restype = ctypes.c_int
+    L.ngsc_team_create.argtypes = [ctypes.POINTER(vp), u32, ctypes.POINTER(vp)]
+    L.ngsc_team_destroy.restype = None
+    L.ngsc_team_destroy.argtypes = [vp]
+    L.ngsc_team_size.restype = u32
+    L.ngsc_team_size.argtypes = [vp]
+    L.ngsc_team_rccl_ranks.restype = u32
+    L.ngsc_team_rccl_ranks.argtypes = [vp]
+    L.ngsc_team_describe.restype = ctypes.c_char_p
+    L.ngsc_team_describe.argtypes = [vp]
+    L.ngsc_team_compress.restype = ctypes.c_int
+    L.ngsc_team_compress.argtypes = [vp, ctypes.POINTER(Shard), u64, u32, ctypes.POINTER(u64), u32, ctypes.POINTER(ctypes.c_double)]
+    L.ngsc_team_allgather_u64.restype = ctypes.c_int
+    L.ngsc_team_allgather_u64.argtypes = [vp, ctypes.POINTER(u64), u32, ctypes.POINTER(u64)]
+    L.ngsc_rows_to_offsets.restype = ctypes.c_int
+    L.ngsc_rows_to_offsets.argtypes = [ctypes.POINTER(u64), u32, u32, u64, ctypes.POINTER(u64), ctypes.POINTER(u32), u32,
+                                       ctypes.POINTER(u32), ctypes.POINTER(u64)]
     _lib = L
     return L

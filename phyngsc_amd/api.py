@@ -192,6 +192,97 @@ def compress_file_multi(engines: Sequence["Engine"], in_path: str, out_path: str
     return sec[0], sec[1], sec[2]
 
 
+class Team:
+    """One process, several GPUs (ngsc.h: ngsc_team_*): one host thread per engine inside the library plus an RCCL communicator
+    created in-process (ncclCommInitAll).  ``compress`` runs one step on every GPU at once and all-gathers the per-rank block
+    rows; ``rccl_ranks`` is what the communicator reports (0: the rows met in host memory, ``describe`` says why)."""
+
+    def __init__(self, engines: Sequence["Engine"]):
+        self._L = _lib.lib()
+        self.engines = list(engines)
+        hs = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+        h = ctypes.c_void_p()
+        rc = self._L.ngsc_team_create(hs, len(engines), ctypes.byref(h))
+        if rc:
+            raise NgscError(rc)
+        self._h = h
+        self.n = len(engines)
+        self.rccl_ranks = int(self._L.ngsc_team_rccl_ranks(h))
+        self.describe = self._L.ngsc_team_describe(h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ngsc_team_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compress(self, shards: Sequence[tuple], file_size: int, P: int, row_len: int):
+        """shards[i] = (d_in tensor, buf_off, rank_lo, rank_hi, d_out tensor) on engine i's device.  Returns (rows, ms per member):
+        rows[r] = [n_blocks, n_subblocks, overlap_used, block sizes ...] for every virtual rank r, as every GPU holds them after
+        the all-gather."""
+        arr = (_lib.Shard * self.n)()
+        for i, (d_in, buf_off, lo, hi, d_out) in enumerate(shards):
+            arr[i].d_buf, arr[i].buf_len, arr[i].buf_off = d_in.data_ptr(), d_in.numel(), buf_off
+            arr[i].rank_lo, arr[i].rank_hi, arr[i].d_out, arr[i].out_cap = lo, hi, d_out.data_ptr(), d_out.numel()
+        rows = (ctypes.c_uint64 * (P * row_len))()
+        ms = (ctypes.c_double * self.n)()
+        rc = self._L.ngsc_team_compress(self._h, arr, file_size, P, rows, row_len, ms)
+        if rc:
+            raise NgscError(rc, "; ".join(self._L.ngsc_last_hip_error(e._h).decode() for e in self.engines))
+        return np.frombuffer(rows, dtype=np.uint64).reshape(P, row_len).copy(), list(ms)
+
+    def allgather_u64(self, send: np.ndarray) -> np.ndarray:
+        """The bare collective: send[i] (count words) from member i; returns recv[i] = what member i received (n x count)."""
+        send = np.ascontiguousarray(send, dtype=np.uint64)
+        assert send.shape[0] == self.n
+        count = int(send.size // self.n)
+        recv = np.zeros((self.n, self.n * count), dtype=np.uint64)
+        rc = self._L.ngsc_team_allgather_u64(self._h, send.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), count,
+                                             recv.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+        if rc:
+            raise NgscError(rc)
+        return recv
+
+
+def rows_from_sizes(sizes: Sequence[Sequence[int]], meta: Sequence[Tuple[int, int]], row_len: int) -> np.ndarray:
+    """The exchange's row layout (ngsc.h): [n_blocks, n_subblocks, overlap_used, sizes ...] per virtual rank."""
+    rows = np.zeros((len(sizes), row_len), dtype=np.uint64)
+    for r, (s, m) in enumerate(zip(sizes, meta)):
+        assert len(s) + 3 <= row_len
+        rows[r, 0], rows[r, 1], rows[r, 2] = len(s), m[0], np.int64(m[1]).astype(np.uint64)
+        rows[r, 3:3 + len(s)] = s
+    return rows
+
+
+def sizes_from_rows(rows: np.ndarray):
+    """Inverse of rows_from_sizes: (sizes per rank, (n_subblocks, overlap_used) per rank)."""
+    sizes = [[int(x) for x in row[3:3 + int(row[0])]] for row in rows]
+    meta = [(int(row[1]), int(np.uint64(row[2]).astype(np.int64))) for row in rows]
+    return sizes, meta
+
+
+def rows_to_offsets(rows: np.ndarray, file_size: int):
+    """ngsc_rows_to_offsets: {(rank, k): file offset}, cbo, end - the library's own prefix sum over the block order."""
+    L = _lib.lib()
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    P, row_len = rows.shape
+    offs = np.zeros((P, row_len - 3), dtype=np.uint64)
+    cap = int(rows[:, 0].sum()) + 1
+    cbo = (ctypes.c_uint32 * cap)()
+    nb, end = ctypes.c_uint32(), ctypes.c_uint64()
+    rc = L.ngsc_rows_to_offsets(rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), P, row_len, file_size,
+                                offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), cbo, cap, ctypes.byref(nb), ctypes.byref(end))
+    if rc:
+        raise NgscError(rc)
+    table = {(r, k): int(offs[r, k]) for r in range(P) for k in range(int(rows[r, 0]))}
+    return table, list(cbo[:nb.value]), int(end.value)
+
+
 def _copy_struct(s):
     c = type(s)()
     ctypes.memmove(ctypes.byref(c), ctypes.byref(s), ctypes.sizeof(s))
@@ -312,8 +403,10 @@ def ranks_of_process(P: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def exchange_block_sizes(local_sizes: List[List[int]], local_meta: List[Tuple[int, int]], dist, device=None):
-    """The only cross-GPU step: all-gather of per-rank block sizes + (n_subblocks, overlap_used).
+def exchange_block_sizes(local_sizes: List[List[int]], local_meta: List[Tuple[int, int]], dist, device=None, group=None):
+    """The only cross-GPU step, one-process-per-GPU form: all-gather of the per-rank rows
+    [n_blocks, n_subblocks, overlap_used, block sizes ...] (the row layout of ngsc.h: ngsc_team_compress does the same
+    exchange with RCCL inside one process).
 
     Replaces MPI_Gather / MPI_Gatherv of phyNGSC.cpp:964, 994 and the arrival-order shared file
     pointer: every process learns every rank's block sizes and derives the same file offsets.
@@ -321,29 +414,17 @@ def exchange_block_sizes(local_sizes: List[List[int]], local_meta: List[Tuple[in
     Returns (sizes per global rank, meta per global rank) in WRID order.
     """
     import torch
-    world = dist.get_world_size()
-    per = len(local_sizes)
+    world = dist.get_world_size(group)
     maxb = max((len(s) for s in local_sizes), default=0)
     t = torch.tensor([maxb], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    maxb = int(t.item())
-    payload = torch.zeros(per, maxb + 3, dtype=torch.int64, device=device)
-    for i, (s, m) in enumerate(zip(local_sizes, local_meta)):
-        payload[i, 0] = len(s)
-        payload[i, 1] = m[0]
-        payload[i, 2] = m[1]
-        if s:
-            payload[i, 3:3 + len(s)] = torch.tensor(s, dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    row_len = int(t.item()) + 3
+    rows = rows_from_sizes(local_sizes, local_meta, row_len)
+    payload = torch.from_numpy(rows.view(np.int64)).to(device) if device is not None else torch.from_numpy(rows.view(np.int64).copy())
     gathered = [torch.zeros_like(payload) for _ in range(world)]
-    dist.all_gather(gathered, payload)
-    sizes, meta = [], []
-    for g in gathered:
-        g = g.cpu()
-        for i in range(per):
-            nb = int(g[i, 0])
-            sizes.append([int(x) for x in g[i, 3:3 + nb]])
-            meta.append((int(g[i, 1]), int(g[i, 2])))
-    return sizes, meta
+    dist.all_gather(gathered, payload, group=group)
+    all_rows = np.concatenate([g.cpu().numpy().view(np.uint64) for g in gathered], axis=0)
+    return sizes_from_rows(all_rows)
 
 
 def file_offsets(sizes_per_rank: Sequence[Sequence[int]], ranks_per_grp: Optional[int] = None):

@@ -613,7 +613,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
         if (early && (rc = fork_s())) return rc;
         hipStream_t sq0 = early ? sts : st;
-        { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec); }
+        { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec, max_rec_bytes); }
         if (!early && (rc = fork_s())) return rc;
         { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
         { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
@@ -633,7 +633,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
     { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
     { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec, t_swar); }
-    if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec); }
+    if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec, max_rec_bytes); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
     if ((rc = join())) return rc;

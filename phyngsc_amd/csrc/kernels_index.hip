@@ -21,33 +21,22 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t y)
     return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
 }
 
-// Newline flags of the 32 bytes starting at `base` (restricted to [start, len)): 8 words of bit-7 flags.
-__device__ __forceinline__ uint32_t load_nl_flags(const uint8_t *buf, uint32_t base, uint32_t start, uint32_t len,
-                                                  uint32_t flags[8])
+// Newline flags of the 16 bytes starting at `base` (restricted to [start, len)) as a 16-bit mask, bit k = byte base + k.
+__device__ __forceinline__ uint32_t load_nl_mask16(const uint8_t *buf, uint32_t base, uint32_t start, uint32_t len)
 {
-    uint32_t cnt = 0;
-    if (base >= start && base + BYTES_PER_THREAD <= len) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(buf + base);
-        uint4 a = p[0], b = p[1];
-        uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t m = 0;
+    if (base >= start && base + 16 <= len) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(buf + base);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            flags[i] = zero_bytes(w[i] ^ 0x0A0A0A0Au);
-            cnt += __popc(flags[i]);
-        }
+        for (int i = 0; i < 4; ++i) m |= (((zero_bytes(w[i] ^ 0x0A0A0A0Au) >> 7) * 0x01020408u) >> 24) << (4 * i);
     } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint32_t f = 0;
-            for (int k = 0; k < 4; ++k) {
-                uint32_t pos = base + i * 4 + k;
-                if (pos >= start && pos < len && buf[pos] == '\n') f |= 0x80u << (8 * k);
-            }
-            flags[i] = f;
-            cnt += __popc(f);
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t pos = base + k;
+            if (pos >= start && pos < len && buf[pos] == '\n') m |= 1u << k;
         }
     }
-    return cnt;
+    return m;
 }
 
 __device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v)
@@ -78,20 +67,41 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
     __shared__ uint32_t s_part[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
     uint32_t c = 0;
+    // Every load instruction of a wave covers one contiguous KB (16 bytes per lane), and a tile that lies inside [start, len)
+    // - all but the job's first and last - takes a branch-free path with eight loads in flight per lane: behind the
+    // per-load range tests the compiler waited for every load before issuing the next (one KB in flight per wave).  One
+    // bit per byte is kept: the write pass reads 1/8 of a byte per input byte instead of the input again; a lane's 16 bits
+    // are half a mask word.
+    uint16_t *mask16 = reinterpret_cast<uint16_t *>(nl_mask);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t tile0 = blockIdx.x * TILE_BYTES;
+    if (tile0 >= start && tile0 + TILE_BYTES <= len && tile0 + TILE_BYTES > tile0) {
 #pragma unroll
-    for (uint32_t pc = 0; pc < PIECES; ++pc) {
-        const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-        uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        c += (base < len && base + BYTES_PER_THREAD > start) ? load_nl_flags(buf, base, start, len, flags) : 0;
-        // one bit per byte: the write pass reads 1/8 of a byte per input byte instead of the input again
-        uint32_t m = 0;
+        for (uint32_t half = 0; half < 2; ++half) {
+            uint4 v[PIECES];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m |= (((flags[i] >> 7) * 0x01020408u) >> 24) << (4 * i);
-        if (at_file_end && base <= len && len - base < BYTES_PER_THREAD && len > start) {
-            m |= 1u << (len - base);   // the assumed newline at position len
-            ++c;
+            for (uint32_t k = 0; k < PIECES; ++k)
+                v[k] = *reinterpret_cast<const uint4 *>(buf + tile0 + k * PIECE_BYTES + (wave * 2 + half) * 1024u + lane * 16u);
+#pragma unroll
+            for (uint32_t k = 0; k < PIECES; ++k) {
+                const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m |= (((zero_bytes(w[i] ^ 0x0A0A0A0Au) >> 7) * 0x01020408u) >> 24) << (4 * i);
+                c += (uint32_t)__popc(m);
+                mask16[(tile0 + k * PIECE_BYTES + (wave * 2 + half) * 1024u + lane * 16u) / 16] = (uint16_t)m;
+            }
         }
-        nl_mask[base / BYTES_PER_THREAD] = m;
+    } else {
+        for (uint32_t pc = 0; pc < PIECES; ++pc) {
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint32_t base = tile0 + pc * PIECE_BYTES + (wave * 2 + h) * 1024u + lane * 16u;
+                uint32_t m = (base < len && base + 16 > start) ? load_nl_mask16(buf, base, start, len) : 0u;
+                if (at_file_end && base <= len && len - base < 16 && len > start) m |= 1u << (len - base);   // the assumed newline at position len
+                c += (uint32_t)__popc(m);
+                mask16[base / 16] = (uint16_t)m;
+            }
+        }
     }
     c = wave_reduce_add(c);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;

@@ -27,6 +27,15 @@ __device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *de
     if (A.dstride) return *reinterpret_cast<const uint4 *>(dense + ((size_t)(off >> 4) * A.dstride + g) * 16);
     return load16_unaligned(A.buf, file_pos + off, A.buf_len);
 }
+// aligned 16 bytes at a (a multiple of 16), zero behind the end of the job buffer
+__device__ __forceinline__ uint4 load16_guarded_sq(const uint8_t *buf, uint32_t a, uint32_t buf_len)
+{
+    if (a + 16 <= buf_len) return *reinterpret_cast<const uint4 *>(buf + a);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t x = 0; x < 16; ++x)
+        if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32_t off, const uint4 &S, const uint4 &Q)
 {
     if (A.dstride) {
@@ -36,11 +45,18 @@ __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32
     }
 }
 
-template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw)
+// STAGED (short records, round 3): the 64 records of a wave are one contiguous span of the file (~8 KB at 36 bases).  The wave
+// fetches that span with coalesced 16-byte loads - eight rows of 1 KB instead of six loads per lane at addresses a whole
+// record apart, which the texture path prices at ~160 cycles each (tools/ubench_loads.hip: unaligned scattered loads cost twice
+// the aligned ones and keep the kernel off the HBM roofline) - parks it in LDS, and every lane reads its own record's chunks
+// back with unaligned 16-byte LDS reads.  Same bytes, same logic behind the loads.  span_cap: bytes of LDS per wave,
+// >= 64 x the job's longest record + 48.
+template <bool BURST, bool STAGED>
+__global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
 {
+    static_assert(!(BURST && STAGED), "the staged form is for short records");
     if (*A.err) return;
-    extern __shared__ __align__(16) uint32_t s_hist[];   // [lds_rows][SR_HSTRIDE], then 64 trash words
+    extern __shared__ __align__(16) uint32_t s_hist[];   // [lds_rows][SR_HSTRIDE], then 64 trash words, then (STAGED) the waves' spans
     __shared__ uint32_t s_occ[256];
     __shared__ uint8_t s_amb[256];
     __shared__ uint32_t s_red[3];
@@ -52,6 +68,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
     const uint32_t last = first + rpw < n ? first + rpw : n;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t hwords = lds_rows * SR_HSTRIDE;
+    uint8_t *const span = reinterpret_cast<uint8_t *>(s_hist + ((hwords + 64 + 3) & ~3u)) + (size_t)(tid >> 6) * span_cap;
+    uint32_t span_lo = 0;   // file offset of span[0] (wave-uniform)
 
     for (uint32_t k = tid; k < hwords; k += SR_THREADS) s_hist[k] = 0;
     s_occ[tid] = 0;
@@ -91,6 +109,38 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
             }
         }
 
+        if constexpr (STAGED) {
+            // the wave's records [s0 of its first lane, end of its last valid lane's qualities) -> LDS, 1 KB per row
+            const unsigned long long vm = __ballot(valid);
+            if (vm) {   // (valid lanes are a prefix of the wave)
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0) & ~15u;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(q0 + L), (int)__builtin_popcountll(vm) - 1);
+                const uint32_t rows = (hi - lo + 1023u) >> 10;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous batch's reads are done
+                for (uint32_t r0 = 0; r0 < rows; r0 += 4) {
+                    uint4 v[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (r0 + k < rows) v[k] = load16_guarded_sq(A.buf, lo + 1024u * (r0 + k) + 16u * lane, A.buf_len);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (r0 + k < rows) *reinterpret_cast<uint4 *>(span + 1024u * (r0 + k) + 16u * lane) = v[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                span_lo = lo;
+            }
+        }
+        // one 16-byte chunk at file offset pos: from the staged span or from the file
+        auto ld16 = [&](uint32_t pos) __attribute__((always_inline)) -> uint4 {
+            if constexpr (STAGED) {
+                const U4u v = *reinterpret_cast<const U4u *>(span + (pos - span_lo));
+                return make_uint4(v.x, v.y, v.z, v.w);
+            } else {
+                return load16_unaligned(A.buf, pos, A.buf_len);
+            }
+        };
+
         // ---- one pass over the 16-byte chunks: everything except the ambiguous positions ----
         uint32_t fl = 0, namb = 0;   // N-transfer test (phyNGSC.cpp:549-571): bit0 some ambiguity code, bit1 a failure
         uint32_t nall = 0, apos0 = 0, apos1 = 0;   // non-ACGT bytes of the record and the positions of the first four
@@ -101,8 +151,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         constexpr uint32_t NBX = BURST ? NB : 1u;
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
         if (!BURST && L) {
-            Sn = load16_unaligned(A.buf, s0, A.buf_len);
-            Qn = load16_unaligned(A.buf, q0, A.buf_len);
+            Sn = ld16(s0);
+            Qn = ld16(q0);
         }
         for (uint32_t grp = 0; __any(16 * NBX * grp < L); ++grp) {
             uint4 Sb[NBX], Qb[NBX];
@@ -126,8 +176,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * grp + 16) {
-                    Sn = load16_unaligned(A.buf, s0 + 16 * grp + 16, A.buf_len);
-                    Qn = load16_unaligned(A.buf, q0 + 16 * grp + 16, A.buf_len);
+                    Sn = ld16(s0 + 16 * grp + 16);
+                    Qn = ld16(q0 + 16 * grp + 16);
                 }
                 if (L > 16 * grp) sq_chunk_keep(A, g, 16 * grp, Sb[0], Qb[0]);   // (the chunk that has arrived, not the one in flight)
             }
@@ -1004,21 +1054,35 @@ static bool sr_burst(const Arena &A)
     return A.qrows - 1 > 16 * NB;   // reads that one trip of NB chunks does not cover anyway
 }
 
-void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
+// The staged form (see k_sq_stats_reg): NGSC_SQ_STAGED=0|1 forces; by default for jobs whose 64-record spans fit 10 KB of LDS
+// per wave (records of up to ~160 bytes: reads of up to ~50 bases), where three workgroups still share a CU.
+static bool sr_staged(const Arena &A, uint32_t max_rec_bytes, uint32_t &span_cap)
+{
+    span_cap = (64u * max_rec_bytes + 48u + 1023u) & ~1023u;
+    static const int forced = getenv("NGSC_SQ_STAGED") ? atoi(getenv("NGSC_SQ_STAGED")) : -1;
+    if (sr_burst(A) || !max_rec_bytes || span_cap > (24u << 10)) return false;
+    if (forced >= 0) return forced != 0;
+    return span_cap <= (10u << 10);
+}
+
+void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes)
 {
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
     if (rows > max_rows) rows = max_rows;
     const uint32_t rpw = sr_records_per_wg(A, max_rec);
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
+    uint32_t span_cap = 0;
+    const bool staged = sr_staged(A, max_rec_bytes, span_cap);
     // at least 24 KB, i.e. at most six workgroups per CU: with the eight that a short-read histogram (7.5 KB) allows, the
     // kernel is 3-4 % SLOWER (0.494 against 0.476 ms; measured with 8 / 16 / 24 KB of padding - the lanes' scattered loads
     // share the CU's 32 KB L1, and four to six workgroups' worth of them fit it better); below four it loses again
     size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
-    if (lds < (24u << 10)) lds = 24u << 10;
-    auto kern = sr_burst(A) ? k_sq_stats_reg<true> : k_sq_stats_reg<false>;
-    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10);
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw);
+    if (staged) lds = ((lds + 15) & ~(size_t)15) + (size_t)(SR_THREADS / 64) * span_cap;
+    else if (lds < (24u << 10)) lds = 24u << 10;
+    auto kern = staged ? k_sq_stats_reg<false, true> : (sr_burst(A) ? k_sq_stats_reg<true, false> : k_sq_stats_reg<false, false>);
+    if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw, span_cap);
 }
 
 static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)

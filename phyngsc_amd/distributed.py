@@ -44,7 +44,11 @@ def write_container(path: str, P: int, fastq_size: int, local: Sequence[LocalRan
         sizes, meta = sizes_local, meta_local
         rank0 = True
     assert len(sizes) == P, f"gathered {len(sizes)} ranks, expected {P}"
-    offsets, cbo, end = api.file_offsets(sizes, api.ranks_per_group(fastq_size, P))
+    # offsets: the library's prefix sum over the deterministic block order (ngsc_rows_to_offsets), the same function the
+    # one-process team uses on the rows its RCCL all-gather delivers
+    row_len = max((len(s) for s in sizes), default=0) + 3
+    offsets, cbo, end = api.rows_to_offsets(api.rows_from_sizes(sizes, meta, row_len), fastq_size)
+    assert (offsets, cbo, end) == api.file_offsets(sizes, api.ranks_per_group(fastq_size, P))
     if rank0:
         # create / truncate before anyone writes
         with open(path, "wb"):

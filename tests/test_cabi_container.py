@@ -19,7 +19,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def test_header_symbols_are_exported():
     with open(os.path.join(ROOT, "include", "ngsc.h")) as f:
         text = f.read()
-    declared = set(re.findall(r"\b(ngsc_[a-z_]+)\s*\(", text))
+    declared = set(re.findall(r"\b(ngsc_[a-z_0-9]+)\s*\(", text))
     assert declared, "no declarations parsed"
     L = _lib.lib()
     for name in sorted(declared):

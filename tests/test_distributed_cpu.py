@@ -73,3 +73,18 @@ def test_rank_partition():
         api.ranks_of_process(6, 4, 0)
     lo, hi = api.job_byte_range(1000_000, 8, 2, 4)
     assert lo == 2 * 125000 and hi == min(1000_000, 4 * 125000 + 500 + (1 << 16))
+
+
+def test_rows_to_offsets_matches_python_order():
+    """ngsc_rows_to_offsets (the prefix sum behind the team's RCCL all-gather) against api.file_offsets, on random block
+    lists and file sizes that give one group, several groups and one rank per group."""
+    import random
+    rng = random.Random(7)
+    for _ in range(200):
+        P = rng.choice([2, 3, 8, 16, 64])
+        fs = rng.choice([1000, 10 << 20, 600 << 20, 5 << 30, 50 << 30])
+        sizes = [[rng.randrange(1, 8 << 20) for _ in range(rng.randrange(0, 6))] for _ in range(P)]
+        meta = [(rng.randrange(0, 50), rng.randrange(-3, 500)) for _ in range(P)]
+        rows = api.rows_from_sizes(sizes, meta, 3 + 6)
+        assert api.sizes_from_rows(rows) == (sizes, meta)
+        assert api.rows_to_offsets(rows, fs) == api.file_offsets(sizes, api.ranks_per_group(fs, P))

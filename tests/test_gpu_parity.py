@@ -487,9 +487,56 @@ def test_cfg5_as_stated_36_300bp(eng):
         assert out == want, P
 
 
+def test_team_in_process_rccl_and_host_exchange(eng):
+    """The single-process multi-GPU host (ngsc_team_*): a team over ONE context has a one-rank RCCL communicator created in
+    this process (ncclCommInitAll) and its all-gather carries the block rows; a team whose contexts share a device cannot
+    have one (RCCL wants a GPU per rank) and says so - the rows then meet in host memory.  Either way every member
+    ends up with the rows the block planner gives for the engine's own result, and the offsets follow from them."""
+    data = fastq_gen.generate(fastq_gen.CFG5, target_bytes=24_000_000)
+    P = 8
+    d_in = torch.from_numpy(data).cuda()
+    res = eng.compress_device(d_in, data.size, P)
+    sizes = [[b.size for b in api.plan_blocks(P, rk.rank, [res.subblocks[rk.first_subblock + k].size for k in range(rk.n_subblocks)])]
+             for rk in res.ranks]
+    meta = [(rk.n_subblocks, rk.overlap_used) for rk in res.ranks]
+    want_rows = api.rows_from_sizes(sizes, meta, 8)
+    ref_out = res.out[:res.total_bytes].cpu().numpy().copy()
+    # one member: RCCL with one rank
+    t1 = api.Team([eng])
+    assert t1.rccl_ranks == 1, t1.describe
+    assert "ncclCommInitAll" in t1.describe
+    out1 = torch.empty_like(res.out)
+    rows, ms = t1.compress([(d_in, 0, 0, P, out1)], data.size, P, 8)
+    assert (rows == want_rows).all() and len(ms) == 1
+    assert (out1[:res.total_bytes].cpu().numpy() == ref_out).all()
+    send = np.arange(5, dtype=np.uint64).reshape(1, 5) + 7
+    assert (t1.allgather_u64(send) == send).all()
+    t1.close()
+    # two members on the same device: no RCCL, host exchange, same rows; each member compresses its half of the ranks
+    e2 = api.Engine(0)
+    t2 = api.Team([eng, e2])
+    assert t2.rccl_ranks == 0 and "share a device" in t2.describe
+    lo0, hi0 = api.job_byte_range(data.size, P, 0, 4)
+    lo1, hi1 = api.job_byte_range(data.size, P, 4, 8)
+    lo1 &= ~15
+    a_in, b_in = torch.from_numpy(data[lo0:hi0].copy()).cuda(), torch.from_numpy(data[lo1:hi1].copy()).cuda()
+    a_out, b_out = torch.empty_like(res.out), torch.empty_like(res.out)
+    rows2, ms2 = t2.compress([(a_in, lo0, 0, 4, a_out), (b_in, lo1, 4, 8, b_out)], data.size, P, 8)
+    assert (rows2 == want_rows).all() and len(ms2) == 2
+    send = np.arange(6, dtype=np.uint64).reshape(2, 3)
+    got = t2.allgather_u64(send)
+    assert (got[0] == send.reshape(-1)).all() and (got[1] == send.reshape(-1)).all()
+    table, cbo, end = api.rows_to_offsets(rows2, data.size)
+    assert (table, cbo, end) == api.file_offsets(sizes, api.ranks_per_group(data.size, P))
+    with pytest.raises(api.NgscError):      # row too short for the rank's blocks
+        t2.compress([(a_in, lo0, 0, 4, a_out), (b_in, lo1, 4, 8, b_out)], data.size, P, 4 if max(len(s) for s in sizes) > 1 else 3)
+    t2.close()
+
+
 def test_bench_multi_gpu_modes_start_without_a_launcher():
-    """`python bench.py --gpus N` needs no external launcher: one process, N contexts on N host threads (here in
-    rehearsal form when the box has a single GPU: all contexts on device 0)."""
+    """`python bench.py --gpus N` needs no external launcher: one process, a team of N contexts on N host threads inside the
+    library (here in rehearsal form when the box has a single GPU: all contexts on device 0, where RCCL cannot give every
+    rank a GPU and the line must say rccl_ranks 0)."""
     import sys
     env = dict(os.environ)
     if torch.cuda.device_count() < 2:
@@ -500,7 +547,11 @@ def test_bench_multi_gpu_modes_start_without_a_launcher():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["virtual_ranks"] == 16
-    assert "2 contexts" in line["config"]["launch"]
+    assert "team of 2" in line["config"]["launch"]
+    if torch.cuda.device_count() < 2:
+        assert line["config"]["rccl_ranks"] == 0 and "share a device" in line["config"]["collective"]
+    else:
+        assert line["config"]["rccl_ranks"] == 2, line["config"]["collective"]
 
 
 @pytest.mark.parametrize("ngsc_path", REVERSIBLE, ids=[os.path.basename(p) for p in REVERSIBLE])
