@@ -371,7 +371,24 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
     if (!w->rc && (hipStreamCreateWithFlags(&in_stream, hipStreamNonBlocking) != hipSuccess ||
                    hipStreamCreateWithFlags(&out_stream, hipStreamNonBlocking) != hipSuccess))
         w->rc = NGSC_ERR_HIP;
+    // (test hook: NGSC_TEST_FAIL_ALLOC=<device index> makes that worker's buffer allocation fail)
+    if (const char *fa = getenv("NGSC_TEST_FAIL_ALLOC"))
+        if (atoi(fa) == (int)w->index && !w->rc) w->rc = NGSC_ERR_NOMEM;
     const double t_alloc = now_s() - t_alloc0;
+    if (w->rc) {
+        // no reader or writer thread will ever run: nobody would end the wait below, and the other workers would wait for
+        // this worker's groups in begin_group() - tell them, release what was allocated, and return the error
+        sink->abort();
+        for (int i = 0; i < 2; ++i) {
+            if (d_in[i]) (void)hipFree(d_in[i]);
+            if (h_in[i]) (void)hipHostFree(h_in[i]);
+            if (d_out[i]) (void)hipFree(d_out[i]);
+            if (h_out[i]) (void)hipHostFree(h_out[i]);
+        }
+        if (in_stream) (void)hipStreamDestroy(in_stream);
+        if (out_stream) (void)hipStreamDestroy(out_stream);
+        return;
+    }
     Pipe pipe;
     std::vector<JobResult> results(jobs.size());
     std::thread reader, writer;

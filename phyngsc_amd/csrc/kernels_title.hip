@@ -176,6 +176,12 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
             for (uint32_t k = 0; k < T.len[f]; ++k) al[4 * wcur + k] = T.title[T.start[f] + k];
             wcur += 2 * ((T.len[f] + 7u) / 8u);
         }
+        // record 0's own separator / digit masks, one bit per title byte (the first 128): what a dword equal to record 0's
+        // contributes to another record's masks (t_load_title)
+        for (uint32_t p = 0; p < tlen && p < 128; ++p) {
+            if (is_sep(T.title[p])) T.sepm[p >> 5] |= 1u << (p & 31);
+            if (T.title[p] >= '0' && T.title[p] <= '9') T.digm[p >> 5] |= 1u << (p & 31);
+        }
         T.nf0 = nf0;
         T.ncand = ncand;
         A.sb[s].nf = nf0;
@@ -604,9 +610,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
 // Title of one record as 16 * W dwords (bytes past the title are other lines' bytes: every use masks by length),
 // written to the lane's LDS column, plus its separator / digit masks.
 // r0w: record 0's title as dwords (zero padded); diffmask: bit p set where byte p differs from record 0's byte p
+// sep0 / dig0: record 0's own separator / digit masks as 32-bit halves (Rec0Tab::sepm / digm).  A dword that equals record
+// 0's dword in every lane of the wave - the constant stretches of a title, seven of cfg2's thirteen dwords - is not
+// classified at all: its mask bits are record 0's (the vote costs two instructions, the classification and the
+// difference bits forty), and dwords behind the wave's longest title are skipped.
 template <uint32_t W>
 __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
-                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W], const uint32_t *r0w, uint64_t (&diffmask)[W])
+                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W], const uint32_t *r0w, uint64_t (&diffmask)[W],
+                                             const uint32_t *sep0, const uint32_t *dig0)
 {
     uint32_t sp32[2 * W], dg32[2 * W], df32[2 * W];
 #pragma unroll
@@ -619,13 +630,20 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t cls = t_classify4(w[j]);
-                const uint32_t sp = t_movemask((((cls & 0x0F0F0F0Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u);
-                const uint32_t dg = t_movemask((cls >> 4) & 0x01010101u);
-                const uint32_t sh = 4 * ((4 * m + j) & 7);
-                sp32[m >> 1] |= sp << sh;
-                dg32[m >> 1] |= dg << sh;
-                df32[m >> 1] |= t_movemask(t_nonzero01(w[j] ^ r0w[4 * m + j])) << sh;
+                const uint32_t d = 4 * m + j, sh = 4 * (d & 7);
+                if (!__any(4 * d < tlen)) continue;
+                const uint32_t x = w[j] ^ r0w[d];
+                if (__any(x != 0 && 4 * d < tlen)) {
+                    const uint32_t cls = t_classify4(w[j]);
+                    const uint32_t sp = t_movemask((((cls & 0x0F0F0F0Fu) + 0x7F7F7F7Fu) >> 7) & 0x01010101u);
+                    const uint32_t dg = t_movemask((cls >> 4) & 0x01010101u);
+                    sp32[m >> 1] |= sp << sh;
+                    dg32[m >> 1] |= dg << sh;
+                    df32[m >> 1] |= t_movemask(t_nonzero01(x)) << sh;
+                } else {
+                    sp32[m >> 1] |= sep0[m >> 1] & (0xFu << sh);
+                    dg32[m >> 1] |= dig0[m >> 1] & (0xFu << sh);
+                }
             }
         }
         s_w[4 * m + 0][tid] = q.x;
@@ -692,7 +710,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     const uint32_t tlen = valid ? te - ls + 1 : 0;            // title bytes including the closing newline
 
     uint64_t sepmask[W], digmask[W], diffmask[W];
-    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, reinterpret_cast<const uint32_t *>(s_r0.title), diffmask);
+    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, reinterpret_cast<const uint32_t *>(s_r0.title), diffmask, s_r0.sepm, s_r0.digm);
     uint32_t nsep = 0;
 #pragma unroll
     for (uint32_t k = 0; k < W; ++k) {
@@ -703,8 +721,39 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
 
     uint32_t pos = 0;
     fmask_t nummask = 0;
+    // (round 3) Fields that EVERY lane of the wave holds exactly as record 0 holds them - same place, same bytes, same
+    // separator behind them: the constant fields of a title, as long as no field in front of them has changed its length -
+    // are recognised from the title-wide difference mask and cost ~15 instructions instead of ~100: nothing about them can
+    // change a statistic except through record 0's own lane (whose wave takes the full path) and the zero value delta.
+    bool pos_aligned = true;                                  // (wave-uniform) every lane's field starts where record 0's does
+    const bool wave_has_rec0 = __any(owned && i == 0);
     for (uint32_t f = 0; f < nf0; ++f) {
         const uint32_t len0 = s_r0.len[f], kk = s_r0.kmap[f], wo = s_r0.woff[f];
+        const uint32_t pos0 = s_r0.start[f];
+        if (pos_aligned && !wave_has_rec0 && pos0 + len0 < 64 * W && len0 < 64) {
+            const uint64_t fdw = t_window<W>(diffmask, pos0);
+            if (!__any(valid && (fdw & t_lowbits(len0 + 1)) != 0)) {
+                if (kk != 0xff) {   // record 0's field is numeric, so it is in every lane: value = record 0's
+                    nummask |= (fmask_t)1 << f;
+                    if (kk < NUM_CAND_CAP) {
+                        const uint32_t v0 = s_r0.val0[f];
+                        if (owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v0;
+                        if (lane == 63) s_last[kk][tid >> 6] = v0;
+                        if (lane == 0) s_first[kk][tid >> 6] = v0;
+                        const bool q = owned && i >= 1 && lane >= 1;   // the delta to the previous record is 0
+                        if (__any(q)) {
+                            if (q) {
+                                const uint32_t bd = bias(0);
+                                if (bd > s_stat[f * SW + 8]) atomicMax(&s_stat[f * SW + 8], bd);
+                                if (~bd > s_stat[f * SW + 9]) atomicMax(&s_stat[f * SW + 9], ~bd);
+                            }
+                        }
+                    }
+                }
+                pos += len0 + 1;
+                continue;
+            }
+        }
         const uint32_t len = t_next_set<W>(sepmask, pos);
         const uint32_t minlen = len < len0 ? len : len0;
 
@@ -712,7 +761,6 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         // first one whose length varies) is compared through the title-wide difference mask: its bits [pos, pos + len)
         // are the field's differing bytes.  No funnel-shifted LDS reads, no eight-byte steps.
         uint32_t w0 = 0, w1 = 0, diff = 0, c8 = 0;
-        const uint32_t pos0 = s_r0.start[f];
         const bool aligned = len0 <= 64 && !__any(valid && (pos != pos0 || len > 64));
         if (aligned) {
             const uint64_t fd = t_window<W>(diffmask, pos0);
@@ -813,6 +861,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             }
         }
         pos += len + 1;
+        pos_aligned = pos_aligned && !__any(valid && len != len0);
     }
     if (lane == 63) s_nm_last[tid >> 6] = nummask;
     if (lane == 0) s_nm_first[tid >> 6] = (owned && i >= 1) ? nummask : (fmask_t)0;

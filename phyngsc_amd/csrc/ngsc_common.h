@@ -250,6 +250,7 @@ struct Rec0Tab {
     uint8_t ovf0[MAX_FIELDS];                     // ... and whether it exceeds INT32_MAX
     uint16_t woff[MAX_FIELDS];                    // dword offset of the field inside al
     uint32_t al[(REC0_TITLE_CAP + 8 * MAX_FIELDS) / 4];  // field-aligned copy, each field zero padded to 8 bytes
+    uint32_t sepm[4], digm[4];                    // separator / digit bit per byte of the first 128 title bytes
 };
 static_assert(sizeof(Rec0Tab) % 4 == 0, "Rec0Tab is copied word-wise");
 

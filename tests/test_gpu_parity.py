@@ -422,6 +422,26 @@ def test_multi_context_file_driver(tmp_path, monkeypatch):
                           capture_output=True).returncode == 1
 
 
+@pytest.mark.timeout(300)
+def test_file_driver_worker_allocation_failure_is_an_error_not_a_hang(tmp_path, monkeypatch):
+    """A worker whose staging buffers cannot be allocated (forced here) must end the whole job with an error code: its
+    reader / writer threads never start, so nothing would end its final wait, and the other workers would wait for its
+    groups' turn for ever."""
+    data = fastq_gen.generate(fastq_gen.CFG2, target_bytes=12_000_000)
+    inp = tmp_path / "in.fastq"
+    data.tofile(inp)
+    e0, e1 = api.Engine(0), api.Engine(0)
+    monkeypatch.setenv("NGSC_TEST_FAIL_ALLOC", "0")   # (a file of this size is one group of the block order: worker 0's)
+    for engines in ([e0], [e0, e1]):
+        with pytest.raises(api.NgscError) as ei:
+            api.compress_file_multi(engines, str(inp), str(tmp_path / "x.ngsc"), 8)
+        assert ei.value.code in (-6, -11)
+    monkeypatch.delenv("NGSC_TEST_FAIL_ALLOC")
+    api.compress_file_multi([e0, e1], str(inp), str(tmp_path / "ok.ngsc"), 8)
+    want, _ = orc.compress_file(data, 8, threads=8)
+    assert (tmp_path / "ok.ngsc").read_bytes() == want
+
+
 def test_file_driver_parts_groups_and_streamed_writes(tmp_path, monkeypatch):
     """The file driver beyond one group (ngsc.h: NGSC_ORDER_GROUP_BYTES): (a) a rank larger than a job is walked in parts
     (ngsc_compress_rank_part) - inside a multi-rank group its stream is collected, (b) as a group of its own (region above
