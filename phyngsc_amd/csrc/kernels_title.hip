@@ -204,14 +204,14 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
     if (blockIdx.x * OWNED >= n) return;
     const int tid = threadIdx.x;
 
-    __shared__ uint32_t s_stat[MAX_FIELDS * 24];
+    __shared__ uint32_t s_stat[MAX_FIELDS * FSTAT_WORDS];
     __shared__ uint32_t s_val[NUM_CAND_CAP][TT_THREADS];
     __shared__ fmask_t s_nummask[TT_THREADS];
     __shared__ Rec0Tab s_r0;
 
     for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
         reinterpret_cast<uint32_t *>(&s_r0)[k] = reinterpret_cast<const uint32_t *>(A.rec0 + s)[k];
-    for (uint32_t k = tid; k < MAX_FIELDS * 24; k += TT_THREADS) s_stat[k] = 0;
+    for (uint32_t k = tid; k < MAX_FIELDS * FSTAT_WORDS; k += TT_THREADS) s_stat[k] = 0;
     __syncthreads();
     const uint32_t nf0 = s_r0.nf0;
 
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
         stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | (nd << 3);
         v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num (utils.h:117-125)
         if (__any(nd)) {
-            if (nd && owned && k < 256) t_lds_or(&s_stat[f * 24 + 10 + (k >> 5)], 1u << (k & 31));
+            if (nd && owned && k < MAX_TEXT_LEN0) t_lds_or(&s_stat[f * FSTAT_WORDS + 10 + (k >> 5)], 1u << (k & 31));
         }
         k += body;
         if (__any(sepb)) {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
                     // thread contributes, so only differing fields (and record 0 itself) touch the counters.
                     const bool same = len == len0 && !(stf & 8);
                     if (owned && (!same || i == 0)) {
-                        uint32_t *st = s_stat + f * 24;
+                        uint32_t *st = s_stat + f * FSTAT_WORDS;
                         const uint32_t a0 = st[0], a1 = st[1], a2 = st[2], a3 = st[3], a4 = st[4], a5 = st[5], a6 = st[6],
                                        a7 = st[7];
                         const uint32_t bv = bias((int32_t)v);
@@ -288,18 +288,18 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
             if ((both >> ff) & 1) {
                 const int32_t d = (int32_t)(s_val[kk][tid] - s_val[kk][tid - 1]);  // tasks.cpp:149-166
                 const uint32_t bd = bias(d);
-                if (bd > s_stat[ff * 24 + 8]) atomicMax(&s_stat[ff * 24 + 8], bd);
-                if (~bd > s_stat[ff * 24 + 9]) atomicMax(&s_stat[ff * 24 + 9], ~bd);
+                if (bd > s_stat[ff * FSTAT_WORDS + 8]) atomicMax(&s_stat[ff * FSTAT_WORDS + 8], bd);
+                if (~bd > s_stat[ff * FSTAT_WORDS + 9]) atomicMax(&s_stat[ff * FSTAT_WORDS + 9], ~bd);
             }
         }
     }
     __syncthreads();
     uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
-    for (uint32_t kx = tid; kx < nf0 * 24; kx += TT_THREADS) {
+    for (uint32_t kx = tid; kx < nf0 * FSTAT_WORDS; kx += TT_THREADS) {
         uint32_t x = s_stat[kx];
         if (!x) continue;
-        uint32_t w = kx % 24;
-        if (w >= 10 && w < 18) atomicOr(gst + kx, x);
+        uint32_t w = kx % FSTAT_WORDS;
+        if (w >= 10 && w < 26) atomicOr(gst + kx, x);
         else if (w < 10) atomicMax(gst + kx, x);
     }
 }
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     for (uint32_t kx = tid; kx < nf0 * SW; kx += TT_THREADS) {
         uint32_t x = s_stat[kx];
         if (!x) continue;
-        const uint32_t w = kx % SW, gx = kx / SW * 24 + w;   // (FieldStat is 24 words in global memory)
+        const uint32_t w = kx % SW, gx = kx / SW * FSTAT_WORDS + w;   // (a FieldStat in global memory has all its words)
         if (w >= 10) atomicOr(gst + gx, x);
         else atomicMax(gst + gx, x);
     }

@@ -31,7 +31,7 @@ constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
 // ---- engine limits (inputs beyond them get NGSC_ERR_UNSUPPORTED, never a wrong stream) ------------
 constexpr uint32_t MAX_FIELDS = 64;         // separators per title (one bit each in the field masks, fmask_t)
 typedef uint64_t fmask_t;                   // a bit per title field
-constexpr uint32_t MAX_TEXT_LEN0 = 256;     // record-0 length of a non-constant text field (Hamming mask bits)
+constexpr uint32_t MAX_TEXT_LEN0 = 512;     // record-0 length of a non-constant text field (Hamming mask bits): a whole first title (REC0_TITLE_CAP)
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
 constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
 constexpr uint32_t REC0_TITLE_CAP = 512;      // longest first-record title the title kernels keep in LDS
@@ -187,11 +187,12 @@ struct FieldStat {
     uint32_t ovf;           // some numeric value >= 2^31
     uint32_t max_v, inv_min_v;  // biased int32
     uint32_t max_d, inv_min_d;  // biased int32 (deltas between consecutive records)
-    uint32_t not_ham[8];    // bit p set: some record differs from record 0 at position p (< 256)
-    uint32_t no_delta;      // tiled path: deltas of this field were not tracked (too many numeric candidates)
+    uint32_t not_ham[16];   // bit p set: some record differs from record 0 at position p (< 512 = REC0_TITLE_CAP)
+    uint32_t no_delta;      // deltas of this field were not tracked (too many numeric candidates)
     uint32_t pad[5];
 };
-static_assert(sizeof(FieldStat) == 96, "FieldStat layout");
+constexpr uint32_t FSTAT_WORDS = 32;   // words per FieldStat: scalars 0..9, Hamming words 10..25, no_delta 26
+static_assert(sizeof(FieldStat) == 4 * FSTAT_WORDS, "FieldStat layout");
 
 // Finalised field description (tasks.cpp:196-222 + the header decisions of tasks.cpp:304-390)
 struct FieldDesc {
@@ -208,12 +209,12 @@ struct FieldDesc {
     uint32_t n_sym;         // its symbol count (diff)
     int32_t base;           // min_v or min_d
     uint32_t slot;          // text statistics / code slot, 0xffffffff if none
-    uint32_t ham[8];        // Hamming mask bits (1 = every record equals record 0 at that position)
+    uint32_t ham[16];       // Hamming mask bits (1 = every record equals record 0 at that position)
     uint32_t kf;            // index among the sub-block's non-constant fields
     uint32_t cand;          // numeric candidate index of the field (Rec0Tab::kmap), 0xff if record 0's field is not numeric
     uint32_t pad[3];
 };
-static_assert(sizeof(FieldDesc) == 128, "FieldDesc layout");
+static_assert(sizeof(FieldDesc) == 160, "FieldDesc layout");
 
 struct SbState {        // per sub-block scalars
     uint32_t rec_lo, n_rec, rank, nf;
@@ -396,7 +397,7 @@ NGSC_HD int finalize_field(const FieldStat &st, uint32_t start0, uint32_t len0, 
     d.min_v = d.max_v = 0;
     d.min_d = 1;   // Field() defaults, structures.h:103-106
     d.max_d = -1;
-    for (int i = 0; i < 8; ++i) d.ham[i] = ~st.not_ham[i];
+    for (int i = 0; i < 16; ++i) d.ham[i] = ~st.not_ham[i];
     if (!st.not_const) { d.kind = KIND_CONST; return OK; }
     if (!st.not_num) {
         if (st.ovf) return ERR_RANGE;

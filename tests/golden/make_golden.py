@@ -217,6 +217,16 @@ def small_cases():
                                 for i in range(1500)), [2])
     add("digit_first_base", "".join(rec(f"@d.{i}", ("2" if i % 700 == 0 else "A") + rand_seq(rng4, 35), rand_qual(rng4, 36))
                                     for i in range(1400)), [2])    # base space whose first read starts with a digit: flags only
+    # round 3: titles on what were engine limits (a varying text field whose FIRST record is longer than 256 bytes; more than 64
+    # separators) - both inside the reference's 500-byte record domain
+    rng5 = random.Random(20261007)
+
+    def long_text(i):
+        n = 300 if i == 0 else rng5.randint(180, 320)
+        return "".join(rng5.choice("ACGTacgt-_") if k % 7 else rng5.choice("xyz") for k in range(n)).replace("-", "q").replace("_", "w")
+    add("title_text_first_300", "".join(rec(f"@L{i % 3} {long_text(i)} {i}", rand_seq(rng5, 40), rand_qual(rng5, 40)) for i in range(420)), [2])
+    add("title_fields_80", "".join(rec(f"@F{i}:" + ":".join(str((i * (k + 1) + k) % (3 + k % 7)) if k % 5 else "c" for k in range(79)),
+                                       rand_seq(rng5, 36), rand_qual(rng5, 36)) for i in range(900)), [2, 3])
     return cases
 
 

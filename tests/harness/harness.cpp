@@ -88,7 +88,7 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
                 uint32_t m = std::min(len, len0);
                 bool diff = false;
                 for (uint32_t p = 0; p < m; ++p)
-                    if (buf[pc + p] != buf[p0 + p]) { diff = true; if (p < 256) s.not_ham[p >> 5] |= 1u << (p & 31); }
+                    if (buf[pc + p] != buf[p0 + p]) { diff = true; if (p < 512) s.not_ham[p >> 5] |= 1u << (p & 31); }
                 if (len != len0) { s.not_len_const = 1; s.not_const = 1; }
                 else if (diff) s.not_const = 1;
                 if (!isnum) s.not_num = 1;
