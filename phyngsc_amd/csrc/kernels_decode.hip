@@ -207,8 +207,28 @@ struct DecSub {
     uint64_t dna_bitpos;        // where the DNA payload starts in the sub-block (plain DNA is decoded by the assembly kernel)
     uint64_t text_bytes;
     uint64_t t_head, t_qual, t_dna;   // wall_clock64 ticks (100 MHz) of the three phases, for NGSC_VERBOSE
+    // titles are rendered by the assembly kernel, all threads at once, from what the serial walk over the title body left:
+    uint32_t nf, nvw;           // fields; value words per record
+    uint64_t af_off;            // AField[nf] at pool + af_off
+    uint64_t tchar_off;         // decoded characters of the varying text fields, in the text area
     uint8_t dsym[256];
 };
+
+// One title field as the renderer needs it.  kind 0: constant (len0 bytes at pool + data_off); 1: numeric, value word vidx of the
+// record; 2: text, words vidx (offset of its characters in the character area) and vidx + 1 (length)
+struct AField { uint32_t kind, sep, len0, vidx; uint64_t data_off; };
+
+// A varying field as the serial walk over the title body needs it (LDS)
+struct VField {
+    uint32_t f, kind, vidx, delta, has_g, bits_val, bits_num, bits_len, is_len_const, len0, min_len, max_len;
+    int32_t min_v, min_d;
+};
+
+__device__ __forceinline__ uint32_t dec_ndigits(uint32_t v)
+{
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) +
+           (v >= 100000000u) + (v >= 1000000000u);
+}
 
 // decimal digits of v straight into dst (no local array: a lone lane's scratch memory costs a memory round trip per byte)
 __device__ __forceinline__ uint32_t dec_put_decimal(uint8_t *dst, uint32_t v)
@@ -257,9 +277,9 @@ constexpr uint32_t DEC_OUT = 6144;       // symbols per round at most
 
 struct DecCtl {   // lane 0 -> wave
     int32_t err;
-    uint32_t n, max_q, Kq, q_lds, nqual;
+    uint32_t n, max_q, Kq, q_lds, nqual, nf, lt_bits;
     uint64_t pos;            // bit position behind what lane 0 has consumed
-    uint64_t qual_total, text;
+    uint64_t qual_total, text, qual_total_bases;
     const uint16_t *qtab;    // global table when it does not fit LDS
     const DTree *qt;
     uint32_t wi, ko, i, done;
@@ -391,34 +411,43 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
     }
 }
 
-// Lane 0: info header, title header and body, quality alphabet and trees.  Returns an error code (0: go on).
-__device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *F, uint8_t *qsym, uint16_t *s_qtab, uint32_t lds_entries,
-                        uint32_t rec_cap, DecCtl &C, uint16_t *stack)
+// Lane 0: the info header (phyNGSC.cpp:719-742).  The length table behind it is read by the whole wave (fixed-width entries).
+__device__ int dec_info(BitIn &r, DecScratch &D, DecSub &O, uint32_t rec_cap, DecCtl &C)
 {
-    // ---- info header phyNGSC.cpp:719-742 ----
     const uint32_t n = r.u32(), max_q = r.u32();
     (void)r.u32();
     const uint32_t nsym = r.u8();
     (void)r.u8();
     const uint32_t nqual = r.u8(), flags = r.u32();
     if (r.bad || n == 0 || n > rec_cap || !nsym || !nqual || max_q > (1u << 24)) return ERR_FORMAT;
-    uint64_t qual_total = 0;
     if (flags & F_USE_DELTA) return ERR_COLORSPACE;   // colour space is stored lossily (phyNGSC.cpp:531): nothing to give back
     O.n_rec = n; O.max_q = max_q; O.flags = flags; O.nsym = nsym; O.plain = (flags & F_DNA_PLAIN) ? 1u : 0u;
-    {
-        const uint32_t b = bit_length(max_q);
-        uint64_t tot = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t L = r.bits(b > 32 ? 32 : b);
-            D.qlen[i] = L;
-            tot += L;
-            if (L > max_q) r.bad = 1;
-        }
-        r.align();
-        if (r.bad || 2 * tot > D.tcap) return r.bad ? ERR_FORMAT : ERR_CAPACITY;
-        qual_total = tot;
-    }
+    const uint32_t b = bit_length(max_q);
+    C.n = n; C.max_q = max_q; C.nqual = nqual; C.lt_bits = b > 32 ? 32 : b; C.pos = r.pos;
+    if (r.pos + (uint64_t)n * C.lt_bits > r.nbits) return ERR_FORMAT;
+    (void)D;
+    return OK;
+}
 
+// w <= 32 bits at bit position bitpos of the stream (any lane, any position)
+__device__ __forceinline__ uint32_t dec_bits_at(const uint8_t *p, uint64_t nbytes, uint64_t bitpos, uint32_t w)
+{
+    if (!w) return 0;
+    const uint64_t byte = bitpos >> 3;
+    uint64_t x = 0;
+    if (byte + 8 <= nbytes) {
+        const U2u v = *reinterpret_cast<const U2u *>(p + byte);
+        x = ((uint64_t)__builtin_bswap32(v.x) << 32) | __builtin_bswap32(v.y);
+    } else {
+        for (uint32_t k = 0; k < 8; ++k) x = (x << 8) | (byte + k < nbytes ? p[byte + k] : 0u);
+    }
+    return (uint32_t)((x << (bitpos & 7)) >> (64 - w));
+}
+
+// Lane 0: title header.  Returns an error code (0: go on).
+__device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *F, DecCtl &C, uint16_t *stack)
+{
+    const uint32_t n = C.n;
     // ---- title header (cf. FetchTitleHeader tasks.cpp:625-735; value-coding trees as the encoder stores them, Q2b) ----
     const uint32_t nf = r.u32();
     if (r.bad || nf == 0 || nf > DEC_MAX_FIELDS) return r.bad ? ERR_FORMAT : ERR_UNSUPPORTED;
@@ -477,62 +506,20 @@ __device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *
     }
     if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
 
-    // ---- title body (cf. FetchTitleBody tasks.cpp:738-954): groups of 32 records, byte aligned ----
-    {
-        uint64_t tn = 0;
-        for (uint32_t g0 = 0; g0 < n && !r.bad; g0 += GROUP) {
-            const uint32_t g1 = g0 + GROUP < n ? g0 + GROUP : n;
-            for (uint32_t f = 0; f < nf; ++f)
-                if (!F[f].is_const) { F[f].gflag = (uint8_t)r.bit(); F[f].prev = 0; }
-            for (uint32_t i = g0; i < g1 && !r.bad; ++i) {
-                D.toff[i] = (uint32_t)tn;
-                for (uint32_t f = 0; f < nf; ++f) {
-                    DField &fd = F[f];
-                    if (tn + fd.max_len + fd.len0 + 16 > D.tcap) { r.bad = 3; break; }
-                    if (fd.is_const) {
-                        for (uint32_t j = 0; j < fd.len0; ++j) D.titles[tn + j] = fd.data0[j];
-                        tn += fd.len0;
-                    } else if (fd.is_num) {
-                        int32_t v;
-                        if (i == g0) v = fd.min_v + (int32_t)r.bits(fd.bits_val > 32 ? 32 : fd.bits_val);
-                        else if (fd.gflag) v = fd.delta_coding ? fd.prev + fd.min_d : fd.prev;
-                        else {
-                            const int32_t x = fd.has_g ? (int32_t)tree_get(fd.g, r) : (int32_t)r.bits(fd.bits_num > 32 ? 32 : fd.bits_num);
-                            v = fd.delta_coding ? fd.prev + fd.min_d + x : fd.min_v + x;
-                        }
-                        fd.prev = v;
-                        tn += dec_put_decimal(D.titles + tn, (uint32_t)v);
-                    } else if (i != g0 && fd.gflag) {
-                        for (uint32_t j = 0; j < fd.gval_len; ++j) D.titles[tn + j] = fd.gval[j];
-                        tn += fd.gval_len;
-                    } else {
-                        const uint32_t L = fd.is_len_const ? fd.len0 : fd.min_len + r.bits(fd.bits_len > 32 ? 32 : fd.bits_len);
-                        if (L > fd.max_len) { r.bad = 1; break; }
-                        for (uint32_t j = 0; j < L; ++j) {
-                            uint8_t c;
-                            if (j < fd.len0 && fd.ham[j]) c = fd.data0[j];
-                            else {
-                                const DTree &t = fd.l[j < MAX_STAT_LEN ? j : MAX_STAT_LEN];
-                                if (!t.n) { r.bad = 1; break; }
-                                c = (uint8_t)tree_get(t, r);
-                            }
-                            D.titles[tn + j] = c;
-                            if (i == g0) fd.gval[j] = c;
-                        }
-                        if (i == g0) fd.gval_len = L;
-                        tn += L;
-                    }
-                    D.titles[tn++] = fd.sep;
-                }
-            }
-            r.align();
-        }
-        D.toff[n] = (uint32_t)tn;
-    }
-    if (r.bad) return r.bad == 3 ? ERR_CAPACITY : ERR_FORMAT;
+    // (the title body is walked by the whole wave, scalarised: dec_title_body_wave)
+    C.pos = r.pos; C.nf = nf;
+    (void)D; (void)O;
+    return OK;
+}
 
+// Lane 0, behind the title body: quality alphabet and trees.
+__device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qsym, uint16_t *s_qtab, uint32_t lds_entries, DecCtl &C, uint16_t *stack)
+{
+    const uint32_t n = C.n, max_q = C.max_q, nqual = C.nqual;
+    const uint64_t qual_total = C.qual_total;
+    (void)n;
     // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees; the codes are decoded by the wave ----
-    const uint64_t text = D.toff[n];
+    const uint64_t text = C.text;   // bytes of the text area the value table and the text fields' characters take
     const uint64_t q_at = (text + 15) & ~15ull, s_at = q_at + ((qual_total + 15) & ~15ull);
     if (s_at + qual_total > D.tcap) return ERR_CAPACITY;
     D.lay[0] = q_at; D.lay[1] = s_at;
@@ -553,12 +540,159 @@ __device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *
     }
     r.align();
     if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
-    C.n = n; C.max_q = max_q; C.Kq = Kq; C.q_lds = q_lds ? 1u : 0u; C.nqual = nqual; C.qtab = qtab; C.qt = qt;
-    C.pos = r.pos; C.qual_total = qual_total; C.text = text;
+    C.Kq = Kq; C.q_lds = q_lds ? 1u : 0u; C.qtab = qtab; C.qt = qt;
+    C.pos = r.pos;
     return OK;
 }
 
-// One wave per sub-block: lane 0 walks the header and the titles, the wave decodes the two symbol streams.
+
+// ---- title body (cf. FetchTitleBody tasks.cpp:738-954): groups of 32 records, byte aligned -----------------------------------
+// Round 2 had lane 0 write every title byte by byte (constant fields copied, numbers printed in decimal: ~7 us per record,
+// more than half of a short-read sub-block's decode time).  Here the serial part is only what IS serial: the walk over the
+// bit string, which leaves one value word per varying numeric field and record (text fields: offset and length of their
+// decoded characters) - a few dozen scalar instructions per record - and the assembly kernel renders the titles from those
+// words with all its threads.  Every lane runs the walk on the same values (readfirstlane on what comes from memory), so
+// it compiles to scalar code as in dec_symbols_wave; the bit string comes through the same LDS staging.
+constexpr uint32_t DEC_TPTR_FIELDS = 4, DEC_TPTR_POS = 32;   // text-field table pointers cached in LDS: fields x positions
+
+__device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const VField *VF, uint32_t nvf, uint32_t nvw,
+                                                    const DField *F, uint32_t *vtab, uint8_t *tchars, uint64_t tchar_cap, uint32_t *s_in,
+                                                    int32_t *s_prev, uint32_t *s_gv, const uint16_t *const *s_tptr)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);
+    const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
+    auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    const uint64_t pos0 = ((uint64_t)U((uint32_t)(C.pos >> 32)) << 32) | U((uint32_t)C.pos);
+    const uint32_t n = U(C.n);
+    nvf = U(nvf); nvw = U(nvw);
+    uint64_t win = 0, tused = 0;
+    uint32_t have = 0, wi = (uint32_t)(pos0 >> 5), base = wi, bad = 0;
+    auto stage = [&]() {
+        base = wi;
+        __syncthreads();
+        for (uint32_t t = lane; t < DEC_IN_DW + 4; t += 64) s_in[t] = base + t < ndw ? __builtin_bswap32(p32[base + t]) : 0u;
+        __syncthreads();
+    };
+    auto refill = [&]() {
+        if (wi - base >= DEC_IN_DW + 2) stage();
+        win |= (uint64_t)U(s_in[wi - base]) << (32 - have);
+        have += 32;
+        ++wi;
+    };
+    auto get = [&](uint32_t nb) -> uint32_t {   // nb <= 32; more than 32 bits are in the window between calls
+        if (!nb) return 0u;
+        const uint32_t v = (uint32_t)(win >> (64 - nb));
+        win <<= nb;
+        have -= nb;
+        if (have <= 32) refill();
+        return v;
+    };
+    stage();
+    {
+        const uint32_t skip0 = (uint32_t)(pos0 & 31);
+        win = (uint64_t)U(s_in[0]) << 32 << skip0;
+        have = 32 - skip0;
+        ++wi;
+        refill();
+        if (have <= 32) refill();
+    }
+    // a Huffman symbol through a tree's DEC_K-bit table (codes longer than that: walk the tree in global memory)
+    auto sym = [&](const DTree *t, const uint16_t *tab) -> uint32_t {
+        if (tab) {
+            const uint32_t e = U(tab[(uint32_t)(win >> (64 - DEC_K))]);
+            if (e) { (void)get(e >> 12); return e & 0xfffu; }
+        }
+        const uint32_t tn = U(t->n);
+        uint32_t node = U(t->root), steps = 0;
+        while (node >= tn) {
+            if (++steps > 64) { bad = 1; return 0u; }
+            const uint32_t idx = node - tn;
+            node = U(get(1) ? t->rc[idx] : t->lc[idx]);
+        }
+        return node;
+    };
+    for (uint32_t g0 = 0; g0 < n && !bad; g0 += GROUP) {
+        const uint32_t g1 = g0 + GROUP < n ? g0 + GROUP : n;
+        uint64_t gmask = 0;
+        for (uint32_t k = 0; k < nvf; ++k) gmask |= (uint64_t)get(1) << k;
+        for (uint32_t i = g0; i < g1 && !bad; ++i) {
+            uint32_t *vrow = vtab + (size_t)i * nvw;
+            for (uint32_t k = 0; k < nvf; ++k) {
+                const VField &vf = VF[k];
+                const uint32_t kind = U(vf.kind), vidx = U(vf.vidx);
+                const bool gfl = (gmask >> k) & 1;
+                if (kind == 1) {
+                    int32_t v;
+                    if (i == g0) v = (int32_t)U((uint32_t)vf.min_v) + (int32_t)get(U(vf.bits_val));
+                    else {
+                        const int32_t prev = (int32_t)U((uint32_t)s_prev[k]);
+                        const bool delta = U(vf.delta) != 0;
+                        if (gfl) v = delta ? prev + (int32_t)U((uint32_t)vf.min_d) : prev;
+                        else {
+                            int32_t x;
+                            if (U(vf.has_g)) { const DTree *t = &F[U(vf.f)].g; x = (int32_t)sym(t, (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)t->tab >> 32)) << 32) | U((uint32_t)(uintptr_t)t->tab))); }
+                            else x = (int32_t)get(U(vf.bits_num));
+                            v = delta ? prev + (int32_t)U((uint32_t)vf.min_d) + x : (int32_t)U((uint32_t)vf.min_v) + x;
+                        }
+                    }
+                    s_prev[k] = v;
+                    vrow[vidx] = (uint32_t)v;
+                } else {   // text
+                    if (i != g0 && gfl) {   // the group's first record's characters
+                        vrow[vidx] = U(s_gv[2 * k]);
+                        vrow[vidx + 1] = U(s_gv[2 * k + 1]);
+                    } else {
+                        const uint32_t len0 = U(vf.len0), maxl = U(vf.max_len);
+                        const uint32_t L = U(vf.is_len_const) ? len0 : U(vf.min_len) + get(U(vf.bits_len));
+                        if (L > maxl || tused + L > tchar_cap) { bad = L > maxl ? 1u : 3u; break; }
+                        const DField &fd = F[U(vf.f)];
+                        const uint8_t *ham = (const uint8_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.ham >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.ham));
+                        const uint8_t *d0 = (const uint8_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.data0 >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.data0));
+                        const DTree *tl = (const DTree *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.l >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.l));
+                        for (uint32_t j = 0; j < L && !bad; ++j) {
+                            uint32_t c;
+                            if (j < len0 && U(ham[j])) c = U(d0[j]);
+                            else {
+                                const uint32_t tj = j < MAX_STAT_LEN ? j : MAX_STAT_LEN;
+                                const DTree *t = tl + tj;
+                                const uint16_t *tab;
+                                if (k < DEC_TPTR_FIELDS && tj < DEC_TPTR_POS) {
+                                    const uint16_t *const *pp = s_tptr + k * DEC_TPTR_POS + tj;
+                                    const uint64_t a = *reinterpret_cast<const uint64_t *>(pp);
+                                    tab = (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)(a >> 32)) << 32) | U((uint32_t)a));
+                                    if (!tab && !U(t->n)) { bad = 1; break; }
+                                } else {
+                                    if (!U(t->n)) { bad = 1; break; }
+                                    tab = (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)t->tab >> 32)) << 32) | U((uint32_t)(uintptr_t)t->tab));
+                                }
+                                c = sym(t, tab);
+                            }
+                            tchars[tused + j] = (uint8_t)c;
+                        }
+                        vrow[vidx] = (uint32_t)tused;
+                        vrow[vidx + 1] = L;
+                        if (i == g0) { s_gv[2 * k] = (uint32_t)tused; s_gv[2 * k + 1] = L; }
+                        tused += L;
+                    }
+                }
+            }
+        }
+        // byte-align behind the group (tasks.cpp:508): pos = wi * 32 - have
+        const uint32_t d = have & 7u;
+        if (d) (void)get(d);
+    }
+    const uint64_t pos = (uint64_t)wi * 32 - have;
+    if (pos > nbits && !bad) bad = 1;
+    if (lane == 0) {
+        C.pos = pos;
+        C.text = tused;
+        if (bad) C.err = bad == 3 ? ERR_CAPACITY : ERR_FORMAT;
+    }
+    __syncthreads();
+}
+
+// One wave per sub-block: lane 0 walks the headers, the wave the length table, the title body and the two symbol streams.
 __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
                                                     uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
                                                     DecSub *out, uint32_t lds_entries)
@@ -567,10 +701,15 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     if (s >= n_sb) return;
     const uint32_t lane = threadIdx.x;
     __shared__ DField s_F[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
+    __shared__ VField s_VF[DEC_MAX_FIELDS];
+    __shared__ int32_t s_prev[DEC_MAX_FIELDS];
+    __shared__ uint32_t s_gv[2 * DEC_MAX_FIELDS];
+    __shared__ const uint16_t *s_tptr[DEC_TPTR_FIELDS * DEC_TPTR_POS];
     __shared__ uint8_t s_map[256];
     __shared__ uint32_t s_in[DEC_IN_DW + 4];
     __shared__ uint8_t s_out[DEC_OUT];
     __shared__ DecCtl C;
+    __shared__ uint32_t s_nv[2];
     __shared__ uint16_t s_dtab[1u << DEC_K];
     extern __shared__ __align__(16) uint16_t s_qtab[];
     DecSub &O = out[s];
@@ -583,12 +722,113 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     if (lane == 0) {
         O.err = OK; O.text_bytes = 0; O.n_rec = 0;
         stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
-        C.err = dec_head(r, D, pool, O, s_F, s_map, s_qtab, lds_entries, rec_cap, C, stack);
+        C.err = dec_info(r, D, O, rec_cap, C);
         if (C.err) O.err = C.err;
     }
     __syncthreads();
     if (C.err) return;
     const uint32_t n = C.n;
+    // ---- the length table (phyNGSC.cpp:730-742): n entries of lt_bits bits, every lane its own entries ----
+    {
+        const uint32_t b = C.lt_bits, mq = C.max_q;
+        const uint64_t lt0 = C.pos, nbytes = sb_len[s];
+        uint64_t tot = 0;
+        uint32_t badl = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t L = dec_bits_at(r.p, nbytes, lt0 + (uint64_t)i * b, b);
+            D.qlen[i] = L;
+            tot += L;
+            badl |= L > mq;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); badl |= (uint32_t)__shfl_xor((int)badl, d); }
+        if (lane == 0) {
+            C.qual_total = tot;
+            if (badl) C.err = ERR_FORMAT;
+            else if (2 * tot > D.tcap) C.err = ERR_CAPACITY;
+            if (C.err) O.err = C.err;
+        }
+    }
+    __syncthreads();
+    if (C.err) return;
+    // ---- title header (lane 0), then the tables the body walk and the renderer work from ----
+    if (lane == 0) {
+        r.seek(C.pos + (uint64_t)n * C.lt_bits);
+        r.align();
+        C.err = dec_head(r, D, pool, O, s_F, C, stack);
+        if (!C.err) {
+            const uint32_t nf = C.nf;
+            AField *af = (AField *)pool.take(sizeof(AField) * nf);
+            uint32_t nvf = 0, nvw = 0;
+            if (!af) C.err = ERR_NOMEM;
+            for (uint32_t k = 0; k < DEC_TPTR_FIELDS * DEC_TPTR_POS; ++k) s_tptr[k] = nullptr;
+            for (uint32_t f = 0; f < nf && !C.err; ++f) {
+                const DField &fd = s_F[f];
+                AField &a = af[f];
+                a.sep = fd.sep; a.len0 = fd.len0; a.vidx = 0; a.data_off = 0;
+                if (fd.is_const) { a.kind = 0; a.data_off = (uint64_t)(fd.data0 - D.pool); continue; }
+                VField &v = s_VF[nvf];
+                v.f = f; v.kind = fd.is_num ? 1u : 2u; v.vidx = nvw; v.delta = fd.delta_coding; v.has_g = fd.has_g;
+                v.bits_val = fd.bits_val > 32 ? 32 : fd.bits_val; v.bits_num = fd.bits_num > 32 ? 32 : fd.bits_num;
+                v.bits_len = fd.bits_len > 32 ? 32 : fd.bits_len; v.is_len_const = fd.is_len_const; v.len0 = fd.len0;
+                v.min_len = fd.min_len; v.max_len = fd.max_len; v.min_v = fd.min_v; v.min_d = fd.min_d;
+                a.kind = v.kind; a.vidx = nvw;
+                if (!fd.is_num && nvf < DEC_TPTR_FIELDS)
+                    for (uint32_t j = 0; j < DEC_TPTR_POS && j <= MAX_STAT_LEN; ++j) s_tptr[nvf * DEC_TPTR_POS + j] = fd.l[j].n ? fd.l[j].tab : nullptr;
+                nvw += fd.is_num ? 1u : 2u;
+                ++nvf;
+            }
+            s_nv[0] = nvf; s_nv[1] = nvw;
+            O.nf = nf; O.nvw = nvw; O.af_off = af ? (uint64_t)((uint8_t *)af - D.pool) : 0;
+            // text area: [value table n x nvw words][characters of the text fields][qualities][bases of a Huffman-coded alphabet]
+            const uint64_t vbytes = (4ull * n * nvw + 15) & ~15ull;
+            if (!C.err && vbytes + 2 * C.qual_total > D.tcap) C.err = ERR_CAPACITY;
+            O.tchar_off = vbytes;
+        }
+        if (C.err) O.err = C.err;
+    }
+    __syncthreads();
+    if (C.err) return;
+    {
+        const uint64_t vbytes = O.tchar_off;
+        const uint64_t room = D.tcap - vbytes - 2 * C.qual_total;   // what is left for the text fields' characters (32 bytes kept for alignment)
+        dec_title_body_wave(r.p, r.nbits, C, s_VF, s_nv[0], s_nv[1], s_F, (uint32_t *)D.titles, D.titles + vbytes, room > 64 ? room - 64 : 0, s_in,
+                            s_prev, s_gv, s_tptr);
+    }
+    if (C.err) { if (lane == 0) O.err = C.err; return; }
+    // ---- title length of every record (its place in the text needs it): constant fields and separators + the digits of its
+    // numbers + its text fields' characters; every lane its share of the records ----
+    {
+        const uint32_t nf = O.nf, nvw = O.nvw;
+        const AField *af = (const AField *)(D.pool + O.af_off);
+        uint32_t fixed = nf;   // one separator per field
+        for (uint32_t f = 0; f < nf; ++f) fixed += af[f].kind == 0 ? af[f].len0 : 0u;
+        const uint32_t *vtab = (const uint32_t *)D.titles;
+        uint64_t tot = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            uint32_t tl = fixed;
+            const uint32_t *vrow = vtab + (size_t)i * nvw;
+            for (uint32_t f = 0; f < nf; ++f) {
+                const uint32_t kind = af[f].kind;
+                if (kind == 1) tl += dec_ndigits(vrow[af[f].vidx]);
+                else if (kind == 2) tl += vrow[af[f].vidx + 1];
+            }
+            D.toff[i] = tl;
+            tot += tl;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        if (lane == 0) O.text_bytes = tot + 2ull * C.qual_total + 4ull * n;
+    }
+    // ---- quality alphabet and trees (lane 0) ----
+    if (lane == 0) {
+        C.text += O.tchar_off;   // the value table and the characters
+        r.seek(C.pos);
+        C.err = dec_head_quality(r, D, pool, s_map, s_qtab, lds_entries, C, stack);
+        if (C.err) O.err = C.err;
+    }
+    __syncthreads();
+    if (C.err) return;
     const uint64_t t1 = wall_clock64();
     uint8_t *d_qual = D.titles + D.lay[0], *d_seq = D.titles + D.lay[1];
     if (C.q_lds) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
@@ -599,6 +839,14 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     // ---- DNA (cf. FetchDNA tasks.cpp:957-1033): alphabet; a Huffman-coded alphabet is decoded here, two-bit codes by the assembly kernel ----
     const uint64_t t2 = wall_clock64();
     __shared__ DTree s_dt;
+    {   // bases kept per record -> their total (every lane its share)
+        uint64_t bases = 0;
+        for (uint32_t i = lane; i < n; i += 64) bases += D.slen[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) bases += __shfl_xor(bases, d);
+        if (lane == 0) C.qual_total_bases = bases;
+    }
+    __syncthreads();
     if (lane == 0) {
         r.seek(C.pos);
         r.align();
@@ -609,9 +857,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
             if (!tree_load(r, nsym, pool, s_dt, stack)) C.err = r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
             else tree_table(s_dt, s_dtab, DEC_K, s_map);
         } else {
-            uint64_t bases = 0;
-            for (uint32_t i = 0; i < n; ++i) bases += D.slen[i];
-            if (r.bad || r.pos + 2 * bases > r.nbits) C.err = ERR_FORMAT;
+            if (r.bad || r.pos + 2 * C.qual_total_bases > r.nbits) C.err = ERR_FORMAT;
         }
         if (r.bad && !C.err) C.err = ERR_FORMAT;
         C.pos = r.pos;
@@ -626,9 +872,6 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     }
     if (lane == 0) {
         O.dna_bitpos = C.pos;
-        uint64_t text = C.text;
-        text += 2ull * C.qual_total + 4ull * n;
-        O.text_bytes = text;
         O.t_head = t1 - t0; O.t_qual = t2 - t1; O.t_dna = wall_clock64() - t2;
     }
 }
@@ -649,6 +892,8 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
     const uint8_t *sb = sub + sb_off[s];
     uint8_t *dst = text + text_off[s];
     const uint8_t amb_base[17] = {0, 0, 'Y', 'R', 'W', 'S', 'K', 'M', 'D', 'V', 'H', 'B', 'N', 'X', 'U', '.', '-'};
+    const uint32_t nf = O.nf;
+    const AField *af = (const AField *)(D.pool + O.af_off);
     if (tid == 0) { s_run[0] = 0; s_run[1] = 0; }
     __syncthreads();
     uint64_t qbase = 0;   // qualities are stored back to back: running offset = sum of the read lengths
@@ -656,7 +901,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
         const uint32_t i = base + tid;
         const bool valid = i < O.n_rec;
         const uint32_t L = valid ? D.qlen[i] : 0, kept = valid ? D.slen[i] : 0;
-        const uint32_t tl = valid ? D.toff[i + 1] - D.toff[i] : 0;
+        const uint32_t tl = valid ? D.toff[i] : 0;   // title bytes of the record (k_dec_streams)
         // exclusive scans over the batch: text bytes, quality bytes, bases
         uint64_t tb = valid ? (uint64_t)tl + 2ull * L + 4 : 0, qb = L, bb = kept;
         uint64_t it = tb, iq = qb, ib = bb;
@@ -676,8 +921,27 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
         const uint64_t o_text = s_run[0] + bt + it - tb, o_q = qbase + bq + iq - qb, o_b = s_run[1] + bbs + ib - bb;
         if (valid) {
             uint8_t *o = dst + o_text;
-            const uint8_t *t = D.titles + D.toff[i];
-            for (uint32_t j = 0; j < tl; ++j) o[j] = t[j];      // (ends with the last field's separator, '\n')
+            {   // the title, field by field, from the record's value words (ends with the last field's separator, '\n')
+                const uint32_t *vrow = (const uint32_t *)D.titles + (size_t)i * O.nvw;
+                const uint8_t *tch = D.titles + O.tchar_off;
+                uint8_t *w = o;
+                for (uint32_t f = 0; f < nf; ++f) {
+                    const AField a = af[f];
+                    if (a.kind == 0) {
+                        const uint8_t *c = D.pool + a.data_off;
+                        for (uint32_t j = 0; j < a.len0; ++j) w[j] = c[j];
+                        w += a.len0;
+                    } else if (a.kind == 1) {
+                        w += dec_put_decimal(w, vrow[a.vidx]);
+                    } else {
+                        const uint8_t *c = tch + vrow[a.vidx];
+                        const uint32_t L = vrow[a.vidx + 1];
+                        for (uint32_t j = 0; j < L; ++j) w[j] = c[j];
+                        w += L;
+                    }
+                    *w++ = (uint8_t)a.sep;
+                }
+            }
             o += tl;
             const uint8_t *q = D.titles + D.lay[0] + o_q;
             uint64_t bi = o_b;                                   // index of the record's next base in the DNA stream
