@@ -18,8 +18,14 @@
 using namespace ngsc;
 
 namespace ngsc {
+void launch_dec_head(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
+                     uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, bool allow_spec, uint32_t *summary);
 void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
-                        uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out);
+                        uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, uint16_t *hop, const uint64_t *hop_off,
+                        uint32_t max_tiles, uint32_t spec_max_q);
+size_t dec_ctl_bytes();
+uint32_t dec_qspec_tile();
+uint32_t dec_sub_spec(const void *h, uint32_t s);
 void launch_dec_assemble(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch, uint64_t stride,
                          uint32_t rec_cap, uint64_t tcap, uint64_t qcap, const void *in, const uint64_t *text_off, uint8_t *text);
 size_t dec_sub_bytes();
@@ -40,35 +46,80 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     hipStream_t st = (hipStream_t)hip_stream;   // nullptr: the default stream
     // scratch of one sub-block: a sub-block holds the records of one 8 MiB window (+ the record that straddles its end)
     const uint32_t rec_cap = MAX_RECORDS + 2;
-    const uint64_t tcap = 10ull << 20, qcap = 0, pool = 4ull << 20;   // text area: titles, qualities, bases <= the window's text
-    const uint64_t stride = ((4ull * rec_cap * 3 + 96 + tcap + pool) + 255) & ~255ull;
-    const uint32_t batch = std::min<uint32_t>(n_sb, 2048);              // ~15 MiB of scratch per sub-block in flight
+    const uint64_t tcap = 10ull << 20, qcap = 0, pool = 4ull << 20;   // text area: value table, qualities, bases <= the window's text
+    const uint64_t stride = ((4ull * rec_cap * 4 + 128 + tcap + pool) + 255) & ~255ull;
+    // batches: at most 2048 sub-blocks (~15 MiB of scratch each) and - for the speculative quality decoder's hop table, 2 bytes
+    // per BIT of a sub-block - at most 512 MiB of compressed bytes
+    const bool spec = !(getenv("NGSC_DEC_SPEC") && !strcmp(getenv("NGSC_DEC_SPEC"), "0"));
+    const uint64_t hop_budget = 512ull << 20;
+    uint32_t batch = std::min<uint32_t>(n_sb, 2048);
+    uint64_t max_batch_bytes = 0;
+    {   // the largest compressed size a batch of `batch` consecutive sub-blocks can have under the budget
+        uint64_t run = 0;
+        uint32_t cnt = 0, worst = batch;
+        for (uint32_t k = 0, k0 = 0; k < n_sb; ++k) {
+            run += sb_len[k]; ++cnt;
+            while (cnt > 1 && (run > hop_budget || cnt > batch)) { run -= sb_len[k0++]; --cnt; }
+            max_batch_bytes = std::max(max_batch_bytes, run);
+            (void)worst;
+        }
+    }
     uint8_t *scratch = nullptr;
-    uint64_t *d_off = nullptr, *d_toff = nullptr;
+    uint64_t *d_off = nullptr, *d_toff = nullptr, *d_hoff = nullptr;
     uint32_t *d_len = nullptr;
-    void *d_res = nullptr;
+    void *d_res = nullptr, *d_ctl = nullptr;
+    uint16_t *d_hop = nullptr;
+    uint32_t *d_sum = nullptr;
     const size_t rb = dec_sub_bytes();
     std::vector<uint8_t> h_res(rb * batch);
     int rc = NGSC_OK;
     if (hipMalloc(&scratch, stride * batch) != hipSuccess || hipMalloc(&d_off, 8ull * batch) != hipSuccess ||
-        hipMalloc(&d_toff, 8ull * batch) != hipSuccess || hipMalloc(&d_len, 4ull * batch) != hipSuccess || hipMalloc(&d_res, rb * batch) != hipSuccess)
+        hipMalloc(&d_toff, 8ull * batch) != hipSuccess || hipMalloc(&d_hoff, 8ull * batch) != hipSuccess ||
+        hipMalloc(&d_len, 4ull * batch) != hipSuccess || hipMalloc(&d_res, rb * batch) != hipSuccess ||
+        hipMalloc(&d_ctl, dec_ctl_bytes() * batch) != hipSuccess || hipMalloc((void **)&d_sum, 64) != hipSuccess)
         rc = NGSC_ERR_NOMEM;
+    if (!rc && spec && hipMalloc((void **)&d_hop, 16ull * max_batch_bytes + 64) != hipSuccess) d_hop = nullptr;   // (no room: serial decode)
     uint64_t text_pos = 0;
-    for (uint32_t b0 = 0; b0 < n_sb && !rc; b0 += batch) {
-        const uint32_t nb = std::min(batch, n_sb - b0);
+    uint32_t n_spec = 0;
+    for (uint32_t b0 = 0; b0 < n_sb && !rc;) {
+        uint32_t nb = 0;
+        uint64_t bbytes = 0;
+        while (b0 + nb < n_sb && nb < batch && (nb == 0 || bbytes + sb_len[b0 + nb] <= hop_budget)) { bbytes += sb_len[b0 + nb]; ++nb; }
+        std::vector<uint64_t> hoff(nb);
+        uint64_t hpos = 0;
+        uint32_t max_tiles = 1;
+        for (uint32_t k = 0; k < nb; ++k) {
+            hoff[k] = hpos;
+            hpos += 8ull * sb_len[b0 + k];
+            max_tiles = std::max<uint32_t>(max_tiles, (uint32_t)(8ull * sb_len[b0 + k] / dec_qspec_tile()) + 1);
+        }
+        const bool use_hop = d_hop && hpos <= 8ull * max_batch_bytes;
         if (hipMemcpyAsync(d_off, sb_off + b0, 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(d_len, sb_len + b0, 4ull * nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-        launch_dec_streams(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res);
+            hipMemcpyAsync(d_len, sb_len + b0, 4ull * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_hoff, hoff.data(), 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        if (use_hop && hipMemsetAsync(d_hop, 0xFF, 2ull * hpos, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        uint32_t spec_max_q = 0;
+        if (hipMemsetAsync(d_sum, 0, 4, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        launch_dec_head(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop, d_sum);
+        if (use_hop && (hipMemcpyAsync(&spec_max_q, d_sum, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+            rc = NGSC_ERR_HIP;
+            break;
+        }
+        launch_dec_streams(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop ? d_hop : nullptr,
+                           d_hoff, max_tiles, spec_max_q);
         if (hipMemcpyAsync(h_res.data(), d_res, rb * nb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = NGSC_ERR_HIP;
             break;
         }
         std::vector<uint64_t> toff(nb);
+        for (uint32_t k = 0; k < nb; ++k) n_spec += dec_sub_err(h_res.data(), k) ? 0u : dec_sub_spec(h_res.data(), k);
         if (getenv("NGSC_VERBOSE")) {   // the slowest sub-block of the batch, phase by phase (100 MHz ticks)
-            uint64_t mx[3] = {0, 0, 0};
-            for (uint32_t k = 0; k < nb; ++k) { uint64_t t[3]; dec_sub_ticks(h_res.data(), k, t); for (int q = 0; q < 3; ++q) mx[q] = std::max(mx[q], t[q]); }
-            fprintf(stderr, "[ngsc decode] %u sub-blocks: header + titles %.1f ms, qualities %.1f ms, bases %.1f ms (slowest of the batch)\n", nb,
-                    mx[0] / 1e5, mx[1] / 1e5, mx[2] / 1e5);
+            uint64_t mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t k = 0; k < nb; ++k) { uint64_t t[8]; dec_sub_ticks(h_res.data(), k, t); for (int q = 0; q < 8; ++q) mx[q] = std::max(mx[q], t[q]); }
+            fprintf(stderr, "[ngsc decode] head kernel: info + length table %.2f ms, title header %.2f ms, title body %.2f ms, title lengths %.2f ms, "
+                            "quality header %.2f ms\n", mx[3] / 1e5, mx[4] / 1e5, mx[5] / 1e5, mx[6] / 1e5, mx[7] / 1e5);
+            fprintf(stderr, "[ngsc decode] %u sub-blocks (%u with the speculative quality decoder so far): header + titles %.1f ms, tail kernel: "
+                            "qualities %.1f ms, bases %.1f ms (slowest of the batch)\n", nb, n_spec, mx[0] / 1e5, mx[1] / 1e5, mx[2] / 1e5);
         }
         for (uint32_t k = 0; k < nb && !rc; ++k) {
             if (dec_sub_err(h_res.data(), k)) { rc = dec_sub_err(h_res.data(), k); break; }
@@ -82,6 +133,7 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
         if (hipMemcpyAsync(d_toff, toff.data(), 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         launch_dec_assemble(st, (const uint8_t *)d_sub, d_off, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_toff, (uint8_t *)d_text);
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        b0 += nb;
     }
     text_off[n_sb] = text_pos;
     if (scratch) (void)hipFree(scratch);
@@ -89,6 +141,10 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     if (d_toff) (void)hipFree(d_toff);
     if (d_len) (void)hipFree(d_len);
     if (d_res) (void)hipFree(d_res);
+    if (d_ctl) (void)hipFree(d_ctl);
+    if (d_hoff) (void)hipFree(d_hoff);
+    if (d_hop) (void)hipFree(d_hop);
+    if (d_sum) (void)hipFree(d_sum);
     return rc;
 }
 

@@ -10,11 +10,18 @@
 // record.  One wave per sub-block: lane 0 walks the serial parts (title fields, per-position quality codes, Huffman-coded
 // DNA) into scratch buffers; then all 64 lanes do what is parallel - 2-bit DNA at offsets from a prefix sum of the read
 // lengths, and the assembly of the four lines of every record at offsets from a prefix sum of the record sizes.
-//   k_dec_streams   serial decode per sub-block -> titles, qualities (+ sizes)
+//   k_dec_head      headers, length table, title walk per sub-block (one wave each)
+//   k_dec_qspec_*   the quality stream of equally long reads, speculatively: every bit offset, then the chain, then the records
+//   k_dec_tail      what is left of the serial streams: qualities of unequal reads, Huffman-coded bases
 //   k_dec_assemble  per record: title \n bases \n + \n qualities \n
 // Integer / bit work; bounded by dependent-load latency of one lane per wave (no MFMA, no bandwidth to speak of).
 #include "ngsc_kernels.h"
 #include "ngsc_swar.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace ngsc {
 
@@ -209,6 +216,8 @@ struct DecSub {
     uint64_t t_head, t_qual, t_dna;   // wall_clock64 ticks (100 MHz) of the three phases, for NGSC_VERBOSE
     // titles are rendered by the assembly kernel, all threads at once, from what the serial walk over the title body left:
     uint32_t nf, nvw;           // fields; value words per record
+    uint32_t spec, pad_;        // the quality stream went through the speculative decoder
+    uint64_t t_ph[6];           // head kernel, ticks: info + length table, title header, title body, title lengths, quality header
     uint64_t af_off;            // AField[nf] at pool + af_off
     uint64_t tchar_off;         // decoded characters of the varying text fields, in the text area
     uint8_t dsym[256];
@@ -243,7 +252,7 @@ __device__ __forceinline__ uint32_t dec_put_decimal(uint8_t *dst, uint32_t v)
 // then - where they end, which is known before the quality stream is opened - the qualities, then the bases of a
 // Huffman-coded alphabet: together never more than the sub-block's FASTQ text.
 struct DecScratch {
-    uint32_t *qlen, *toff, *slen;
+    uint32_t *qlen, *toff, *slen, *rs;   // rs: start bit of every record's qualities, relative to the stream's start (+ its end)
     uint64_t *lay;          // [0] offset of the qualities in the text area, [1] of the bases
     uint8_t *titles;
     uint8_t *pool;
@@ -257,6 +266,7 @@ __device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, ui
     D.qlen = (uint32_t *)b; b += 4ull * rec_cap;
     D.toff = (uint32_t *)b; b += 4ull * (rec_cap + 1);
     D.slen = (uint32_t *)b; b += 4ull * rec_cap;
+    D.rs = (uint32_t *)b; b += 4ull * (rec_cap + 1);
     b = (uint8_t *)(((uintptr_t)b + 15) & ~(uintptr_t)15);
     D.lay = (uint64_t *)b; b += 16;
     D.titles = b; b += tcap;
@@ -275,14 +285,21 @@ __device__ DecScratch dec_scratch(uint8_t *base, uint64_t stride, uint32_t s, ui
 constexpr uint32_t DEC_IN_DW = 512;      // 2 KB of bit string per round (+ 2 dwords of look-ahead)
 constexpr uint32_t DEC_OUT = 6144;       // symbols per round at most
 
-struct DecCtl {   // lane 0 -> wave
+struct DecCtl {   // state of one sub-block's decode: lane 0 -> wave inside a kernel (an LDS copy), kernel -> kernel (global)
     int32_t err;
     uint32_t n, max_q, Kq, q_lds, nqual, nf, lt_bits;
-    uint64_t pos;            // bit position behind what lane 0 has consumed
+    uint64_t pos;            // bit position behind what has been consumed
     uint64_t qual_total, text, qual_total_bases;
-    const uint16_t *qtab;    // global table when it does not fit LDS
+    const uint16_t *qtab;    // per-position tables of Kq bits in global memory (the pool)
     const DTree *qt;
-    uint32_t wi, ko, i, done;
+    uint32_t spec;           // every read has max_q qualities: the speculative decoder (k_dec_qspec_*) takes the quality stream
+    uint32_t spec_bad;       // ... and found something it does not handle: the tail kernel decodes the stream serially
+    uint64_t cov_lo, cov_hi; // hops computed so far / being computed: bit offsets relative to the stream's start
+    uint64_t chain_cur;      // where the chain of record starts stands (relative), and at which record
+    uint32_t chain_i, pad1_;
+    uint64_t pool_off;       // bump offset of the pool behind the head kernel
+    uint64_t t_head;
+    uint8_t qsym[256];       // quality alphabet: symbol index -> byte
 };
 
 // lens[i] symbols for record i = 0..n-1; PER_POS: symbol j of a record uses table row j + 1 (tasks.cpp:609-619) and its
@@ -528,11 +545,11 @@ __device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qs
     for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
     DTree *qt = (DTree *)pool.take(sizeof(DTree) * ((uint64_t)max_q + 1));
     if (!qt) return ERR_NOMEM;
-    // the per-position tables: in LDS while they fit (the quality codes are most of the sub-block's symbols)
-    uint32_t Kq = DEC_K;   // the widest tables that fit (codes longer than Kq bits walk their tree)
-    while (Kq > 5 && (((uint64_t)max_q + 1) << Kq) > lds_entries) --Kq;
-    const bool q_lds = (((uint64_t)max_q + 1) << Kq) <= lds_entries;
-    uint16_t *qtab = q_lds ? s_qtab : (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
+    // the per-position tables, DEC_K bits wide, in the pool: the kernels that decode the symbols copy what fits into LDS
+    // (narrower if need be: dec_fill_lds_table)
+    const uint32_t Kq = DEC_K;
+    (void)s_qtab; (void)lds_entries;
+    uint16_t *qtab = (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
     if (!qtab) return ERR_NOMEM;
     for (uint32_t p = 0; p <= max_q && !r.bad; ++p) {
         qt[p].n = 0;
@@ -540,7 +557,7 @@ __device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qs
     }
     r.align();
     if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
-    C.Kq = Kq; C.q_lds = q_lds ? 1u : 0u; C.qtab = qtab; C.qt = qt;
+    C.Kq = Kq; C.q_lds = 0u; C.qtab = qtab; C.qt = qt;
     C.pos = r.pos;
     return OK;
 }
@@ -612,70 +629,89 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
         }
         return node;
     };
+    // The first four varying fields - nearly always all of them - live in scalar registers: a field's constants read from LDS
+    // one by one, each a round trip that the next branch waits for, made a record cost 0.75 us (50 ms per sub-block).
+    struct VFc { uint32_t f, kind, vidx, delta, has_g, bits_val, bits_num, bits_len, is_len_const, len0, min_len, max_len; int32_t min_v, min_d; };
+    auto ldc = [&](uint32_t k) {
+        VFc c;
+        const VField &v = VF[k];
+        c.f = U(v.f); c.kind = U(v.kind); c.vidx = U(v.vidx); c.delta = U(v.delta); c.has_g = U(v.has_g); c.bits_val = U(v.bits_val);
+        c.bits_num = U(v.bits_num); c.bits_len = U(v.bits_len); c.is_len_const = U(v.is_len_const); c.len0 = U(v.len0);
+        c.min_len = U(v.min_len); c.max_len = U(v.max_len); c.min_v = (int32_t)U((uint32_t)v.min_v); c.min_d = (int32_t)U((uint32_t)v.min_d);
+        return c;
+    };
+    auto ptr64 = [&](const void *q) { const uint64_t a = (uint64_t)(uintptr_t)q; return ((uint64_t)U((uint32_t)(a >> 32)) << 32) | U((uint32_t)a); };
+    // one field of one record; prev / gv0 / gv1: the field's running value and its group's first text value
+    auto do_field = [&](uint32_t k, const VFc &c, int32_t &prev, uint32_t &gv0, uint32_t &gv1, uint32_t *vrow, bool first, bool gfl) {
+        if (c.kind == 1) {
+            int32_t v;
+            if (first) v = c.min_v + (int32_t)get(c.bits_val);
+            else if (gfl) v = c.delta ? prev + c.min_d : prev;
+            else {
+                int32_t x;
+                if (c.has_g) { const DTree *t = &F[c.f].g; x = (int32_t)sym(t, (const uint16_t *)(uintptr_t)ptr64(t->tab)); }
+                else x = (int32_t)get(c.bits_num);
+                v = c.delta ? prev + c.min_d + x : c.min_v + x;
+            }
+            prev = v;
+            vrow[c.vidx] = (uint32_t)v;
+        } else if (!first && gfl) {   // text: the group's first record's characters
+            vrow[c.vidx] = gv0;
+            vrow[c.vidx + 1] = gv1;
+        } else {
+            const uint32_t L = c.is_len_const ? c.len0 : c.min_len + get(c.bits_len);
+            if (L > c.max_len || tused + L > tchar_cap) { bad = L > c.max_len ? 1u : 3u; return; }
+            const DField &fd = F[c.f];
+            const uint8_t *ham = (const uint8_t *)(uintptr_t)ptr64(fd.ham), *d0 = (const uint8_t *)(uintptr_t)ptr64(fd.data0);
+            const DTree *tl = (const DTree *)(uintptr_t)ptr64(fd.l);
+            for (uint32_t j = 0; j < L && !bad; ++j) {
+                uint32_t ch;
+                if (j < c.len0 && U(ham[j])) ch = U(d0[j]);
+                else {
+                    const uint32_t tj = j < MAX_STAT_LEN ? j : MAX_STAT_LEN;
+                    const DTree *t = tl + tj;
+                    const uint16_t *tab;
+                    if (k < DEC_TPTR_FIELDS && tj < DEC_TPTR_POS) {
+                        tab = (const uint16_t *)(uintptr_t)ptr64(s_tptr[k * DEC_TPTR_POS + tj]);
+                        if (!tab && !U(t->n)) { bad = 1; break; }
+                    } else {
+                        if (!U(t->n)) { bad = 1; break; }
+                        tab = (const uint16_t *)(uintptr_t)ptr64(t->tab);
+                    }
+                    ch = sym(t, tab);
+                }
+                tchars[tused + j] = (uint8_t)ch;
+            }
+            vrow[c.vidx] = (uint32_t)tused;
+            vrow[c.vidx + 1] = L;
+            if (first) { gv0 = (uint32_t)tused; gv1 = L; }
+            tused += L;
+        }
+    };
+    VFc c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    if (nvf > 0) c0 = ldc(0);
+    if (nvf > 1) c1 = ldc(1);
+    if (nvf > 2) c2 = ldc(2);
+    if (nvf > 3) c3 = ldc(3);
+    int32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+    uint32_t ga0 = 0, ga1 = 0, gb0 = 0, gb1 = 0, gc0 = 0, gc1 = 0, gd0 = 0, gd1 = 0;
     for (uint32_t g0 = 0; g0 < n && !bad; g0 += GROUP) {
         const uint32_t g1 = g0 + GROUP < n ? g0 + GROUP : n;
         uint64_t gmask = 0;
         for (uint32_t k = 0; k < nvf; ++k) gmask |= (uint64_t)get(1) << k;
         for (uint32_t i = g0; i < g1 && !bad; ++i) {
             uint32_t *vrow = vtab + (size_t)i * nvw;
-            for (uint32_t k = 0; k < nvf; ++k) {
-                const VField &vf = VF[k];
-                const uint32_t kind = U(vf.kind), vidx = U(vf.vidx);
-                const bool gfl = (gmask >> k) & 1;
-                if (kind == 1) {
-                    int32_t v;
-                    if (i == g0) v = (int32_t)U((uint32_t)vf.min_v) + (int32_t)get(U(vf.bits_val));
-                    else {
-                        const int32_t prev = (int32_t)U((uint32_t)s_prev[k]);
-                        const bool delta = U(vf.delta) != 0;
-                        if (gfl) v = delta ? prev + (int32_t)U((uint32_t)vf.min_d) : prev;
-                        else {
-                            int32_t x;
-                            if (U(vf.has_g)) { const DTree *t = &F[U(vf.f)].g; x = (int32_t)sym(t, (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)t->tab >> 32)) << 32) | U((uint32_t)(uintptr_t)t->tab))); }
-                            else x = (int32_t)get(U(vf.bits_num));
-                            v = delta ? prev + (int32_t)U((uint32_t)vf.min_d) + x : (int32_t)U((uint32_t)vf.min_v) + x;
-                        }
-                    }
-                    s_prev[k] = v;
-                    vrow[vidx] = (uint32_t)v;
-                } else {   // text
-                    if (i != g0 && gfl) {   // the group's first record's characters
-                        vrow[vidx] = U(s_gv[2 * k]);
-                        vrow[vidx + 1] = U(s_gv[2 * k + 1]);
-                    } else {
-                        const uint32_t len0 = U(vf.len0), maxl = U(vf.max_len);
-                        const uint32_t L = U(vf.is_len_const) ? len0 : U(vf.min_len) + get(U(vf.bits_len));
-                        if (L > maxl || tused + L > tchar_cap) { bad = L > maxl ? 1u : 3u; break; }
-                        const DField &fd = F[U(vf.f)];
-                        const uint8_t *ham = (const uint8_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.ham >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.ham));
-                        const uint8_t *d0 = (const uint8_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.data0 >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.data0));
-                        const DTree *tl = (const DTree *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)fd.l >> 32)) << 32) | U((uint32_t)(uintptr_t)fd.l));
-                        for (uint32_t j = 0; j < L && !bad; ++j) {
-                            uint32_t c;
-                            if (j < len0 && U(ham[j])) c = U(d0[j]);
-                            else {
-                                const uint32_t tj = j < MAX_STAT_LEN ? j : MAX_STAT_LEN;
-                                const DTree *t = tl + tj;
-                                const uint16_t *tab;
-                                if (k < DEC_TPTR_FIELDS && tj < DEC_TPTR_POS) {
-                                    const uint16_t *const *pp = s_tptr + k * DEC_TPTR_POS + tj;
-                                    const uint64_t a = *reinterpret_cast<const uint64_t *>(pp);
-                                    tab = (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)(a >> 32)) << 32) | U((uint32_t)a));
-                                    if (!tab && !U(t->n)) { bad = 1; break; }
-                                } else {
-                                    if (!U(t->n)) { bad = 1; break; }
-                                    tab = (const uint16_t *)(uintptr_t)(((uint64_t)U((uint32_t)((uintptr_t)t->tab >> 32)) << 32) | U((uint32_t)(uintptr_t)t->tab));
-                                }
-                                c = sym(t, tab);
-                            }
-                            tchars[tused + j] = (uint8_t)c;
-                        }
-                        vrow[vidx] = (uint32_t)tused;
-                        vrow[vidx + 1] = L;
-                        if (i == g0) { s_gv[2 * k] = (uint32_t)tused; s_gv[2 * k + 1] = L; }
-                        tused += L;
-                    }
-                }
+            const bool first = i == g0;
+            if (nvf > 0) do_field(0, c0, p0, ga0, ga1, vrow, first, gmask & 1);
+            if (nvf > 1 && !bad) do_field(1, c1, p1, gb0, gb1, vrow, first, (gmask >> 1) & 1);
+            if (nvf > 2 && !bad) do_field(2, c2, p2, gc0, gc1, vrow, first, (gmask >> 2) & 1);
+            if (nvf > 3 && !bad) do_field(3, c3, p3, gd0, gd1, vrow, first, (gmask >> 3) & 1);
+            for (uint32_t k = 4; k < nvf && !bad; ++k) {
+                const VFc c = ldc(k);
+                int32_t pv = (int32_t)U((uint32_t)s_prev[k]);
+                uint32_t x0 = U(s_gv[2 * k]), x1 = U(s_gv[2 * k + 1]);
+                do_field(k, c, pv, x0, x1, vrow, first, (gmask >> k) & 1);
+                s_prev[k] = pv; s_gv[2 * k] = x0; s_gv[2 * k + 1] = x1;
             }
         }
         // byte-align behind the group (tasks.cpp:508): pos = wi * 32 - have
@@ -692,10 +728,28 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
     __syncthreads();
 }
 
-// One wave per sub-block: lane 0 walks the headers, the wave the length table, the title body and the two symbol streams.
-__global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
-                                                    uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
-                                                    DecSub *out, uint32_t lds_entries)
+// Narrower copy of a sub-block's per-position tables for LDS: Kl <= Kq bits (an entry whose code is longer than Kl bits
+// becomes 0 = "walk the tree").  Whole workgroup; returns Kl, or 0 when not even 6-bit tables fit (use the global ones).
+__device__ __forceinline__ uint32_t dec_fill_lds_table(uint16_t *s_qtab, uint32_t lds_entries, const uint16_t *qtab, uint32_t Kq, uint32_t rows)
+{
+    uint32_t Kl = Kq;
+    while (Kl > 5 && ((uint64_t)rows << Kl) > lds_entries) --Kl;
+    if (((uint64_t)rows << Kl) > lds_entries) return 0;
+    const uint32_t total = rows << Kl, sh = Kq - Kl;
+    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
+        const uint32_t row = k >> Kl, x = k & ((1u << Kl) - 1u);
+        const uint16_t e = qtab[((size_t)row << Kq) + (x << sh)];
+        s_qtab[k] = (e >> 12) <= Kl ? e : (uint16_t)0;
+    }
+    __syncthreads();
+    return Kl;
+}
+
+// One wave per sub-block: lane 0 walks the headers, the wave the length table and the title body.  Leaves the state of
+// the decode in ctl[s]: the quality stream is taken up by the speculative kernels (k_dec_qspec_*) or by the tail kernel.
+__global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
+                                                 uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
+                                                 DecSub *out, DecCtl *ctl, uint32_t allow_spec, uint32_t *summary)
 {
     const uint32_t s = blockIdx.x;
     if (s >= n_sb) return;
@@ -705,13 +759,9 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     __shared__ int32_t s_prev[DEC_MAX_FIELDS];
     __shared__ uint32_t s_gv[2 * DEC_MAX_FIELDS];
     __shared__ const uint16_t *s_tptr[DEC_TPTR_FIELDS * DEC_TPTR_POS];
-    __shared__ uint8_t s_map[256];
     __shared__ uint32_t s_in[DEC_IN_DW + 4];
-    __shared__ uint8_t s_out[DEC_OUT];
     __shared__ DecCtl C;
     __shared__ uint32_t s_nv[2];
-    __shared__ uint16_t s_dtab[1u << DEC_K];
-    extern __shared__ __align__(16) uint16_t s_qtab[];
     DecSub &O = out[s];
     BitIn r;
     r.init(sub + sb_off[s], sb_len[s]);
@@ -721,6 +771,8 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     const uint64_t t0 = wall_clock64();
     if (lane == 0) {
         O.err = OK; O.text_bytes = 0; O.n_rec = 0;
+        ctl[s].err = ERR_FORMAT;   // (overwritten with the whole state when the head has gone through)
+        C.spec = 0; C.spec_bad = 0;
         stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
         C.err = dec_info(r, D, O, rec_cap, C);
         if (C.err) O.err = C.err;
@@ -733,16 +785,21 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
         const uint32_t b = C.lt_bits, mq = C.max_q;
         const uint64_t lt0 = C.pos, nbytes = sb_len[s];
         uint64_t tot = 0;
-        uint32_t badl = 0;
+        uint32_t badl = 0, uneq = 0;
         for (uint32_t i = lane; i < n; i += 64) {
             const uint32_t L = dec_bits_at(r.p, nbytes, lt0 + (uint64_t)i * b, b);
             D.qlen[i] = L;
             tot += L;
             badl |= L > mq;
+            uneq |= L != mq;
         }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { tot += __shfl_xor(tot, d); badl |= (uint32_t)__shfl_xor((int)badl, d); }
+        for (int d = 32; d >= 1; d >>= 1) {
+            tot += __shfl_xor(tot, d); badl |= (uint32_t)__shfl_xor((int)badl, d); uneq |= (uint32_t)__shfl_xor((int)uneq, d);
+        }
         if (lane == 0) {
+            // every read has max_q qualities (and a record's codes fit the 16-bit hop of the speculative decoder)
+            C.spec = (allow_spec && !uneq && mq >= 1 && mq <= 2000) ? 1u : 0u;
             C.qual_total = tot;
             if (badl) C.err = ERR_FORMAT;
             else if (2 * tot > D.tcap) C.err = ERR_CAPACITY;
@@ -751,6 +808,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     }
     __syncthreads();
     if (C.err) return;
+    const uint64_t tp1 = wall_clock64();
     // ---- title header (lane 0), then the tables the body walk and the renderer work from ----
     if (lane == 0) {
         r.seek(C.pos + (uint64_t)n * C.lt_bits);
@@ -789,6 +847,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     }
     __syncthreads();
     if (C.err) return;
+    const uint64_t tp2 = wall_clock64();
     {
         const uint64_t vbytes = O.tchar_off;
         const uint64_t room = D.tcap - vbytes - 2 * C.qual_total;   // what is left for the text fields' characters (32 bytes kept for alignment)
@@ -796,6 +855,7 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
                             s_prev, s_gv, s_tptr);
     }
     if (C.err) { if (lane == 0) O.err = C.err; return; }
+    const uint64_t tp3 = wall_clock64();
     // ---- title length of every record (its place in the text needs it): constant fields and separators + the digits of its
     // numbers + its text fields' characters; every lane its share of the records ----
     {
@@ -820,21 +880,248 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
         for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
         if (lane == 0) O.text_bytes = tot + 2ull * C.qual_total + 4ull * n;
     }
-    // ---- quality alphabet and trees (lane 0) ----
+    const uint64_t tp4 = wall_clock64();
+    // ---- quality alphabet and trees (lane 0), then the state for the kernels behind this one ----
     if (lane == 0) {
+        O.t_ph[0] = tp1 - t0; O.t_ph[1] = tp2 - tp1; O.t_ph[2] = tp3 - tp2; O.t_ph[3] = tp4 - tp3;
         C.text += O.tchar_off;   // the value table and the characters
         r.seek(C.pos);
-        C.err = dec_head_quality(r, D, pool, s_map, s_qtab, lds_entries, C, stack);
+        C.err = dec_head_quality(r, D, pool, C.qsym, nullptr, 0, C, stack);
         if (C.err) O.err = C.err;
+        C.pool_off = pool.off;
+        C.t_head = wall_clock64() - t0;
+        O.t_ph[4] = wall_clock64() - tp4;
+        if (!C.err) {
+            // first phase of the speculative decoder: with two-bit bases the quality stream ends at or behind
+            // (end of the sub-block - alphabet - 2 bits per base of all reads); else nothing is known about its end
+            const uint64_t span = r.nbits - C.pos;
+            const uint64_t dna_max = 8ull * O.nsym + 2ull * C.n * C.max_q;
+            C.cov_lo = 0; C.chain_i = 0; C.chain_cur = 0;
+            C.cov_hi = (O.plain && dna_max + 64 < span) ? span - dna_max + 64 : span;
+            if (r.nbits >= (1ull << 31)) C.spec = 0;   // (the chain keeps 32-bit offsets)
+        }
     }
     __syncthreads();
     if (C.err) return;
-    const uint64_t t1 = wall_clock64();
-    uint8_t *d_qual = D.titles + D.lay[0], *d_seq = D.titles + D.lay[1];
-    if (C.q_lds) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
-    else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+    for (uint32_t k = lane; k < sizeof(DecCtl) / 4; k += 64) reinterpret_cast<uint32_t *>(&ctl[s])[k] = reinterpret_cast<const uint32_t *>(&C)[k];
+    if (lane == 0 && C.spec) atomicMax(&summary[0], C.max_q);   // the longest read the speculative kernels will meet: their LDS tables
+}
+
+// ---- the quality stream of equally long reads, decoded speculatively ------------------------------------------------------------
+// A sub-block's quality stream is one bit string of per-position Huffman codes: where a code starts depends on every code in
+// front of it, so one wave per sub-block decoded it serially (round 2: 115 ns per symbol, 0.3 s per 8 MiB window - the whole
+// decoder's speed at file sizes that do not fill the chip with sub-blocks).  When every read has the same number L of
+// qualities (the length table says so) the stream is a chain of RECORDS, each L codes from the trees 1..L, and the only
+// unknown of a record is the bit it starts at.  So:
+//   A  every bit offset b of the stream gets hop[b] = the bits a record would take if it started at b - L table lookups per
+//      offset, ~60 times more decoding than the stream holds, all of it independent (a lane per offset, the tables in LDS):
+//      milliseconds for the whole job, where the serial walk took hundreds;
+//   B  one wave per sub-block follows the chain of true record starts through hop[] (staged through LDS in order: a hop
+//      costs an LDS read, not a memory round trip) and writes them down;
+//   C  a lane per record decodes its L symbols from its start bit.
+// Anything the lookups cannot settle (a code longer than the LDS tables hold walks its tree; a record longer than the
+// 16-bit hop, a chain that leaves the stream) marks the sub-block spec_bad and the tail kernel decodes it serially.
+constexpr uint32_t QS_THREADS = 512;
+constexpr uint32_t QS_PER_THREAD = 16;                     // candidate offsets per thread and workgroup
+constexpr uint32_t QS_TILE = QS_THREADS * QS_PER_THREAD;   // offsets per workgroup
+constexpr uint32_t QS_INVALID = 0xFFFFu;
+
+// symbol lookups of one record from bit offset b of the stream p (global memory; bits behind the end read as zeros).
+// EMIT: store the symbols (bytes) to dst and count those below 128.  Returns the record's bits, or ~0u when it cannot tell.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t qs_record(const uint32_t *p32, uint32_t ndw, uint64_t b, uint32_t L, const uint16_t *s_tab, uint32_t Kl,
+                                              const DTree *qt, const uint8_t *qsym, uint8_t *dst, uint32_t *kept)
+{
+    uint32_t d = (uint32_t)(b >> 5);
+    const uint32_t sh = (uint32_t)(b & 31);
+    auto dw = [&](uint32_t k) -> uint32_t { return k < ndw ? __builtin_bswap32(p32[k]) : 0u; };
+    // the window as two dwords (hi: the next 32 bits of the stream, lo: those behind them; `have` bits are real, the rest
+    // zero): the codes the tables hold are at most 9 bits long, so a symbol costs 32-bit operations only - one funnel shift
+    // moves the window (64-bit shifts run at a fraction of the rate)
+    const uint64_t w0 = (((uint64_t)dw(d) << 32) | dw(d + 1)) << sh;
+    uint32_t hi = (uint32_t)(w0 >> 32), lo = (uint32_t)w0, have = 64 - sh, total = 0, kc = 0;
+    d += 2;
+    const uint32_t ksh = 32 - Kl;
+    for (uint32_t j = 0; j < L; ++j) {
+        const uint32_t e = s_tab[((j + 1) << Kl) + (hi >> ksh)];
+        uint32_t len, symb;
+        if (e) { len = e >> 12; symb = e & 0xffu; }
+        else {   // a code longer than the LDS table's width (or a one-symbol tree): walk the tree (global memory)
+            const DTree &T = qt[j + 1];
+            uint32_t node = T.root;
+            uint64_t w = ((uint64_t)hi << 32) | lo;
+            uint32_t hv = have, dd = d;
+            len = 0;
+            while (node >= T.n) {
+                if (len >= 32 || hv == 0) return ~0u;
+                node = (w >> 63) ? T.rc[node - T.n] : T.lc[node - T.n];
+                w <<= 1; --hv; ++len;
+                if (hv < 32) { w |= (uint64_t)dw(dd) << (32 - hv); hv += 32; ++dd; }
+            }
+            symb = qsym[node & 0xffu];
+        }
+        if (EMIT) { dst[j] = (uint8_t)symb; kc += symb < 128u; }
+        if (len) {
+            hi = len < 32 ? __builtin_amdgcn_alignbit(hi, lo, 32 - len) : lo;
+            lo = len < 32 ? lo << len : 0u;
+        }
+        have -= len;
+        total += len;
+        while (have <= 32) {   // the real bits are all in hi now
+            const uint32_t x = dw(d++);
+            hi |= have < 32 ? x >> have : 0u;
+            lo = have ? x << (32 - have) : 0u;
+            have += 32;
+        }
+    }
+    if (EMIT) *kept = kc;
+    return total;
+}
+
+// A: hop[b - q0] for the bit offsets q0 + [cov_lo, cov_hi) of a sub-block.  The stream's end is not known before it is
+// decoded; with two-bit bases it is at least (sub-block end - what the bases can take at most), which is what the first
+// phase covers; the chain kernel asks for more (records with transferred bases make the quality stream longer and the
+// base stream shorter) and later phases deliver it.
+__global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, const DecCtl *ctl,
+                                                            uint16_t *hop, const uint64_t *hop_off, uint32_t lds_entries)
+{
+    const uint32_t s = blockIdx.y;
+    const DecCtl &C = ctl[s];
+    if (C.err || C.spec != 1 || C.spec_bad) return;
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8, q0 = C.pos;
+    const uint64_t first = C.cov_lo + (uint64_t)blockIdx.x * QS_TILE;   // (relative to q0)
+    if (first >= C.cov_hi) return;
+    extern __shared__ __align__(16) uint16_t s_qtab[];
+    const uint32_t L = C.max_q;
+    const uint32_t Kl = dec_fill_lds_table(s_qtab, lds_entries, C.qtab, C.Kq, L + 1);
+    if (!Kl) return;   // (the chain kernel finds the hops missing: hop[] is cleared to "invalid" beforehand)
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(sub + sb_off[s]);
+    const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
+    uint16_t *h = hop + hop_off[s];
+    const uint64_t cov_hi = C.cov_hi;
+#pragma unroll 1
+    for (uint32_t o = 0; o < QS_PER_THREAD; ++o) {
+        const uint64_t rel = first + threadIdx.x + (uint64_t)o * QS_THREADS;
+        if (rel >= cov_hi) break;
+        const uint64_t b = q0 + rel;
+        const uint32_t t = qs_record<false>(p32, ndw, b, L, s_qtab, Kl, C.qt, C.qsym, nullptr, nullptr);
+        h[rel] = (t == ~0u || t >= QS_INVALID || b + t > nbits) ? (uint16_t)QS_INVALID : (uint16_t)t;
+    }
+}
+
+// B: the chain of record starts.  One wave per sub-block; hop[] comes through LDS in the order the chain reads it.
+// next_tiles: tiles the next phase of A will cover if the chain runs out of hops (0: there is no next phase).
+constexpr uint32_t QS_CHUNK = 8192;   // hops staged at a time (16 KB)
+__global__ __launch_bounds__(64) void k_dec_qspec_b(const uint32_t *sb_len, DecCtl *ctl, const uint16_t *hop, const uint64_t *hop_off,
+                                                    uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint32_t next_tiles)
+{
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    DecCtl &C = ctl[s];
+    if (C.err || C.spec != 1 || C.spec_bad) return;
+    __shared__ __align__(16) uint16_t s_h[QS_CHUNK];
+    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, 0);
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8, q0 = C.pos, span = nbits - q0;
+    const uint16_t *h = hop + hop_off[s];
+    auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    const uint32_t n = U(C.n);
+    const uint64_t cov_hi = ((uint64_t)U((uint32_t)(C.cov_hi >> 32)) << 32) | U((uint32_t)C.cov_hi);
+    uint64_t cur = ((uint64_t)U((uint32_t)(C.chain_cur >> 32)) << 32) | U((uint32_t)C.chain_cur), base = 0;   // relative to q0
+    uint32_t i = U(C.chain_i), bad = 0, more = 0;
+    bool staged = false;
+    for (; i < n; ++i) {
+        if (cur >= cov_hi) { more = 1; break; }   // hops not computed yet
+        if (!staged || cur - base >= QS_CHUNK) {
+            base = cur & ~7ull;   // 16-byte aligned loads
+            __syncthreads();
+            for (uint32_t t = lane; t < QS_CHUNK / 8; t += 64) {
+                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (base + 8ull * t + 8 <= span) v = *reinterpret_cast<const uint4 *>(h + base + 8ull * t);
+                else for (uint32_t k = 0; k < 8; ++k) if (base + 8ull * t + k < span) reinterpret_cast<uint16_t *>(&v)[k] = h[base + 8ull * t + k];
+                reinterpret_cast<uint4 *>(s_h)[t] = v;
+            }
+            __syncthreads();
+            staged = true;
+        }
+        D.rs[i] = (uint32_t)cur;
+        const uint32_t hp = U((uint32_t)s_h[cur - base]);
+        if (hp == QS_INVALID) { bad = 1; break; }
+        cur += hp;
+    }
+    if (lane == 0) {
+        if (bad || q0 + cur > nbits || (more && (!next_tiles || cov_hi >= span))) C.spec_bad = 1;
+        else if (more) {
+            C.chain_i = i; C.chain_cur = cur;
+            C.cov_lo = cov_hi;
+            const uint64_t want = cov_hi + (uint64_t)next_tiles * QS_TILE;
+            C.cov_hi = want < span ? want : span;
+        } else { D.rs[n] = (uint32_t)cur; C.pos = q0 + cur; C.spec = 2; }   // 2: all starts known, C takes over
+    }
+}
+
+// C: a lane per record
+__global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_c(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, DecCtl *ctl,
+                                                            uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint32_t lds_entries)
+{
+    const uint32_t s = blockIdx.y;
+    DecCtl &C = ctl[s];
+    if (C.err || C.spec != 2) return;
+    const uint32_t n = C.n, L = C.max_q;
+    if (blockIdx.x * QS_THREADS >= n) return;
+    extern __shared__ __align__(16) uint16_t s_qtab[];
+    const uint32_t Kl = dec_fill_lds_table(s_qtab, lds_entries, C.qtab, C.Kq, L + 1);
+    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, 0);
+    if (!Kl) { if (threadIdx.x == 0) atomicOr(&C.spec_bad, 1u); return; }
+    const uint32_t i = blockIdx.x * QS_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8;
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(sub + sb_off[s]);
+    // (C.pos is the stream's END by now: its start is end - rs[n])
+    const uint64_t q0 = C.pos - D.rs[n];
+    uint32_t kept = 0;
+    const uint32_t t = qs_record<true>(p32, (uint32_t)((nbits + 31) >> 5), q0 + D.rs[i], L, s_qtab, Kl, C.qt, C.qsym, D.titles + D.lay[0] + (uint64_t)i * L, &kept);
+    D.slen[i] = kept;
+    if (t != D.rs[i + 1] - D.rs[i]) atomicOr(&C.spec_bad, 1u);   // (cannot happen: A and C run the same lookups)
+}
+
+// One wave per sub-block, behind the head kernel (and the speculative quality kernels): the quality stream if it is still
+// to be decoded, then the bases.
+__global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
+                                                 uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
+                                                 DecSub *out, DecCtl *ctl, uint32_t lds_entries)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= n_sb) return;
+    const uint32_t lane = threadIdx.x;
+    __shared__ uint8_t s_map[256];
+    __shared__ uint32_t s_in[DEC_IN_DW + 4];
+    __shared__ uint8_t s_out[DEC_OUT];
+    __shared__ DecCtl C;
+    __shared__ uint16_t s_dtab[1u << DEC_K];
+    extern __shared__ __align__(16) uint16_t s_qtab[];
+    DecSub &O = out[s];
+    if (O.err) return;
+    for (uint32_t k = lane; k < sizeof(DecCtl) / 4; k += 64) reinterpret_cast<uint32_t *>(&C)[k] = reinterpret_cast<const uint32_t *>(&ctl[s])[k];
     __syncthreads();
     if (C.err) { if (lane == 0) O.err = C.err; return; }
+    BitIn r;
+    r.init(sub + sb_off[s], sb_len[s]);
+    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, qcap);
+    Pool pool = {D.pool, C.pool_off, D.pool_cap};
+    uint16_t *stack = nullptr;
+    if (lane == 0) stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
+    const uint32_t n = C.n;
+    const uint64_t t1 = wall_clock64();
+    uint8_t *d_qual = D.titles + D.lay[0], *d_seq = D.titles + D.lay[1];
+    if (!(C.spec == 2 && !C.spec_bad)) {   // the quality stream, serially
+        s_map[lane] = C.qsym[lane]; s_map[lane + 64] = C.qsym[lane + 64]; s_map[lane + 128] = C.qsym[lane + 128]; s_map[lane + 192] = C.qsym[lane + 192];
+        if (C.spec == 2 && lane == 0) C.pos -= D.rs[n];   // (the chain had moved it to the stream's end)
+        __syncthreads();
+        const uint32_t Kl = dec_fill_lds_table(s_qtab, lds_entries, C.qtab, C.Kq, C.max_q + 1);
+        if (Kl) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, Kl, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+        else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+        __syncthreads();
+        if (C.err) { if (lane == 0) O.err = C.err; return; }
+    }
 
     // ---- DNA (cf. FetchDNA tasks.cpp:957-1033): alphabet; a Huffman-coded alphabet is decoded here, two-bit codes by the assembly kernel ----
     const uint64_t t2 = wall_clock64();
@@ -872,7 +1159,8 @@ __global__ __launch_bounds__(64) void k_dec_streams(const uint8_t *sub, const ui
     }
     if (lane == 0) {
         O.dna_bitpos = C.pos;
-        O.t_head = t1 - t0; O.t_qual = t2 - t1; O.t_dna = wall_clock64() - t2;
+        O.t_head = C.t_head; O.t_qual = t2 - t1; O.t_dna = wall_clock64() - t2;
+        O.spec = (C.spec == 2 && !C.spec_bad) ? 1u : 0u;
     }
 }
 
@@ -901,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
         const uint32_t i = base + tid;
         const bool valid = i < O.n_rec;
         const uint32_t L = valid ? D.qlen[i] : 0, kept = valid ? D.slen[i] : 0;
-        const uint32_t tl = valid ? D.toff[i] : 0;   // title bytes of the record (k_dec_streams)
+        const uint32_t tl = valid ? D.toff[i] : 0;   // title bytes of the record (k_dec_head)
         // exclusive scans over the batch: text bytes, quality bytes, bases
         uint64_t tb = valid ? (uint64_t)tl + 2ull * L + 4 : 0, qb = L, bb = kept;
         uint64_t it = tb, iq = qb, ib = bb;
@@ -971,26 +1259,92 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
     }
 }
 
+size_t dec_ctl_bytes() { return sizeof(DecCtl); }
+uint32_t dec_qspec_tile() { return QS_TILE; }
+
+// head -> (speculative quality kernels) -> tail.  hop: 2 bytes per bit of the batch's sub-blocks (hop_off: each sub-block's
+// first entry), or nullptr: every quality stream is decoded serially by the tail kernel.  summary: one device word that
+// receives the longest read length among the sub-blocks the speculative kernels will take (0: none) - the host reads it
+// between the two calls and sizes their LDS tables with it (spec_max_q).
+static double dec_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void dec_lap(hipStream_t st, double &t0, const char *name)
+{
+    static const bool verbose = getenv("NGSC_VERBOSE") != nullptr;
+    if (!verbose) return;
+    (void)hipStreamSynchronize(st);
+    const double t1 = dec_now();
+    if (name) fprintf(stderr, "[ngsc decode] %-20s %8.2f ms\n", name, t1 - t0);
+    t0 = t1;
+}
+
+void launch_dec_head(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
+                     uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, bool allow_spec, uint32_t *summary)
+{
+    double t0 = 0;
+    dec_lap(st, t0, nullptr);
+    hipLaunchKernelGGL(k_dec_head, dim3(n_sb), dim3(64), 0, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap, (DecSub *)out,
+                       (DecCtl *)ctl, allow_spec ? 1u : 0u, summary);
+    dec_lap(st, t0, "k_dec_head");
+}
+
 void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
-                        uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out)
+                        uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, uint16_t *hop, const uint64_t *hop_off,
+                        uint32_t max_tiles, uint32_t spec_max_q)
 {
     const uint32_t lds_entries = 30u << 10;   // 60 KB of 16-bit table entries: the per-position tables of reads up to 59 bases
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_streams), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_entries));
-    hipLaunchKernelGGL(k_dec_streams, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
-                       (DecSub *)out, lds_entries);
+    double t0 = 0;
+    dec_lap(st, t0, nullptr);
+    if (hop && spec_max_q) {
+        // LDS of the speculative kernels: the tables of the batch's longest equal-length reads, as wide as 120 KB allow
+        // (what a workgroup does not use costs occupancy: 38 KB at 36 bases lets four workgroups share a CU)
+        const uint32_t lds_cap = 60u << 10, rows = spec_max_q + 1;
+        uint32_t K = DEC_K;
+        while (K > 5 && ((uint64_t)rows << K) > lds_cap) --K;
+        const uint32_t lds_spec = (uint32_t)std::min<uint64_t>(lds_cap, (uint64_t)rows << K);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_qspec_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_cap));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_qspec_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_cap));
+        // phases: what the first one leaves uncovered is small when few bases were transferred to the quality stream (each
+        // moves the stream's end by a few bits), so the next ones are small; the last takes whatever is left
+        const uint32_t phase_tiles[4] = {max_tiles, 16, 256, max_tiles};
+        for (int ph = 0; ph < 4; ++ph) {
+            hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), 2 * lds_spec, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
+                               hop, hop_off, lds_spec);
+            if (ph == 0) dec_lap(st, t0, "k_dec_qspec_a");
+            hipLaunchKernelGGL(k_dec_qspec_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off, scratch, stride, rec_cap, tcap,
+                               ph < 3 ? phase_tiles[ph + 1] : 0u);
+            if (ph == 0) dec_lap(st, t0, "k_dec_qspec_b");
+        }
+        dec_lap(st, t0, "k_dec_qspec a+b 1-3");
+        hipLaunchKernelGGL(k_dec_qspec_c, dim3((rec_cap + QS_THREADS - 1) / QS_THREADS, n_sb), dim3(QS_THREADS), 2 * lds_spec, st, sub, sb_off, sb_len,
+                           (DecCtl *)ctl, scratch, stride, rec_cap, tcap, lds_spec);
+        dec_lap(st, t0, "k_dec_qspec_c");
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_entries));
+    hipLaunchKernelGGL(k_dec_tail, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
+                       (DecSub *)out, (DecCtl *)ctl, lds_entries);
+    dec_lap(st, t0, "k_dec_tail");
 }
 
 void launch_dec_assemble(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch, uint64_t stride,
                          uint32_t rec_cap, uint64_t tcap, uint64_t qcap, const void *in, const uint64_t *text_off, uint8_t *text)
 {
+    static const bool verbose = getenv("NGSC_VERBOSE") != nullptr;
+    double t0 = 0;
+    if (verbose) { (void)hipStreamSynchronize(st); t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     hipLaunchKernelGGL(k_dec_assemble, dim3(n_sb), dim3(256), 0, st, sub, sb_off, n_sb, scratch, stride, rec_cap, tcap, qcap, (const DecSub *)in,
                        text_off, text);
+    if (verbose) {
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[ngsc decode] %-16s %8.2f ms\n", "k_dec_assemble",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0);
+    }
 }
 
 size_t dec_sub_bytes() { return sizeof(DecSub); }
 int32_t dec_sub_err(const void *h, uint32_t s) { return ((const DecSub *)h)[s].err; }
 uint64_t dec_sub_text(const void *h, uint32_t s) { return ((const DecSub *)h)[s].text_bytes; }
 uint32_t dec_sub_records(const void *h, uint32_t s) { return ((const DecSub *)h)[s].n_rec; }
-void dec_sub_ticks(const void *h, uint32_t s, uint64_t *t) { const DecSub &d = ((const DecSub *)h)[s]; t[0] = d.t_head; t[1] = d.t_qual; t[2] = d.t_dna; }
+uint32_t dec_sub_spec(const void *h, uint32_t s) { return ((const DecSub *)h)[s].spec; }
+void dec_sub_ticks(const void *h, uint32_t s, uint64_t *t) { const DecSub &d = ((const DecSub *)h)[s]; t[0] = d.t_head; t[1] = d.t_qual; t[2] = d.t_dna; for (int k = 0; k < 5; ++k) t[3 + k] = d.t_ph[k]; }
 
 }  // namespace ngsc
