@@ -401,7 +401,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(sizeof(fmask_t) * grp_cap), o_tbits = cr2.take(4 * slot_cap);
     const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
     const uint32_t tsep_words = max_title <= 64 ? 1u : 2u;
-    size_t o_tsep = cr2.take(8 * tsep_words * rec_cap), o_apos = cr2.take(8 * rec_cap);
+    size_t o_tsep = cr2.take(8 * tsep_words * rec_cap), o_apos = cr2.take(8 * rec_cap), o_bcnt = cr2.take(8 * rec_cap);
     rc = ensure(c, c->recs2, cr2.off);
     if (rc) return rc;
     uint8_t *rb2 = (uint8_t *)c->recs2.p;
@@ -476,6 +476,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.tsep = (uint64_t *)(rb2 + o_tsep);
     A.tsep_words = tsep_words;
     A.apos = (AmbPos *)(rb2 + o_apos);
+    A.bcnt = (uint64_t *)(rb2 + o_bcnt);
     A.gflags = (fmask_t *)(rb2 + o_gflags);
     A.wq = (uint32_t *)(pb + p_wq);
     A.wd = (uint32_t *)(pb + p_wd);

@@ -52,7 +52,7 @@ __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32
 // back with unaligned 16-byte LDS reads.  Same bytes, same logic behind the loads.  span_cap: bytes of LDS per wave,
 // >= 64 x the job's longest record + 48.
 template <bool BURST, bool STAGED>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
+__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
 {
     static_assert(!(BURST && STAGED), "the staged form is for short records");
     if (*A.err) return;
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         };
 
         // ---- one pass over the 16-byte chunks: everything except the ambiguous positions ----
+        const uint32_t b_t0 = t0, b_t1 = t1, b_t01 = t01, b_nok = nok;   // (the record's own base counts = what it adds to these)
         uint32_t fl = 0, namb = 0;   // N-transfer test (phyNGSC.cpp:549-571): bit0 some ambiguity code, bit1 a failure
         uint32_t nall = 0, apos0 = 0, apos1 = 0;   // non-ACGT bytes of the record and the positions of the first four
         // NBX chunks of a record per trip.  BURST: NB = 4 chunks (64 bytes) are fetched back to back and each is used as it
@@ -331,6 +332,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_stats_reg(Arena A, uint32_t l
         if (valid) {
             A.slen[g] = kept | ((nall < 7 ? nall : 7u) << 28) | ((uint32_t)xfer << 31);
             if (nall >= 1 && nall <= 4) A.apos[g] = AmbPos{apos0, apos1};
+            {   // A / C / T / G among the record's unambiguous bases, 16 bits each: with them the measure kernel prices a
+                // Huffman-coded base alphabet without reading the bases again
+                const uint32_t r0 = t0 - b_t0, r1 = t1 - b_t1, r01 = t01 - b_t01, rok = nok - b_nok;
+                A.bcnt[g] = (uint64_t)(rok - r0 - r1 + r01) | ((uint64_t)(r0 - r01) << 16) | ((uint64_t)(r1 - r01) << 32) | ((uint64_t)r01 << 48);
+            }
         }
         mq = L > mq ? L : mq;
         ms = kept > ms ? kept : ms;
@@ -421,7 +427,11 @@ struct SqTabs {
 // Rows of SQ_QS entries: column q - 33 for the bytes 33..80, column 48 always zero, SQ_QROWS_EXTRA zero rows behind the
 // table.  The lean paths of measure and pack replace every byte that has no entry (behind the end of the read, a
 // transferred quality) by SQ_QPAD: it reads the zero entry, and the 16 lookups of a chunk are straight-line code.
-constexpr uint32_t SQ_QS = SR_HCOLS + 1;
+// (round 3) Eight more columns, 49..56, hold the entries of the TRANSFERRED quality of an N (phyNGSC.cpp:579: 208 + (q - 33),
+// q = '!'..'('): the pack kernel turns the quality byte of a transferred N into q + 49 and looks it up like any other - N is
+// the ambiguity code sequencers write, and with 0.2 % of them nearly every wave-chunk of 150-base reads holds one.
+constexpr uint32_t SQ_NCOL0 = SR_HCOLS + 1;      // first of the eight transferred-N columns
+constexpr uint32_t SQ_QS = SR_HCOLS + 1 + 8;
 constexpr uint32_t SQ_QPAD = 0x51515151u;        // 33 + 48 in every byte
 constexpr uint32_t SQ_QROWS_EXTRA = 17;          // pad bytes of the last chunk, and the (q - 33) & 63 reach of the general path
 // (row_lo: the table holds the rows row_lo .. row_lo + lds_rows - 1 of the sub-block's table - the pack kernel walks long
@@ -436,8 +446,9 @@ __device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const S
     const uint32_t have = A.qrows > row_lo ? (A.qrows - row_lo < lds_rows ? A.qrows - row_lo : lds_rows) : 0;
     for (uint32_t k = threadIdx.x; k < have * nq; k += SR_THREADS) {
         const uint32_t row = k / nq, ci = k % nq;
-        const uint32_t col = (uint32_t)sb.qualities[ci] - 33u;
-        if (col < SR_HCOLS) {
+        const uint32_t qv = sb.qualities[ci];
+        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : qv - 33u;   // (208..215: a transferred N)
+        if (col < SR_HCOLS || (col >= SQ_NCOL0 && col < SQ_QS)) {
             const uint32_t e = qg[(size_t)(row_lo + row) * 256 + ci];
             s_qtab[row * SQ_QS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
         }
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         const bool xfer_d = sl >> 31;                 // for the DNA lengths: a transferred record drops its ambiguity codes
         const bool by_list = xfer_d && nall <= 4;
         const bool xfer = xfer_d && !by_list;         // for the quality lengths inside the chunk loop
-        const bool need_s = !plain || __any(xfer);   // bases matter for the Huffman DNA lengths and for the transferred positions
+        const bool need_s = __any(xfer);   // bases matter only where a record's transferred positions are not listed (more than four)
         uint32_t qb = 0, db = plain ? 2u * (sl & 0x0fffffffu) : 0u;
         // NB chunks are fetched back to back, see k_sq_stats_reg
         auto chunk = [&](const uint32_t ch, const uint4 S, const uint4 Q) __attribute__((always_inline)) {
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
             // ---- lean path (as in k_sq_pack_reg): the alphabet lies inside the table, two-bit bases (their bits are known from
             // the record's length), no record of the wave scans its bases for transferred positions, no byte with the high bit
             // set: sixteen straight-line lookups; bytes behind the read's end become the pad byte, which reads the zero column ----
-            if (lean_wg && plain && !__any(xfer) && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
+            if (lean_wg && !__any(xfer) && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
                 const bool tails = __any(nv != 16);
                 const uint32_t rbase = (16 * ch + 1) * SQ_QS - 33u;
                 uint32_t acc = 0;
@@ -596,25 +607,6 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     for (uint32_t b = 0; b < 4; ++b) qb += ((validm >> (4 * k + b)) & 1u) ? l[b] : 0u;
                 }
             }
-            // DNA bits of a Huffman-coded alphabet (more than four symbols, tasks.cpp:525-557)
-            if (!plain) {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!__any(nv > 4 * k)) continue;
-                    const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
-                    uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vm;
-                    if (__any((ambm >> (4 * k)) & 15u)) {
-#pragma unroll
-                        for (uint32_t b = 0; b < 4; ++b) {
-                            if ((ambm >> (4 * k + b)) & 1u) {
-                                const uint32_t ll = xfer_d ? 0u : (s_dcode[sr_byte(sw, 4 * k + b)] & 31u);
-                                l4 = (l4 & ~(0xffu << (8 * b))) | (ll << (8 * b));
-                            }
-                        }
-                    }
-                    db = __builtin_amdgcn_sad_u8(l4, 0u, db);
-                }
-            }
         };
         if constexpr (BURST) {
             for (uint32_t c4 = 0; __any(16 * NB * c4 < L); ++c4) {
@@ -661,6 +653,34 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 }
             }
         }
+        // DNA bits of a Huffman-coded alphabet (more than four symbols, tasks.cpp:525-557): the counts of A / C / T / G the
+        // statistics kernel left, times their code lengths; a record that keeps its ambiguity codes adds theirs (their
+        // positions are listed, or - more than four - the bases are read after all)
+        if (!plain) {
+            const uint64_t bc = valid ? A.bcnt[g] : 0ull;
+            db = (uint32_t)(bc & 0xffffu) * (ltab & 0xffu) + (uint32_t)((bc >> 16) & 0xffffu) * ((ltab >> 8) & 0xffu) +
+                 (uint32_t)((bc >> 32) & 0xffffu) * ((ltab >> 16) & 0xffu) + (uint32_t)(bc >> 48) * (ltab >> 24);
+            const bool keeps = valid && !xfer_d && nall != 0;
+            if (__any(keeps)) {
+                if (keeps && nall <= 4) {
+                    const AmbPos ap = A.apos[g];
+                    for (uint32_t k = 0; k < nall; ++k) {
+                        const uint32_t pos = ((k < 2 ? ap.x : ap.y) >> (16 * (k & 1))) & 0xffffu;
+                        db += s_dcode[A.buf[s0 + pos]] & 31u;
+                    }
+                } else if (keeps) {
+                    for (uint32_t ch = 0; 16 * ch < L; ++ch) {
+                        const uint32_t nv = L - 16 * ch < 16 ? L - 16 * ch : 16;
+                        const uint4 S = sq_chunk_load(A, A.dense_s, g, 16 * ch, s0);
+                        const uint32_t sw[4] = {S.x, S.y, S.z, S.w};
+                        const uint32_t ambm = sr_amb_mask(sw, nv);
+#pragma unroll
+                        for (uint32_t u = 0; u < 16; ++u)
+                            if ((ambm >> u) & 1u) db += s_dcode[sr_byte(sw, u)] & 31u;
+                    }
+                }
+            }
+        }
         const size_t tix = (size_t)A.tile_lo[s] + tile;
         A.ubits[tix * SR_THREADS + tid] = qb | (db << 16);
         const uint32_t wq = sr_wsum(qb), wd = sr_wsum(db);
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 
 // ---- pack ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
+__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
 {
     // win != 0 (long reads): the table holds one WINDOW of win positions (rows r0 .. r0 + win, lds_rows = win + 1), refilled
     // window after window for every tile - a [301][49] table plus staging left room for two workgroups per CU, a window
@@ -702,7 +722,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const uint32_t n_win = win ? (sb.max_q + win - 1) / win : 1u, win_chunks = win ? win / 16 : ~0u;   // (uniform over the workgroup)
     const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
-    const uint32_t eA = s_dcode['A'], eC = s_dcode['C'], eT = s_dcode['T'], eG = s_dcode['G'];
+    const uint32_t eA = s_dcode['A'], eC = s_dcode['C'], eT = s_dcode['T'], eG = s_dcode['G'], eN = s_dcode['N'];
     const uint32_t ltab = (eA & 31u) | ((eC & 31u) << 8) | ((eT & 31u) << 16) | ((eG & 31u) << 24);
     const uint32_t ctab = ((eA >> 5) & 0xffu) | (((eC >> 5) & 0xffu) << 8) | (((eT >> 5) & 0xffu) << 16) | (((eG >> 5) & 0xffu) << 24);
     // four Huffman base codes can be merged bytewise when each is at most 8 bits long
@@ -809,8 +829,22 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                             idx[k] = sr_idx(w);
                             dacc |= sr_not_acgt(w, idx[k]);
                         }
-                        uint32_t ambm = 0, keep[4] = {vmk[0], vmk[1], vmk[2], vmk[3]};
+                        // Are the wave's non-ACGT bytes of this chunk all N?  Then nothing is an exception: a transferred N is a
+                        // quality byte moved to the transferred-N columns and a base of length 0, a kept N a base with its own code
+                        // (per-lane table halves), both straight-line.  Other ambiguity codes take the masked path below.
+                        // ((w >> 1) & 7 maps A, C, T, G, N to 0, 1, 2, 3, 7: an eight-entry v_perm table holds all five)
+                        bool n_only = false;
                         if (__any(dacc != 0)) {
+                            uint32_t d5 = 0;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; ++k) {
+                                const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
+                                d5 |= __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, (w >> 1) & 0x07070707u) ^ w;
+                            }
+                            n_only = !__any(d5 != 0);
+                        }
+                        uint32_t ambm = 0, keep[4] = {vmk[0], vmk[1], vmk[2], vmk[3]};
+                        if (__any(dacc != 0) && !n_only) {
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
                                 const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
@@ -826,7 +860,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                         uint32_t e[16];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
-                            const uint32_t qm = masked ? ((qw[k] & keep[k]) | (SQ_QPAD & ~keep[k])) : qw[k];
+                            uint32_t qm = masked ? ((qw[k] & keep[k]) | (SQ_QPAD & ~keep[k])) : qw[k];
+                            if (n_only) {   // q -> q + 49 where a transferred record holds an N: column 49 + (q - 33)
+                                const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
+                                qm += xfer ? t_nonzero01(sr_not_acgt(w, idx[k])) * 49u : 0u;
+                            }
 #pragma unroll
                             for (uint32_t b = 0; b < 4; ++b) e[4 * k + b] = s_qtab[rbase + (4 * k + b) * SQ_QS + ((qm >> (8 * b)) & 0xffu)];
                         }
@@ -858,7 +896,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                             }
                         }
                         // DNA (tasks.cpp:544-557)
-                        if (plain && !__any(ambm != 0)) {
+                        if (plain && !__any(dacc != 0)) {
                             if (nv) {
                                 uint32_t x = 0;
 #pragma unroll
@@ -867,10 +905,13 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_pack_reg(Arena A, uint32_t ld
                                 wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
                             }
                         } else if (short_codes) {
+                            // (entry 7 of the eight-entry tables: N - nothing for a transferred record, which drops it)
+                            const uint32_t lhi = xfer ? 0u : (eN & 31u) << 24, chi = xfer ? 0u : ((eN >> 5) & 0xffu) << 24;
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
                                 if (!__any(nv > 4 * k)) continue;
-                                uint32_t l4 = __builtin_amdgcn_perm(0u, ltab, idx[k]) & vmk[k], c4 = __builtin_amdgcn_perm(0u, ctab, idx[k]) & vmk[k];
+                                const uint32_t i7 = ((((sw[k] & vmk[k]) | (0x41414141u & ~vmk[k])) >> 1) & 0x07070707u);
+                                uint32_t l4 = __builtin_amdgcn_perm(lhi, ltab, i7) & vmk[k], c4 = __builtin_amdgcn_perm(chi, ctab, i7) & vmk[k];
                                 if (__any((ambm >> (4 * k)) & 15u)) {
 #pragma unroll
                                     for (uint32_t b = 0; b < 4; ++b) {

@@ -265,6 +265,7 @@ struct Arena {
     const uint32_t *te, *se, *ls;   // record table: title end, sequence end, line start (ls has n+1 entries)
     uint32_t *slen;         // per record: post-transfer sequence length | non-ACGT count (0..6, 7 = more) << 28 | transfer flag << 31
     AmbPos *apos;           // per record with 1..4 non-ACGT bases: their positions, 16 bits each (k_sq_stats_reg)
+    uint64_t *bcnt;         // per record: A | C << 16 | T << 32 | G << 48 among its unambiguous bases (k_sq_stats_reg)
     uint32_t *qoff;         // per record: quality payload bits, then exclusive offsets
     uint32_t *doff;         // per record: DNA payload bits, then exclusive offsets
     uint32_t *goff;         // per title group: bytes, then exclusive offsets
