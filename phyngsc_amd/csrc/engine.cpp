@@ -43,7 +43,9 @@ struct ngsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t side_stream = nullptr;          // title kernels run here, beside the sequence/quality kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
+    size_t zero_hint = 0;         // bytes of the zero-initialised arena the last call used: cleared while the host waits for the cut list
+    uint64_t out_hint = 0;        // output bytes of the last call: that much of the output buffer is cleared beside the index kernels
     std::string hip_err;
     bool profiling = false;
     bool debug_sync = getenv("NGSC_DEBUG_SYNC") != nullptr;
@@ -197,10 +199,18 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return NGSC_ERR_HIP;
     ngsc_ctx *c = new ngsc_ctx();
     c->device = device_id;
+    // The side stream carries the latency-bound kernels of the staggered schedule (sub-block finalisation, Huffman waves, headers)
+    // beside a throughput kernel on the main stream: with a higher priority its few workgroups are dispatched as soon as a
+    // slot frees up instead of taking turns with tens of thousands of queued ones (NGSC_SIDE_PRIO=0: same priority)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char *pe = getenv("NGSC_SIDE_PRIO");
+    const int side_prio = (pe && !strcmp(pe, "0")) ? prio_lo : prio_hi;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, side_prio) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return NGSC_ERR_HIP;
     }
@@ -221,6 +231,7 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
     delete c;
 }
 
@@ -343,6 +354,15 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     uint8_t *rb = (uint8_t *)c->recs.p;
     uint32_t *d_te = (uint32_t *)(rb + o_te), *d_se = (uint32_t *)(rb + o_se), *d_ls = (uint32_t *)(rb + o_ls);
 
+    // (round 3) The output bytes of the step are cleared EARLY - while the host waits for the cut list and the GPU has nothing
+    // to do - as far as the previous call's output reached (jobs of one file are alike; the bench repeats one job);
+    // k_zero_output later clears only what lies beyond.
+    const char *ov_env = getenv("NGSC_OVERLAP");
+    const bool time_all = c->profiling && c->profile_only.empty();
+    uint64_t out_prefix = 0;
+    if (c->out_hint && !c->debug_sync && !getenv("NGSC_NO_EARLY_ZERO"))
+        out_prefix = std::min<uint64_t>(c->out_hint + (c->out_hint >> 6), out_cap) & ~15ull;
+
     // ---- stage A: line index ----
     {
         KScope k(c, st, "k_sync_first");
@@ -361,6 +381,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t plan_bytes = cs.off - o_plans;
     HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(hp + o_plans, sm + o_plans, plan_bytes, hipMemcpyDeviceToHost, st));
+    // (round 3) while the host waits: the zero-initialised arena of this call, as large as the last call needed it
+    void *const prezero_ptr = c->zero.p;
+    const size_t prezero = std::min(c->zero_hint, c->zero.cap);
+    if (prezero) HIPCHK(c, hipMemsetAsync(c->zero.p, 0, prezero, st));
+    if (out_prefix) { KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix); }
     HIPCHK(c, hipStreamSynchronize(st));
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
     const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
@@ -421,10 +446,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t z_qhist = cz.take(4 * (size_t)S * qrows * 256);
     size_t z_nhist = cz.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
     size_t z_chist = cz.take(4 * (size_t)n_slots * TEXT_TREES * 256);
+    size_t z_sb = cz.take(sizeof(SbState) * (size_t)S);   // (zero but for the four words k_init_sb writes)
     rc = ensure(c, c->zero, cz.off);
     if (rc) return rc;
     Carver cp;
-    size_t p_sb = cp.take(sizeof(SbState) * (size_t)S);
     size_t p_fdesc = cp.take(sizeof(FieldDesc) * (size_t)S * MAX_FIELDS);
     size_t p_grplo = cp.take(4 * (size_t)S);
     size_t p_qcodes = cp.take(4 * (size_t)S * qrows * 256);
@@ -462,7 +487,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t t_owner = ct.take(4 * (size_t)n_slots);
     rc = ensure(c, c->slots, ct.off);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->zero.p, 0, cz.off, st));
+    if (c->zero.p != prezero_ptr || cz.off > prezero) HIPCHK(c, hipMemsetAsync(c->zero.p, 0, cz.off, st));
+    c->zero_hint = cz.off;
 
     uint8_t *zb = (uint8_t *)c->zero.p, *pb = (uint8_t *)c->persb.p, *tb = (uint8_t *)c->slots.p;
     Arena A;
@@ -487,7 +513,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.rec0 = (Rec0Tab *)(pb + p_rec0);
     A.tile_lo = (uint32_t *)(pb + p_tilelo);
     A.err = d_err;
-    A.sb = (SbState *)(pb + p_sb);
+    A.sb = (SbState *)(zb + z_sb);
     A.fstat = (FieldStat *)(zb + z_fstat);
     A.fdesc = (FieldDesc *)(pb + p_fdesc);
     A.dna_occ = (uint32_t *)(zb + z_occ);
@@ -530,29 +556,20 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.out = (uint8_t *)d_out;
     uint32_t *d_qrowoff = (uint32_t *)(pb + p_qrowoff);
 
-    // host-initialised SbState + group offsets
+    // SbState (rec_lo, n_rec, rank, slot_bias; everything else zero), group and tile offsets per sub-block: written on the
+    // device from the cut list that is already there (round 3: k_init_sb instead of a host-built table and three copies in
+    // the gap behind the cut-list sync)
     size_t sb_bytes = sizeof(SbState) * (size_t)S;
     rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + o_first + 4096);
     if (rc) return rc;
     hp = (uint8_t *)c->h_pin;
     SbState *h_sb = (SbState *)hp;
-    uint32_t *h_grp = (uint32_t *)(hp + sb_bytes);
-    memset(h_sb, 0, sb_bytes);
-    uint32_t gacc = 0, slot_next = 0;
-    for (uint32_t s = 0; s < S; ++s) {
-        h_sb[s].rec_lo = cuts[s].rec_lo;
-        h_sb[s].slot_bias = slot_next - cuts[s].rec_lo;   // (mod 2^32)
-        slot_next += cuts[s].n_rec;
-        h_sb[s].n_rec = cuts[s].n_rec;
-        h_sb[s].rank = cuts[s].rank;
-        h_grp[s] = gacc;
-        gacc += (cuts[s].n_rec + GROUP - 1) / GROUP;
+    {
+        uint64_t gacc = 0;
+        for (uint32_t s = 0; s < S; ++s) gacc += (cuts[s].n_rec + GROUP - 1) / GROUP;
+        if (gacc > grp_cap) return NGSC_ERR_NOMEM;
     }
-    if (gacc > grp_cap) return NGSC_ERR_NOMEM;
-    HIPCHK(c, hipMemcpyAsync(A.sb, h_sb, sb_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(A.grp_lo, h_grp, 4 * (size_t)S, hipMemcpyHostToDevice, st));
-    memcpy(h_grp + S, tile_lo.data(), 4 * (size_t)S);
-    HIPCHK(c, hipMemcpyAsync(A.tile_lo, h_grp + S, 4 * (size_t)S, hipMemcpyHostToDevice, st));
+    { KScope k(c, st, "k_init_sb"); launch_init_sb(st, A, d_cuts, d_plans, n_ranks, max_cuts, R); }
 
     // ---- stage C: statistics, trees, measure.  The title chain and the sequence/quality chain share nothing
     // until the trees are built and can run on two streams. ----
@@ -574,9 +591,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         A.buf = (const uint8_t *)c->cscopy.p;
         A.cs_mode = 1;
     }
-    const char *ov_env = getenv("NGSC_OVERLAP");
     const bool overlap = ov_env && !strcmp(ov_env, "1");
-    const bool time_all = c->profiling && c->profile_only.empty();
     const bool stagger = (ov_env ? (!strcmp(ov_env, "2") || !strcmp(ov_env, "3")) : !time_all) && sq_reg && !c->debug_sync;
     hipStream_t st2 = overlap ? c->side_stream : st;
     hipStream_t sts = stagger ? c->side_stream : st;   // the sequence/quality chain's stream behind its statistics kernel
@@ -653,16 +668,26 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
     { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
     // ---- sizes and layout are on the device now; their copies for the host travel behind the pack kernels (no sync here) ----
-    HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, st));
+    // (staggered: the copies, the headers and the length tables beside the output clearing and the title pack kernel)
+    if ((rc = fork_s())) return rc;
+    HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, sts));
+    HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, sts));
     // ---- pack ----
-    { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap); }
-    if ((rc = fork_s())) return rc;   // (staggered: headers and length tables beside the title pack kernel)
+    { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap, out_prefix); }
+    if (stagger) {   // the side stream's kernels write into the cleared output
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(sts, c->ev_fork, 0));
+    }
     { KScope k(c, sts, "k_write_headers"); launch_write_headers(sts, A, d_qrowoff); }
     { KScope k(c, sts, "k_pack_lentable"); launch_pack_lentable(sts, A, max_rec); }
+    // (round 3) staggered: the title pack kernel - latency-bound, 0.11 ms alone - follows the headers on the side stream, BESIDE the
+    // payload pack kernel, which starts as soon as the output is clear (they write different streams of the sub-blocks);
+    // NGSC_TPACK_ALONE=1: round 2's order, title pack in front of the payload pack
+    static const bool tpack_alone = getenv("NGSC_TPACK_ALONE") != nullptr;
+    const bool tpack_side = stagger && !tpack_alone;
     if ((rc = fork())) return rc;
-    { KScope k(c, st2, "k_title_pack_reg"); launch_title_pack_reg(st2, A, max_rec); }
-    if ((rc = join_s())) return rc;
+    { hipStream_t tps = tpack_side ? sts : st2; KScope k(c, tps, "k_title_pack_reg"); launch_title_pack_reg(tps, A, max_rec); }
+    if (!tpack_side && (rc = join_s())) return rc;
     if (sq_reg) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
         // length, + 10 % (from the record count: no stream size has to come back to the host first; a tile that needs
@@ -679,6 +704,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    if (tpack_side && (rc = join_s())) return rc;
     if ((rc = join())) return rc;
     // ---- the one sync behind the cut list: error word, sizes, result tables ----
     uint8_t *hfin = hp + sb_bytes + o_first + 64;
@@ -688,6 +714,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);   // state behind the layout kernels
     const uint64_t total = *(uint64_t *)(hp + sb_bytes + o_outtot);
     c->res_bytes = total;
+    c->out_hint = total;
     if (err3 == NGSC_ERR_UNSUPPORTED && !c->slot_retry) {
         const uint32_t asked = *(uint32_t *)(hp + sb_bytes + o_slotc);
         if (asked > n_slots) {
@@ -747,7 +774,9 @@ int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
 {
     PlanResume from;
     memset(&from, 0, sizeof from);
-    return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, nullptr);
+    const int rc = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, nullptr);
+    if (rc != NGSC_OK && c && c->side_stream) (void)hipStreamSynchronize(c->side_stream);   // (the early clearing of d_out may still run)
+    return rc;
 }
 
 int ngsc_compress_rank_part(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size, uint32_t P,
@@ -760,7 +789,9 @@ int ngsc_compress_rank_part(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, ui
         from.resume = 1; from.next_pos = state->next_pos; from.bytes_read = state->bytes_read; from.bsize = state->bsize;
         from.overlap = state->overlap;
     }
-    return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank, rank + 1, d_out, out_cap, hip_stream, from, state);
+    const int rc = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank, rank + 1, d_out, out_cap, hip_stream, from, state);
+    if (rc != NGSC_OK && c && c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    return rc;
 }
 
 }  // extern "C"

@@ -58,13 +58,9 @@ __device__ void build_tree_wave(Tree &T, uint32_t n)
 
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
-template <bool SMALL>
-__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0)
+template <bool SMALL, class Tree>
+__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t)
 {
-    if (*A.err) return;
-    using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
-    __shared__ Tree T;
-    const uint32_t s = blockIdx.y, t = blockIdx.x + t0;
     const int lane = threadIdx.x;
     const SbState &sb = A.sb[s];
     const bool fits_small = sb.nqual <= SMALL_TREE && sb.nsym <= SMALL_TREE;
@@ -116,6 +112,23 @@ __global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0)
     }
 }
 
+// Trees t0 .. t0 + nt - 1 of every sub-block, dealt to the workgroups in turn.  The 512-symbol instance is launched with a
+// small grid: its 26 KB of LDS per (single-wave) workgroup must be free on a CU before a workgroup can even find out that
+// its sub-block's alphabets fit the small instance and it has nothing to do - 4560 such workgroups queued behind the title
+// statistics kernel's LDS for 260 us of the staggered schedule, and the measure kernel behind them (round 3).
+template <bool SMALL>
+__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt)
+{
+    if (*A.err) return;
+    using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
+    __shared__ Tree T;
+    const uint32_t pairs = nt * A.n_sb;
+    for (uint32_t p = blockIdx.x; p < pairs; p += gridDim.x) {
+        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt);
+        __syncthreads();   // (T is used again)
+    }
+}
+
 // Text-field trees: grid (129, TEXT_GRID_Y); each workgroup row walks the used slots with stride
 // gridDim.y (the slot count lives on the device).  Tree j of a field exists iff text_tree_needed().
 constexpr uint32_t TEXT_GRID_Y = 64;
@@ -144,22 +157,33 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A)
     }
 }
 
+// big_grid: workgroups of the 512-symbol instance
+static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uint32_t t0, uint32_t nt, uint32_t big_grid = 1024)
+{
+    const uint32_t pairs = nt * A.n_sb;
+    if (!pairs) return;
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3(pairs), dim3(64), 0, st, A, t0, nt);
+    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt);
+}
+
 void launch_huffman_sb(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
-    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1 + MAX_FIELDS, A.n_sb), dim3(64), 0, st, A, 0u);
+    launch_huffman_range(st, A, true, 0, A.qrows + 1);
+    launch_huffman_range(st, A, false, 0, A.qrows + 1 + MAX_FIELDS);
 }
 
 // The same trees in two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
 // sequence/quality statistics only, the numeric title field trees the title statistics only.
 void launch_huffman_sq(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_huffman_sb<true>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
-    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(A.qrows + 1, A.n_sb), dim3(64), 0, st, A, 0u);
+    launch_huffman_range(st, A, true, 0, A.qrows + 1);
+    // (quality alphabets of more than 64 symbols are rare: a workgroup per CU - each needs 26 KB of LDS that the title statistics
+    // kernel beside it is holding, and a thousand of them took 166 us to find out that they had nothing to do)
+    launch_huffman_range(st, A, false, 0, A.qrows + 1, 256);
 }
 void launch_huffman_fields(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_huffman_sb<false>, dim3(MAX_FIELDS, A.n_sb), dim3(64), 0, st, A, A.qrows + 1);
+    launch_huffman_range(st, A, false, A.qrows + 1, MAX_FIELDS);
 }
 
 void launch_huffman_text(hipStream_t st, const Arena &A)

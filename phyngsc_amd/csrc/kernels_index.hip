@@ -143,39 +143,47 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint32_t *nl_ma
                                                            const uint32_t *tile_off, uint32_t *te, uint32_t *se,
                                                            uint32_t *ls, uint32_t rec_cap)
 {
-    __shared__ uint32_t s_wave[TILE_THREADS / 64];
+    __shared__ uint32_t s_wave[2][TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = start;
     uint32_t line_base = tile_off[blockIdx.x];
-    for (uint32_t pc = 0; pc < PIECES; ++pc) {
-        const uint32_t base = blockIdx.x * TILE_BYTES + pc * PIECE_BYTES + threadIdx.x * BYTES_PER_THREAD;
-        uint32_t m = nl_mask[base / BYTES_PER_THREAD];   // (the mask array covers whole tiles)
-        const uint32_t c = (uint32_t)__popc(m);
-        uint32_t incl = wave_scan_incl(c);
-        __syncthreads();  // s_wave of the previous piece has been consumed
-        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-        __syncthreads();
+    // (round 3) four mask words - 128 input bytes, four or five newlines of a short-read file - per thread and round: two scans and
+    // two barriers per 64 KiB tile instead of eight of each (0.083 -> ms per GB see DESIGN.md)
+    constexpr uint32_t WPT = 4, ROUNDS = TILE_BYTES / (TILE_THREADS * WPT * 32);
+    static_assert(ROUNDS * TILE_THREADS * WPT * 32 == TILE_BYTES, "a tile is a whole number of rounds");
+#pragma unroll
+    for (uint32_t pc = 0; pc < ROUNDS; ++pc) {
+        const uint32_t widx = (blockIdx.x * ROUNDS + pc) * (TILE_THREADS * WPT) + threadIdx.x * WPT;   // (the mask array covers whole tiles)
+        const uint4 mm = *reinterpret_cast<const uint4 *>(nl_mask + widx);
+        uint32_t m[WPT] = {mm.x, mm.y, mm.z, mm.w};
+        const uint32_t c = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+        const uint32_t incl = wave_scan_incl(c);
+        if ((threadIdx.x & 63) == 63) s_wave[pc & 1][threadIdx.x >> 6] = incl;
+        __syncthreads();   // (two buffers: the next round's writes cannot overtake this round's reads)
         uint32_t wbase = 0, total = 0;
 #pragma unroll
         for (uint32_t w = 0; w < TILE_THREADS / 64; ++w) {
-            if (w < (threadIdx.x >> 6)) wbase += s_wave[w];
-            total += s_wave[w];
+            if (w < (threadIdx.x >> 6)) wbase += s_wave[pc & 1][w];
+            total += s_wave[pc & 1][w];
         }
         uint32_t line = line_base + wbase + incl - c;
         line_base += total;
-        // one bit per byte of the thread's 32 bytes, then a single walk over the set bits (a 36-bp record has a
-        // newline every ~29 bytes, so the walk is 1-2 steps; eight separate per-word walks cost 4x the VALU work)
-        while (m) {
-            const uint32_t k = (uint32_t)__ffs(m) - 1;
-            m &= m - 1;
-            const uint32_t pos = base + k;
-            const uint32_t r = line >> 2, kind = line & 3;
-            if (r < rec_cap) {
-                if (kind == 0) te[r] = pos;
-                else if (kind == 1) se[r] = pos;
-                else if (kind == 3) ls[r + 1] = pos + 1;
+#pragma unroll
+        for (uint32_t k4 = 0; k4 < WPT; ++k4) {
+            const uint32_t base = (widx + k4) * 32;
+            uint32_t x = m[k4];
+            while (x) {
+                const uint32_t k = (uint32_t)__ffs(x) - 1;
+                x &= x - 1;
+                const uint32_t pos = base + k;
+                const uint32_t r = line >> 2, kind = line & 3;
+                if (r < rec_cap) {
+                    if (kind == 0) te[r] = pos;
+                    else if (kind == 1) se[r] = pos;
+                    else if (kind == 3) ls[r + 1] = pos + 1;
+                }
+                ++line;
             }
-            ++line;
         }
     }
 }
@@ -189,15 +197,26 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
 {
     uint32_t mq = 0, mr = 0, mt = 0;
     bool bad = false;
-    for (uint32_t r = first; r < n_rec; r += stride) {
-        const uint32_t t = te[r], s = se[r], l0 = ls[r], l1 = ls[r + 1];
+    auto one = [&](uint32_t t, uint32_t s, uint32_t l0, uint32_t l1) __attribute__((always_inline)) {
         const uint32_t L = s - t - 1, RB = l1 - l0, TL = t - l0 + 1;
         // the bare '+' line is checked by the statistics kernels, which read the bytes anyway
         bad = bad || !(t >= l0 && s > t) || l1 != 2 * s - t + 3;
         mq = L > mq ? L : mq;
         mr = RB > mr ? RB : mr;
         mt = TL > mt ? TL : mt;
+    };
+    // four consecutive records per thread and trip, their table entries with 16-byte loads (round 3: 0.068 -> ms)
+    const uint32_t n4 = n_rec & ~3u;
+    for (uint32_t r = 4 * first; r < n4; r += 4 * stride) {
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(te + r), s4 = *reinterpret_cast<const uint4 *>(se + r);
+        const uint4 l4 = *reinterpret_cast<const uint4 *>(ls + r);
+        const uint32_t l5 = ls[r + 4];
+        one(t4.x, s4.x, l4.x, l4.y);
+        one(t4.y, s4.y, l4.y, l4.z);
+        one(t4.z, s4.z, l4.z, l4.w);
+        one(t4.w, s4.w, l4.w, l5);
     }
+    if (first == 0) for (uint32_t r = n4; r < n_rec; ++r) one(te[r], se[r], ls[r], ls[r + 1]);
     if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -273,6 +292,7 @@ struct WaveSearch {
         pair(a, n, key, a, 0, 0, 0, n, r0, r1);
         return r0;
     }
+    __device__ uint32_t at(const uint32_t *a, uint32_t idx) const { return a[idx]; }
     // hint: where both bounds are expected, as a distance from lo (the previous window's record count; windows of one
     // file hold nearly the same number of records).  The first round then probes 64 positions around lo + hint, a
     // 1/2048 of hint apart: if the bound lies between two of them - it nearly always does - one more round finishes
@@ -321,6 +341,77 @@ struct WaveSearch {
     }
 };
 
+// (round 3) The planner's chain - window k+1 starts at the first record behind window k's stop position - is serial, and
+// every link used to cost three dependent trips to memory (two search rounds, then ls[last + 1]): 15 windows of a 125 MB
+// rank took 65-95 us, the tail of the index phase.  But the links are predictable: a window stops 8 MiB - 500 B behind
+// its start and starts at most one record behind the previous stop, so window k's stop lies within k records' bytes behind
+// x0 + (k + 1) * (8 MiB - 500).  The rank's four waves look those places up IN PARALLEL first (a search each, hinted by
+// the job's record density) and park PL_ENT record-table entries around each in LDS; the chain then runs out of LDS.
+// Whatever the cache does not hold (long records, later windows of a long rank) is searched in memory as before.
+constexpr uint32_t PL_WIN = 24;     // windows looked up ahead per rank
+constexpr uint32_t PL_ENT = 128;    // record table entries parked per window (two per lane)
+struct PlanCache {
+    uint32_t ls[PL_WIN][PL_ENT], te[PL_WIN][PL_ENT];
+    uint32_t base[PL_WIN];          // record index of entry 0; 0xffffffff: nothing parked
+};
+
+struct CachedSearch {
+    const PlanCache *pc;
+    const uint32_t *te_ptr, *ls_ptr;
+    uint32_t nwin;
+    mutable uint32_t next;          // the stretch the next window's bounds are expected in
+    WaveSearch ws;
+    __device__ uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const { return ws.one(a, n, key); }
+    // lower bound of key among the parked entries of stretch k, if they decide it (sorted; entries behind the table's end are ~0)
+    __device__ bool lookup(const uint32_t (*tab)[PL_ENT], uint32_t k, uint64_t key, uint32_t &res) const
+    {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t v0 = tab[k][lane], v1 = tab[k][lane + 64];
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)v0, 0), last = (uint32_t)__builtin_amdgcn_readlane((int)v1, 63);
+        if (!((uint64_t)first < key && key <= (uint64_t)last)) return false;
+        res = pc->base[k] + (uint32_t)__popcll(__ballot((uint64_t)v0 < key)) + (uint32_t)__popcll(__ballot((uint64_t)v1 < key));
+        return true;
+    }
+    __device__ void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
+                         uint32_t span, uint32_t &ra, uint32_t &rb, uint32_t hint = 0) const
+    {
+        bool ha = false, hb = false;
+        uint32_t fa = 0, fb = 0;
+        if (a == te_ptr && b == ls_ptr) {
+            for (uint32_t t = 0; t < 2 && !(ha && hb); ++t) {
+                const uint32_t k = next + t;
+                if (k >= nwin || pc->base[k] == 0xffffffffu) break;
+                if (!ha) ha = lookup(pc->te, k, ka, fa);
+                if (!hb) hb = lookup(pc->ls, k, kb, fb);
+            }
+        }
+        ++next;
+        if (ha && hb) {
+            const uint32_t la = lo < na ? lo : na, hia = (uint64_t)lo + span < na ? lo + span : na;
+            const uint32_t lb = lo < nb ? lo : nb, hib = (uint64_t)lo + span < nb ? lo + span : nb;
+            ra = fa < la ? la : (fa > hia ? hia : fa);
+            rb = fb < lb ? lb : (fb > hib ? hib : fb);
+            return;
+        }
+        ws.pair(a, na, ka, b, nb, kb, lo, span, ra, rb, hint);
+    }
+    __device__ uint32_t at(const uint32_t *a, uint32_t idx) const
+    {
+        if (a == ls_ptr) {
+            for (uint32_t t = 0; t < 2; ++t) {   // (the window just planned: stretch next - 1, or the one behind it)
+                const uint32_t k = next - 1 + t;
+                if (next == 0 || k >= nwin) continue;
+                const uint32_t b0 = pc->base[k];
+                if (b0 != 0xffffffffu && idx >= b0 && idx - b0 < PL_ENT) {
+                    const uint32_t v = pc->ls[k][idx - b0];
+                    if (v != 0xffffffffu) return v;
+                }
+            }
+        }
+        return a[idx];
+    }
+};
+
 // One launch, two jobs that do not depend on each other: workgroups [0, n_ranks) plan the sub-block cuts of
 // one rank each (a serial chain of binary searches over the record table, see plan_rank()), the others
 // validate the structure of every record and reduce the job-wide maxima while those chains run.
@@ -339,9 +430,44 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
     if (tail_buf && blockIdx.x == n_ranks && threadIdx.x == 0 && (*total_lines & 3u) == 3u && tail_buf[ls[n_rec_total]] != '\n')
         atomicMin(err, (int32_t)ERR_FORMAT);
     if (blockIdx.x < n_ranks) {
-        if (threadIdx.x >= 64) return;   // one wave per rank; all lanes run the (uniform) planner, the searches are wave-wide
         const uint32_t i = blockIdx.x;
-        int rc = plan_rank_with(WaveSearch(), file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
+        __shared__ PlanCache s_pc;
+        const RankGeom g = rank_geometry(file_size, P, rank_lo + i);
+        uint32_t nwin = 0;
+        {
+            // stop position of window k, were every window to start exactly where the one before stopped
+            const uint64_t x0 = from.resume ? from.next_pos : (uint64_t)g.wr_start;   // (a rank's first window starts with its region)
+            const uint64_t bs = from.resume ? from.bsize : (uint64_t)g.bsize, ov = from.resume ? from.overlap : g.overlap;
+            const uint64_t D = bs > ov ? bs - ov : 0;
+            const uint64_t n_ls = (uint64_t)n_rec_total + 1;
+            const uint32_t last_ls = ls[n_rec_total];
+            if (bs == WINDOW && D && x0 >= buf_off && n_rec_total > 256) {
+                const uint64_t w = ((uint64_t)g.region + D - 1) / D + 1;
+                nwin = w < PL_WIN ? (uint32_t)w : PL_WIN;
+            }
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            for (uint32_t k = wave; k < nwin; k += 4) {
+                const uint64_t key = x0 - buf_off + (uint64_t)(k + 1) * D;
+                uint32_t b0 = 0xffffffffu;
+                if (key <= (uint64_t)last_ls) {
+                    // where the job's record density puts the bound; the probes of the first round lie around it
+                    const uint64_t guess = key * n_rec_total / ((uint64_t)last_ls + 1);
+                    uint32_t r0, r1;
+                    WaveSearch().pair(ls, (uint32_t)n_ls, key, ls, (uint32_t)n_ls, key, 0, (uint32_t)n_ls, r0, r1, (uint32_t)guess);
+                    b0 = r0 >= 8 ? r0 - 8 : 0;
+                    for (uint32_t j = lane; j < PL_ENT; j += 64) {
+                        const uint64_t e = (uint64_t)b0 + j;
+                        s_pc.ls[k][j] = e < n_ls ? ls[e] : 0xffffffffu;
+                        s_pc.te[k][j] = e < n_rec_total ? te[e] : 0xffffffffu;
+                    }
+                }
+                if (lane == 0) s_pc.base[k] = b0;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64) return;   // one wave per rank runs the chain; all its lanes run the (uniform) planner, the searches are wave-wide
+        CachedSearch cs{&s_pc, te, ls, nwin, 0, WaveSearch()};
+        int rc = plan_rank_with(cs, file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
                                 cuts + (size_t)i * max_cuts, max_cuts, &plans[i], &from, buf_end_abs);
         // ... and behind the first record of a window the loop does not skip that byte (phyNGSC.cpp:295-300): there two
         // blank lines qualify as well

@@ -375,19 +375,100 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_sq(Arena A, uint32_t lds_en
 
 // Zeroes the part of the output buffer that the sub-blocks will occupy (its size is on the device: no host round trip).
 // Shared words - the first / last word of a tile, a record, a stream - are merged with atomicOr by the pack kernels.
-__global__ __launch_bounds__(256) void k_zero_output(uint4 *out, const uint64_t *total_ptr, uint64_t out_cap)
+// from16: 16-byte units at the front that are zero already (cleared early by k_zero_range, beside the index kernels)
+__global__ __launch_bounds__(256) void k_zero_output(uint4 *out, const uint64_t *total_ptr, uint64_t out_cap, uint64_t from16)
 {
     uint64_t total = *total_ptr;
     if (total > out_cap) total = out_cap;
     const uint64_t n16 = (total + 15) >> 4;
+    for (uint64_t k = from16 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (uint64_t)gridDim.x * blockDim.x)
+        out[k] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_zero_range(uint4 *out, uint64_t n16)
+{
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += (uint64_t)gridDim.x * blockDim.x)
         out[k] = make_uint4(0, 0, 0, 0);
 }
 
-// ---- launchers ---------------------------------------------------------------------------------------
-void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap)
+// SbState of every sub-block (rec_lo, n_rec, rank, slot_bias; the rest is zero already), its first title group and its first tile, from
+// the cut list the planner left on the device (engine.cpp built these on the host and copied them over until round 3).
+// One workgroup; a thread takes a rank: totals of its cuts, workgroup scan, then its cuts again.
+__global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R)
 {
-    hipLaunchKernelGGL(k_zero_output, dim3(4096), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), total_ptr, out_cap & ~15ull);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (the SbState array lies in the arena the engine clears for every call: only the non-zero words are written here)
+    __shared__ uint32_t s_w[4][4];
+    uint32_t base[4] = {0, 0, 0, 0};   // sub-blocks, record slots, title groups, tiles of the ranks in front (workgroup-uniform)
+    for (uint32_t r0 = 0; r0 < n_ranks; r0 += 256) {
+        const uint32_t i = r0 + tid;
+        const uint32_t nc = i < n_ranks ? (plans[i].n_cuts < max_cuts ? plans[i].n_cuts : max_cuts) : 0;
+        uint32_t v[4] = {nc, 0, 0, 0};
+        for (uint32_t k = 0; k < nc; ++k) {
+            const uint32_t n = cuts[(size_t)i * max_cuts + k].n_rec;
+            v[1] += n;
+            v[2] += (n + GROUP - 1) / GROUP;
+            v[3] += R ? (n + R - 1) / R : 0;
+        }
+        uint32_t ex[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            uint32_t incl = v[q];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if ((int)lane >= d) incl += o;
+            }
+            if (lane == 63) s_w[q][wave] = incl;
+            ex[q] = incl - v[q];
+        }
+        __syncthreads();
+        uint32_t tot[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            tot[q] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (w < wave) ex[q] += s_w[q][w];
+                tot[q] += s_w[q][w];
+            }
+            ex[q] += base[q];
+            base[q] += tot[q];
+        }
+        __syncthreads();   // s_w is written again in the next round
+        uint32_t s = ex[0], slot = ex[1], grp = ex[2], tile = ex[3];
+        for (uint32_t k = 0; k < nc && s < A.n_sb; ++k, ++s) {
+            const Cut c = cuts[(size_t)i * max_cuts + k];
+            SbState &x = A.sb[s];
+            x.rec_lo = c.rec_lo;
+            x.n_rec = c.n_rec;
+            x.rank = c.rank;
+            x.slot_bias = slot - c.rec_lo;   // (mod 2^32)
+            A.grp_lo[s] = grp;
+            A.tile_lo[s] = tile;
+            slot += c.n_rec;
+            grp += (c.n_rec + GROUP - 1) / GROUP;
+            tile += R ? (c.n_rec + R - 1) / R : 0;
+        }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap, uint64_t cleared)
+{
+    // (a step whose front is clear already usually has nothing left to clear: a small grid then)
+    hipLaunchKernelGGL(k_zero_output, dim3(cleared ? 256 : 4096), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), total_ptr, out_cap & ~15ull,
+                       cleared >> 4);
+}
+
+void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes)
+{
+    hipLaunchKernelGGL(k_zero_range, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), bytes >> 4);
+}
+
+void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R)
+{
+    hipLaunchKernelGGL(k_init_sb, dim3(1), dim3(256), 0, st, A, cuts, plans, n_ranks, max_cuts, R);
 }
 
 static uint32_t lds_entries_for(uint32_t qrows)

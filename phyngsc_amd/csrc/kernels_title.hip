@@ -182,6 +182,10 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
             if (is_sep(T.title[p])) T.sepm[p >> 5] |= 1u << (p & 31);
             if (T.title[p] >= '0' && T.title[p] <= '9') T.digm[p >> 5] |= 1u << (p & 31);
         }
+        for (uint32_t f = 0; f < nf0 && f < MAX_FIELDS; ++f) {
+            T.fdw[f][0] = (uint32_t)T.start[f] | ((uint32_t)T.len[f] << 16);
+            T.fdw[f][1] = (uint32_t)T.kmap[f] | ((uint32_t)T.ovf0[f] << 8) | ((uint32_t)T.woff[f] << 16);
+        }
         T.nf0 = nf0;
         T.ncand = ncand;
         A.sb[s].nf = nf0;
@@ -358,6 +362,34 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
     }
 }
 
+// The group's flag bits and their constancy, walked over the sub-block's NON-CONSTANT fields only (kf_field, in field order -
+// the order tasks.cpp:401-425 writes them in): same results as title_group_const / title_put_flags, which visit every field.
+__device__ __forceinline__ fmask_t t_group_const_kf(const FieldDesc *fd, const uint8_t *kf_field, uint32_t ncf, TitleDiffs g, uint32_t group_size)
+{
+    fmask_t gconst = 0;
+#pragma unroll
+    for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+        if (kf >= ncf) break;
+        const uint32_t f = kf_field[kf];
+        const FieldDesc &d = fd[f];
+        uint32_t flag;
+        if (d.kind == KIND_TEXT) flag = !((g.txt >> f) & 1);
+        else if (d.delta_coding) flag = group_size == 1 ? (d.min_d == 0) : !((g.dlt >> f) & 1);   // (tasks.cpp:415)
+        else flag = !((g.val >> f) & 1);
+        gconst |= (fmask_t)flag << f;
+    }
+    return gconst;
+}
+template <class Sink>
+__device__ __forceinline__ void t_put_flags_kf(const uint8_t *kf_field, uint32_t ncf, fmask_t gconst, Sink &w)
+{
+#pragma unroll
+    for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+        if (kf >= ncf) break;
+        w.put((uint32_t)((gconst >> kf_field[kf]) & 1), 1);
+    }
+}
+
 // 256 records (8 groups of 32) per workgroup.  SWAR: titles <= 64 * W bytes whose separator masks k_title_stats_swar
 // left in A.tsep - the fields are found with count-trailing-zeros steps and only the non-constant numeric ones
 // are read (eight bytes, unaligned) and parsed; otherwise the title is parsed byte by byte.
@@ -378,11 +410,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     __shared__ FieldDesc s_fd[MAX_FIELDS];
     __shared__ uint32_t s_w[NCF_CAP][TT_THREADS];
     __shared__ uint8_t s_kf_field[NCF_CAP];
+    __shared__ uint32_t s_ntext;   // some non-constant field is a text field
 
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TT_THREADS)
         reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+    if (tid == 0) s_ntext = 0;
     __syncthreads();
-    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
+    if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) {
+        s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
+        if (s_fd[tid].kind == KIND_TEXT) s_ntext = 1;
+    }
+    __syncthreads();
 
     const bool valid = (uint32_t)tid < nt;
     const uint32_t gi = tid & 31;                  // index inside the 32-record group
@@ -392,7 +430,39 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     const uint32_t ls = A.ls[g], te = A.te[g];
     uint32_t bits = 0;
     fmask_t gconst = 0;
-    if (ncf <= NCF_CAP) {
+    if (SWAR && ncf <= NCF_CAP && !s_ntext) {
+        // (round 3) Every non-constant field is numeric - the usual title: a read counter, coordinates - and its value was parsed by
+        // k_title_stats_swar: no walk over the title's fields, no separator mask, and the neighbours' values (previous record,
+        // first record of the 32-record group: both in this wave) come by lane shuffle instead of through LDS and a barrier.
+        // Flags and bits are computed over the list of non-constant fields, not over all fields.
+        CachedTitle C;
+        TitleDiffs d = {0, 0, 0};
+        const int lane = tid & 63;
+#pragma unroll
+        for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
+            C.cur[kf] = C.prev[kf] = 0;
+            if (kf >= ncf) continue;
+            const uint32_t ff = s_kf_field[kf];
+            const uint32_t wc = valid ? A.tv[(size_t)s_fd[ff].cand * A.tw_stride + g + slot_bias] : 0u;
+            const uint32_t wp = (uint32_t)__shfl_up((int)wc, 1), wf = (uint32_t)__shfl((int)wc, lane & 32);
+            if (!valid) continue;
+            C.cur[kf] = wc;
+            A.tw[(size_t)kf * A.tw_stride + g + slot_bias] = wc;
+            if (gi) {
+                C.prev[kf] = wp;
+                if (wc != wf) d.val |= (fmask_t)1 << ff;
+                if ((int32_t)(wc - wp) != s_fd[ff].min_d) d.dlt |= (fmask_t)1 << ff;
+            }
+        }
+        TitleDiffs gd = {0, t_g32_or(d.val), t_g32_or(d.dlt)};
+        gconst = t_group_const_kf(s_fd, s_kf_field, ncf, gd, gsize);
+        if (valid) {
+            BitCounter bc;
+            if (gi == 0) t_put_flags_kf(s_kf_field, ncf, gconst, bc);
+            title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, bc);
+            bits = (uint32_t)bc.bits;
+        }
+    } else if (ncf <= NCF_CAP) {
         // one pass over the title: cache the non-constant fields of this record
         if constexpr (SWAR) {
             uint64_t sepmask[W];
@@ -459,10 +529,10 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
             }
         }
         TitleDiffs gd = {t_g32_or(d.txt), t_g32_or(d.val), t_g32_or(d.dlt)};
-        gconst = title_group_const(s_fd, nf, gd, gsize);
+        gconst = t_group_const_kf(s_fd, s_kf_field, ncf, gd, gsize);
         if (valid) {
             BitCounter bc;
-            if (gi == 0) title_put_flags(s_fd, nf, gconst, bc);
+            if (gi == 0) t_put_flags_kf(s_kf_field, ncf, gconst, bc);
             title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, bc);
             bits = (uint32_t)bc.bits;
         }
@@ -579,9 +649,9 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
         const fmask_t gconst = A.gflags[grp];
         TLaneWriter w;
         w.init(t_lds ? s_stage : outw, t_lds ? tw0 : 0, title_base + 8ull * A.goff[grp] + (incl - bits));
-        if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
         const uint32_t ls = A.ls[g];
         if (ncf <= NCF_CAP) {
+            if (gi == 0) t_put_flags_kf(s_kf_field, ncf, gconst, w);
             CachedTitle C;
 #pragma unroll
             for (uint32_t kf = 0; kf < NCF_CAP; ++kf) {
@@ -592,6 +662,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
             }
             title_emit_cached(A.buf + ls, A, s, s_fd, s_kf_field, ncf, gi == 0, C, gconst, w);
         } else {
+            if (gi == 0) title_put_flags(s_fd, nf, gconst, w);
             title_record_emit(A.buf, A, s, s_fd, nf, gi == 0, gi ? A.ls[g - 1] : ls, ls, gconst, w);
         }
         w.finish();
@@ -614,10 +685,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
 // 0's dword in every lane of the wave - the constant stretches of a title, seven of cfg2's thirteen dwords - is not
 // classified at all: its mask bits are record 0's (the vote costs two instructions, the classification and the
 // difference bits forty), and dwords behind the wave's longest title are skipped.
+// Wave-uniform read-only tables (record 0's field table) are read through the CONSTANT address space: the compiler then
+// fetches them with scalar loads into SGPRs - no LDS copy of the table per workgroup, no vector load + readfirstlane per value.
+typedef const __attribute__((address_space(4))) uint32_t *cu32p;
+typedef const __attribute__((address_space(4))) Rec0Tab *crec0p;
+
 template <uint32_t W>
 __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
-                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W], const uint32_t *r0w, uint64_t (&diffmask)[W],
-                                             const uint32_t *sep0, const uint32_t *dig0)
+                                             uint64_t (&sepmask)[W], uint64_t (&digmask)[W], cu32p r0w, uint64_t (&diffmask)[W],
+                                             cu32p sep0, cu32p dig0)
 {
     uint32_t sp32[2 * W], dg32[2 * W], df32[2 * W];
 #pragma unroll
@@ -694,13 +770,13 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
     __shared__ fmask_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
     __shared__ uint32_t s_w[TS_ROWS<W>][TT_THREADS];
-    __shared__ Rec0Tab s_r0;
+    // record 0's field table: scalar loads straight from global memory (written by k_rec0_fields, read-only here)
+    const crec0p R0 = (crec0p)(uintptr_t)(A.rec0 + s);
+    const uint32_t r0_nf0 = R0->nf0;
+    const uint32_t nf0 = r0_nf0 < MAX_FIELDS ? r0_nf0 : MAX_FIELDS;
 
-    for (uint32_t k = tid; k < sizeof(Rec0Tab) / 4; k += TT_THREADS)
-        reinterpret_cast<uint32_t *>(&s_r0)[k] = reinterpret_cast<const uint32_t *>(A.rec0 + s)[k];
-    for (uint32_t k = tid; k < MAX_FIELDS * SW; k += TT_THREADS) s_stat[k] = 0;
+    for (uint32_t k = tid; k < nf0 * SW; k += TT_THREADS) s_stat[k] = 0;
     __syncthreads();
-    const uint32_t nf0 = s_r0.nf0 < MAX_FIELDS ? s_r0.nf0 : MAX_FIELDS;
 
     const int64_t i = (int64_t)blockIdx.x * OWNED + tid - 1;  // record index inside the sub-block
     const bool valid = i >= 0 && i < (int64_t)n;
@@ -710,14 +786,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     const uint32_t tlen = valid ? te - ls + 1 : 0;            // title bytes including the closing newline
 
     uint64_t sepmask[W], digmask[W], diffmask[W];
-    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, reinterpret_cast<const uint32_t *>(s_r0.title), diffmask, s_r0.sepm, s_r0.digm);
+    t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, (cu32p)(uintptr_t)(A.rec0[s].title), diffmask,
+                    (cu32p)(uintptr_t)(A.rec0[s].sepm), (cu32p)(uintptr_t)(A.rec0[s].digm));
     uint32_t nsep = 0;
 #pragma unroll
     for (uint32_t k = 0; k < W; ++k) {
         if (owned) A.tsep[(size_t)g * W + k] = sepmask[k];
         nsep += (uint32_t)__popcll(sepmask[k]);
     }
-    if (valid && nsep != s_r0.nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
+    if (valid && nsep != r0_nf0) atomicMin(A.err, (int32_t)ERR_FIELDS);  // phyNGSC.cpp:417-421 only warns
 
     uint32_t pos = 0;
     fmask_t nummask = 0;
@@ -728,15 +805,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     bool pos_aligned = true;                                  // (wave-uniform) every lane's field starts where record 0's does
     const bool wave_has_rec0 = __any(owned && i == 0);
     for (uint32_t f = 0; f < nf0; ++f) {
-        const uint32_t len0 = s_r0.len[f], kk = s_r0.kmap[f], wo = s_r0.woff[f];
-        const uint32_t pos0 = s_r0.start[f];
+        const uint32_t fd0 = R0->fdw[f][0], fd1 = R0->fdw[f][1];
+        const uint32_t pos0 = fd0 & 0xffffu, len0 = fd0 >> 16, kk = fd1 & 0xffu, wo = fd1 >> 16;
         if (pos_aligned && !wave_has_rec0 && pos0 + len0 < 64 * W && len0 < 64) {
             const uint64_t fdw = t_window<W>(diffmask, pos0);
             if (!__any(valid && (fdw & t_lowbits(len0 + 1)) != 0)) {
                 if (kk != 0xff) {   // record 0's field is numeric, so it is in every lane: value = record 0's
                     nummask |= (fmask_t)1 << f;
                     if (kk < NUM_CAND_CAP) {
-                        const uint32_t v0 = s_r0.val0[f];
+                        const uint32_t v0 = R0->val0[f];
                         if (owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v0;
                         if (lane == 63) s_last[kk][tid >> 6] = v0;
                         if (lane == 0) s_first[kk][tid >> 6] = v0;
@@ -786,7 +863,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
             x1 &= (uint32_t)(km >> 32);
             if (c8 == 0) { w0 = x0; w1 = x1; }
             const bool in0 = 8 * c8 < len0;
-            const uint32_t a0 = in0 ? s_r0.al[wo + 2 * c8] : 0, a1 = in0 ? s_r0.al[wo + 2 * c8 + 1] : 0;
+            const uint32_t a0 = in0 ? R0->al[wo + 2 * c8] : 0, a1 = in0 ? R0->al[wo + 2 * c8 + 1] : 0;
             const uint32_t d0 = x0 ^ a0, d1 = x1 ^ a1;
             diff |= d0 | d1;
             if (__any(d0 | d1)) {
@@ -805,8 +882,8 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         if (kk != 0xff && !__any(valid && !same)) {
             // every lane holds record 0's (numeric) field: nothing to parse
             isn = true;
-            v = s_r0.val0[f];
-            ovf = s_r0.ovf0[f] != 0;
+            v = R0->val0[f];
+            ovf = ((fd1 >> 8) & 0xffu) != 0;
             if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;
             nummask |= (fmask_t)1 << f;
         } else if (kk != 0xff) {
@@ -868,9 +945,9 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     __syncthreads();
     {
         // the first lanes of waves 1..3 against the last lanes of waves 0..2
-        const uint32_t ncand = s_r0.ncand, kk = (uint32_t)tid >> 2, w = (uint32_t)tid & 3u;
+        const uint32_t ncand = R0->ncand, kk = (uint32_t)tid >> 2, w = (uint32_t)tid & 3u;
         if (w >= 1 && kk < ncand) {
-            const uint32_t ff = s_r0.cand_f[kk];
+            const uint32_t ff = A.rec0[s].cand_f[kk];
             if (((s_nm_first[w] & s_nm_last[w - 1]) >> ff) & 1) {
                 const uint32_t bd = bias((int32_t)(s_first[kk][w] - s_last[kk][w - 1]));
                 if (bd > s_stat[ff * SW + 8]) atomicMax(&s_stat[ff * SW + 8], bd);

@@ -252,6 +252,9 @@ struct Rec0Tab {
     uint16_t woff[MAX_FIELDS];                    // dword offset of the field inside al
     uint32_t al[(REC0_TITLE_CAP + 8 * MAX_FIELDS) / 4];  // field-aligned copy, each field zero padded to 8 bytes
     uint32_t sepm[4], digm[4];                    // separator / digit bit per byte of the first 128 title bytes
+    // per field, as dwords a kernel can fetch with SCALAR loads (gfx950 has no sub-dword scalar loads; the u8 / u16 arrays above
+    // cost a vector load and a readfirstlane per value): [0] = start | len << 16, [1] = kmap | ovf0 << 8 | woff << 16
+    uint32_t fdw[MAX_FIELDS][2];
 };
 static_assert(sizeof(Rec0Tab) % 4 == 0, "Rec0Tab is copied word-wise");
 
@@ -740,6 +743,7 @@ NGSC_HD RankGeom rank_geometry(uint64_t file_size, uint32_t P, uint32_t r)
 // Search policy of plan_rank(): one thread (host harness, reference semantics) ...
 struct ScalarSearch {
     NGSC_HD uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const { return lower_bound_u32(a, n, key); }
+    NGSC_HD uint32_t at(const uint32_t *a, uint32_t idx) const { return a[idx]; }
     NGSC_HD void pair(const uint32_t *a, uint32_t na, uint64_t ka, const uint32_t *b, uint32_t nb, uint64_t kb, uint32_t lo,
                       uint32_t span, uint32_t &ra, uint32_t &rb, uint32_t /* hint */ = 0) const
     {
@@ -804,7 +808,7 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
         Cut &c = cuts[plan->n_cuts++];
         c.rank = r; c.rec_lo = cur; c.n_rec = cnt; c.overlap = overlap;
         c.win_pos = (uint64_t)win_pos; c.wsize = (uint64_t)bsize;
-        int64_t next_abs = (int64_t)ls[last + 1] + (int64_t)buf_off;
+        int64_t next_abs = (int64_t)search.at(ls, last + 1) + (int64_t)buf_off;
         bytes_read = next_abs - g.wr_start;   // :745-746
         win_pos = next_abs;
         if (win_pos + bsize > g.wr_end) {      // :748-755
