@@ -380,7 +380,9 @@ def decompress_bytes(ngsc: bytes, engine: Optional[Engine] = None, device: int =
     from . import ngsc_format
     eng = engine or Engine(device)
     streams = ngsc_format.rank_streams(bytes(ngsc))
-    subs = [sb for w in sorted(streams) for sb in streams[w]]
+    ranks = sorted(streams)
+    subs = [sb for w in ranks for sb in streams[w]]
+    owner = [w for w in ranks for _ in streams[w]]
     offs, pos = [], 0
     for sb in subs:
         offs.append(pos)
@@ -391,8 +393,26 @@ def decompress_bytes(ngsc: bytes, engine: Optional[Engine] = None, device: int =
     d_sub = torch.from_numpy(buf).to(f"cuda:{eng.device}")
     text, toff, _ = eng.decompress_device(d_sub, offs, [len(sb) for sb in subs])
     out = text.cpu().numpy().tobytes()
-    fs = ngsc_format.read_footer(bytes(ngsc)).FS   # (a file whose last line had no newline decodes with one too many)
-    return out[:fs] if len(out) == fs + 1 and out.endswith(b"\n") else out
+    # Rank w's text belongs at s_w = w * (FS / P) + OV[w] (the first-record sync distance the footer keeps, phyNGSC.cpp:131-160)
+    # up to s_(w+1), exactly as ngsc_decompress_file places it: a record that two ranks both stored (phyNGSC.cpp:295-300) comes
+    # out once, and a file whose last line had no newline gets its exact size back.
+    f = ngsc_format.read_footer(bytes(ngsc))
+    P, fs = f.PS, f.FS
+    ov = [0] + list(f.OV)
+    s_at = [min(fs, w * (fs // P) + ov[w]) for w in range(P)] + [fs]
+    res = bytearray(fs)
+    filled = [0] * P
+    toff = list(toff)
+    for k, w in enumerate(owner):
+        piece = out[toff[k]:toff[k + 1]]
+        room = s_at[w + 1] - s_at[w] - filled[w]
+        n = min(len(piece), max(room, 0))
+        res[s_at[w] + filled[w]:s_at[w] + filled[w] + n] = piece[:n]
+        filled[w] += n
+    for w in range(P):
+        if s_at[w + 1] < s_at[w] or filled[w] != s_at[w + 1] - s_at[w]:
+            raise NgscError(-1, f"rank {w} decodes to {filled[w]} bytes, its stretch of the file has {s_at[w + 1] - s_at[w]}")
+    return bytes(res)
 
 
 # ---- multi-process (one process per GPU) ------------------------------------------------------------

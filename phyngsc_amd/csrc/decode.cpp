@@ -13,6 +13,9 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 using namespace ngsc;
@@ -29,6 +32,9 @@ uint32_t dec_sub_spec(const void *h, uint32_t s);
 void launch_dec_assemble(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch, uint64_t stride,
                          uint32_t rec_cap, uint64_t tcap, uint64_t qcap, const void *in, const uint64_t *text_off, uint8_t *text);
 size_t dec_sub_bytes();
+}
+extern "C" void *ngsc_ctx_scratch(ngsc_ctx *c, uint32_t slot, size_t bytes);   // engine.cpp
+namespace ngsc {
 int32_t dec_sub_err(const void *h, uint32_t s);
 uint64_t dec_sub_text(const void *h, uint32_t s);
 uint32_t dec_sub_records(const void *h, uint32_t s);
@@ -37,7 +43,7 @@ void dec_sub_ticks(const void *h, uint32_t s, uint64_t *t);
 
 extern "C" {
 
-// (the context's own stream and device; scratch is allocated per call and freed again: decoding is not the hot path)
+// (the context's device; working memory is the context's and stays between calls)
 int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, void *d_text,
                            uint64_t text_cap, uint64_t *text_off, uint32_t *n_records, void *hip_stream)
 {
@@ -53,6 +59,13 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     const bool spec = !(getenv("NGSC_DEC_SPEC") && !strcmp(getenv("NGSC_DEC_SPEC"), "0"));
     const uint64_t hop_budget = 512ull << 20;
     uint32_t batch = std::min<uint32_t>(n_sb, 2048);
+    {   // ... and what the device has room for: at most half of its free memory goes into the per-sub-block scratch
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
+            const uint64_t fit = (uint64_t)free_b / 2 / stride;
+            batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch, fit));
+        }
+    }
     uint64_t max_batch_bytes = 0;
     {   // the largest compressed size a batch of `batch` consecutive sub-blocks can have under the budget
         uint64_t run = 0;
@@ -64,21 +77,27 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
             (void)worst;
         }
     }
-    uint8_t *scratch = nullptr;
-    uint64_t *d_off = nullptr, *d_toff = nullptr, *d_hoff = nullptr;
-    uint32_t *d_len = nullptr;
-    void *d_res = nullptr, *d_ctl = nullptr;
-    uint16_t *d_hop = nullptr;
-    uint32_t *d_sum = nullptr;
+    // working memory: kept in the context between calls (one carve for the small tables, one for the per-sub-block scratch,
+    // one for the hop table); an allocation that fails - a shared or fragmented device - is tried again with half the batch
     const size_t rb = dec_sub_bytes();
-    std::vector<uint8_t> h_res(rb * batch);
     int rc = NGSC_OK;
-    if (hipMalloc(&scratch, stride * batch) != hipSuccess || hipMalloc(&d_off, 8ull * batch) != hipSuccess ||
-        hipMalloc(&d_toff, 8ull * batch) != hipSuccess || hipMalloc(&d_hoff, 8ull * batch) != hipSuccess ||
-        hipMalloc(&d_len, 4ull * batch) != hipSuccess || hipMalloc(&d_res, rb * batch) != hipSuccess ||
-        hipMalloc(&d_ctl, dec_ctl_bytes() * batch) != hipSuccess || hipMalloc((void **)&d_sum, 64) != hipSuccess)
-        rc = NGSC_ERR_NOMEM;
-    if (!rc && spec && hipMalloc((void **)&d_hop, 16ull * max_batch_bytes + 64) != hipSuccess) d_hop = nullptr;   // (no room: serial decode)
+    uint8_t *scratch = nullptr;
+    for (;;) {
+        scratch = (uint8_t *)ngsc_ctx_scratch(c, 0, stride * batch);
+        if (scratch || batch == 1) break;
+        batch = (batch + 1) / 2;
+    }
+    std::vector<uint8_t> h_res(rb * batch);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_off = 0, o_toff = o_off + up(8ull * batch), o_hoff = o_toff + up(8ull * batch), o_len = o_hoff + up(8ull * batch);
+    const size_t o_res = o_len + up(4ull * batch), o_ctl = o_res + up(rb * batch), o_sum = o_ctl + up(dec_ctl_bytes() * batch);
+    uint8_t *tabs = scratch ? (uint8_t *)ngsc_ctx_scratch(c, 1, o_sum + 256) : nullptr;
+    if (!scratch || !tabs) rc = NGSC_ERR_NOMEM;
+    uint64_t *d_off = (uint64_t *)(tabs + o_off), *d_toff = (uint64_t *)(tabs + o_toff), *d_hoff = (uint64_t *)(tabs + o_hoff);
+    uint32_t *d_len = (uint32_t *)(tabs + o_len), *d_sum = (uint32_t *)(tabs + o_sum);
+    void *d_res = tabs + o_res, *d_ctl = tabs + o_ctl;
+    uint16_t *d_hop = nullptr;
+    if (!rc && spec) d_hop = (uint16_t *)ngsc_ctx_scratch(c, 2, 16ull * max_batch_bytes + 64);   // (no room: serial decode)
     uint64_t text_pos = 0;
     uint32_t n_spec = 0;
     for (uint32_t b0 = 0; b0 < n_sb && !rc;) {
@@ -136,15 +155,6 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
         b0 += nb;
     }
     text_off[n_sb] = text_pos;
-    if (scratch) (void)hipFree(scratch);
-    if (d_off) (void)hipFree(d_off);
-    if (d_toff) (void)hipFree(d_toff);
-    if (d_len) (void)hipFree(d_len);
-    if (d_res) (void)hipFree(d_res);
-    if (d_ctl) (void)hipFree(d_ctl);
-    if (d_hoff) (void)hipFree(d_hoff);
-    if (d_hop) (void)hipFree(d_hop);
-    if (d_sum) (void)hipFree(d_sum);
     return rc;
 }
 
@@ -194,7 +204,11 @@ bool parse_footer(const uint8_t *d, uint64_t len, FooterIn &f)
 }
 
 struct Piece { uint64_t off; uint32_t len; };
-struct SubIn { uint32_t rank; uint32_t bytes = 0; std::vector<Piece> pieces; };
+struct SubIn { uint32_t rank; uint64_t bytes = 0; std::vector<Piece> pieces; };
+// A sub-block is one 8 MiB window of FASTQ text; its streams cannot be longer than a few times that (the worst case is a
+// bit per symbol more than the input).  A container that claims more - e.g. through a chain of continuation bits - is refused
+// before any buffer is sized from the sum.
+constexpr uint64_t MAX_SUB_BYTES = 64ull << 20;
 
 bool pread_all(int fd, void *dst, uint64_t n, uint64_t off)
 {
@@ -266,7 +280,8 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     const int fd = open(in_path, O_RDONLY);
     if (fd < 0) return NGSC_ERR_IO;
     struct stat sb;
-    if (fstat(fd, &sb) != 0 || sb.st_size < 4) { close(fd); return sb.st_size < 4 ? NGSC_ERR_FORMAT : NGSC_ERR_IO; }
+    if (fstat(fd, &sb) != 0) { close(fd); return NGSC_ERR_IO; }
+    if (sb.st_size < 4) { close(fd); return NGSC_ERR_FORMAT; }
     const uint64_t size = (uint64_t)sb.st_size;
     uint8_t tail[2];
     if (!pread_all(fd, tail, 2, size - 2)) { close(fd); return NGSC_ERR_IO; }
@@ -314,6 +329,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
             if (!first_cont) { open_sub[wrid] = SubIn(); open_sub[wrid].rank = wrid; }
             open_sub[wrid].pieces.push_back({pos, ln});
             open_sub[wrid].bytes += ln;
+            if (open_sub[wrid].bytes > MAX_SUB_BYTES) { close(fd); return NGSC_ERR_FORMAT; }
             pos += ln;
             open_has[wrid] = last_cont;
             if (!last_cont) subs[wrid].push_back(std::move(open_sub[wrid]));
@@ -334,76 +350,186 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     const uint64_t text_per_sb = 10ull << 20;
     std::vector<uint64_t> written(F.PS, 0);
     int rc = NGSC_OK;
-    uint8_t *h_in = nullptr, *h_text = nullptr, *d_in = nullptr, *d_text = nullptr;
-    uint64_t cap_in = 0, cap_text = 0;
-    for (size_t b0 = 0; b0 < order.size() && !rc;) {
-        size_t b1 = b0; uint64_t bytes = 0;
-        while (b1 < order.size() && b1 - b0 < 512 && bytes + order[b1]->bytes + 32 <= (2ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
-        if (b1 == b0) { bytes = (order[b1]->bytes + 15u) & ~15ull; ++b1; }
-        const uint32_t nb = (uint32_t)(b1 - b0);
-        const uint64_t need_in = bytes + 64, need_text = nb * text_per_sb;
-        if (need_in > cap_in) {
-            if (h_in) (void)hipHostFree(h_in); if (d_in) (void)hipFree(d_in);
-            h_in = d_in = nullptr; cap_in = need_in;
-            if (hipHostMalloc((void **)&h_in, cap_in, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_in, cap_in) != hipSuccess) { rc = NGSC_ERR_NOMEM; break; }
+    struct Batch { size_t b0, b1; uint64_t bytes; };
+    std::vector<Batch> batches;
+    uint64_t max_in = 0;
+    uint32_t max_nb = 0;
+    {
+        const uint32_t per = getenv("NGSC_DEC_BATCH") ? (uint32_t)std::max(1, atoi(getenv("NGSC_DEC_BATCH"))) : 512u;   // (tests: small batches)
+        for (size_t b0 = 0; b0 < order.size();) {
+            size_t b1 = b0; uint64_t bytes = 0;
+            while (b1 < order.size() && b1 - b0 < per && bytes + order[b1]->bytes + 32 <= (2ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
+            if (b1 == b0) { bytes = (order[b1]->bytes + 15u) & ~15ull; ++b1; }
+            batches.push_back({b0, b1, bytes});
+            max_in = std::max(max_in, bytes + 64);
+            max_nb = std::max<uint32_t>(max_nb, (uint32_t)(b1 - b0));
+            b0 = b1;
         }
-        if (need_text > cap_text) {
-            if (h_text) (void)hipHostFree(h_text); if (d_text) (void)hipFree(d_text);
-            h_text = d_text = nullptr; cap_text = need_text;
-            if (hipHostMalloc((void **)&h_text, cap_text, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_text, cap_text) != hipSuccess) { rc = NGSC_ERR_NOMEM; break; }
-        }
-        tr = dsec();
-        std::vector<uint64_t> off(nb), toff(nb + 1);
-        std::vector<uint32_t> len(nb);
-        uint64_t pos = 0;
-        memset(h_in, 0, need_in);
-        for (uint32_t k = 0; k < nb && !rc; ++k) {
-            const SubIn &x = *order[b0 + k];
-            off[k] = pos; len[k] = x.bytes;
-            uint64_t q = pos;
-            for (const Piece &pc : x.pieces) { if (!pread_all(fd, h_in + q, pc.len, pc.off)) { rc = NGSC_ERR_IO; break; } q += pc.len; }
-            pos += (x.bytes + 15u) & ~15ull;
-        }
-        t_read += dsec() - tr;
-        if (rc) break;
-        tr = dsec();
-        if (hipMemcpy(d_in, h_in, need_in, hipMemcpyHostToDevice) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-        rc = ngsc_decompress_device(c, d_in, off.data(), len.data(), nb, d_text, cap_text, toff.data(), nullptr, nullptr);
-        if (rc) break;
-        if (hipMemcpy(h_text, d_text, toff[nb], hipMemcpyDeviceToHost) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-        t_dev += dsec() - tr;
-        tr = dsec();
-        for (uint32_t k = 0; k < nb; ++k) {   // (consecutive sub-blocks of a rank are consecutive in the text: one write per run)
-            const uint32_t w = order[b0 + k]->rank;
-            uint32_t k2 = k;
-            while (k2 + 1 < nb && order[b0 + k2 + 1]->rank == w) ++k2;
-            const uint64_t have = toff[k2 + 1] - toff[k], room = s_at[w + 1] - s_at[w] - std::min(written[w], s_at[w + 1] - s_at[w]);
-            const uint64_t n = std::min(have, room);
-            if (n && !pwrite_all_at(ofd, h_text + toff[k], n, s_at[w] + written[w])) {
-                fprintf(stderr, "[ngsc -d] write of %llu bytes at offset %llu of %s failed: %s\n", (unsigned long long)n,
-                        (unsigned long long)(s_at[w] + written[w]), out_path, strerror(errno));
-                rc = NGSC_ERR_IO;
-                break;
+    }
+    // (round 3) Three stages, two buffers between each pair: a reader thread (pread of a batch's pieces into pinned memory, upload),
+    // this thread (the decoder kernels), a writer thread (download, pwrite at each rank's place) - the file used to go through
+    // read, upload, decode, download and write one after the other with blocking copies (the compress driver of container.cpp
+    // has overlapped them since round 2).
+    const uint64_t cap_text = (uint64_t)max_nb * text_per_sb;
+    uint8_t *h_in[2] = {nullptr, nullptr}, *h_text[2] = {nullptr, nullptr}, *d_in[2] = {nullptr, nullptr}, *d_text[2] = {nullptr, nullptr};
+    hipStream_t s_up = nullptr, s_dec = nullptr, s_down = nullptr;
+    const uint32_t nbuf = batches.size() > 1 ? 2u : 1u;
+    for (uint32_t k = 0; k < nbuf && !rc; ++k)
+        if (hipHostMalloc((void **)&h_in[k], max_in, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_in[k], max_in) != hipSuccess ||
+            hipHostMalloc((void **)&h_text[k], cap_text, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_text[k], cap_text) != hipSuccess)
+            rc = NGSC_ERR_NOMEM;
+    if (!rc && (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) != hipSuccess))
+        rc = NGSC_ERR_HIP;
+    struct Meta { std::vector<uint64_t> off, toff; std::vector<uint32_t> len; };
+    std::vector<Meta> meta(batches.size());
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t uploaded = 0, decoded = 0, drained = 0;   // batches that have passed each stage (drained: its device text buffer is free again)
+    int fail = NGSC_OK;
+    const int dev = ngsc_ctx_device(c);
+    auto set_fail = [&](int code) { std::lock_guard<std::mutex> lk(mu); if (!fail) fail = code; cv.notify_all(); };
+    std::thread reader, writer;
+    if (!rc) {
+        reader = std::thread([&]() {
+            (void)hipSetDevice(dev);
+            const unsigned nt = std::max(1u, std::min(8u, getenv("NGSC_IO_THREADS") ? (unsigned)atoi(getenv("NGSC_IO_THREADS")) : 8u));
+            for (size_t b = 0; b < batches.size(); ++b) {
+                {   // the buffer pair of batch b - 2 must have been decoded
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return fail || b < decoded + nbuf; });
+                    if (fail) return;
+                }
+                const double t = dsec();
+                const Batch &B = batches[b];
+                const uint32_t nb = (uint32_t)(B.b1 - B.b0);
+                Meta &M = meta[b];
+                M.off.resize(nb); M.len.resize(nb); M.toff.assign(nb + 1, 0);
+                uint8_t *dst = h_in[b % nbuf];
+                uint64_t pos = 0;
+                struct Job { uint64_t at, off; uint32_t len; };
+                std::vector<Job> jobs;
+                for (uint32_t k = 0; k < nb; ++k) {
+                    const SubIn &x = *order[B.b0 + k];
+                    M.off[k] = pos; M.len[k] = (uint32_t)x.bytes;
+                    uint64_t q = pos;
+                    for (const Piece &pc : x.pieces) { jobs.push_back({q, pc.off, pc.len}); q += pc.len; }
+                    const uint64_t end = pos + ((x.bytes + 15u) & ~15ull);
+                    memset(dst + q, 0, end - q);   // (the decoder reads whole 16-byte units)
+                    pos = end;
+                }
+                memset(dst + pos, 0, 64);
+                std::vector<char> okv(nt, 1);
+                std::vector<std::thread> th;
+                for (unsigned w = 0; w < nt; ++w) {
+                    auto work = [&, w]() { for (size_t j = w; j < jobs.size(); j += nt) if (!pread_all(fd, dst + jobs[j].at, jobs[j].len, jobs[j].off)) okv[w] = 0; };
+                    if (w + 1 == nt) work(); else th.emplace_back(work);
+                }
+                for (auto &x : th) x.join();
+                for (char o : okv) if (!o) { set_fail(NGSC_ERR_IO); return; }
+                if (hipMemcpyAsync(d_in[b % nbuf], dst, B.bytes + 64, hipMemcpyHostToDevice, s_up) != hipSuccess || hipStreamSynchronize(s_up) != hipSuccess) {
+                    set_fail(NGSC_ERR_HIP);
+                    return;
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                t_read += dsec() - t;
+                ++uploaded;
+                cv.notify_all();
             }
-            written[w] += n;
-            k = k2;
+        });
+        writer = std::thread([&]() {
+            (void)hipSetDevice(dev);
+            for (size_t b = 0; b < batches.size(); ++b) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return fail || decoded > b; });
+                    if (fail) return;
+                }
+                const double t = dsec();
+                const Batch &B = batches[b];
+                const uint32_t nb = (uint32_t)(B.b1 - B.b0);
+                const Meta &M = meta[b];
+                uint8_t *src = h_text[b % nbuf];
+                if (hipMemcpyAsync(src, d_text[b % nbuf], M.toff[nb], hipMemcpyDeviceToHost, s_down) != hipSuccess || hipStreamSynchronize(s_down) != hipSuccess) {
+                    set_fail(NGSC_ERR_HIP);
+                    return;
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ++drained;   // the decoder may fill this device buffer again (the pinned copy is this thread's own until its writes are done)
+                    cv.notify_all();
+                }
+                struct Run { uint64_t at, from, n; };
+                std::vector<Run> runs;
+                for (uint32_t k = 0; k < nb; ++k) {   // (consecutive sub-blocks of a rank are consecutive in the text: one write per run)
+                    const uint32_t w = order[B.b0 + k]->rank;
+                    uint32_t k2 = k;
+                    while (k2 + 1 < nb && order[B.b0 + k2 + 1]->rank == w) ++k2;
+                    const uint64_t have = M.toff[k2 + 1] - M.toff[k], room = s_at[w + 1] - s_at[w] - std::min(written[w], s_at[w + 1] - s_at[w]);
+                    const uint64_t n = std::min(have, room);
+                    if (n) runs.push_back({s_at[w] + written[w], M.toff[k], n});
+                    written[w] += n;
+                    k = k2;
+                }
+                // big runs are cut into pieces for the I/O threads
+                std::vector<Run> parts;
+                for (const Run &r : runs)
+                    for (uint64_t o = 0; o < r.n; o += 64ull << 20) parts.push_back({r.at + o, r.from + o, std::min<uint64_t>(64ull << 20, r.n - o)});
+                const unsigned nt = std::max(1u, std::min(8u, getenv("NGSC_IO_THREADS") ? (unsigned)atoi(getenv("NGSC_IO_THREADS")) : 8u));
+                std::vector<char> okv(nt, 1);
+                std::vector<std::thread> th;
+                for (unsigned w = 0; w < nt; ++w) {
+                    auto work = [&, w]() { for (size_t j = w; j < parts.size(); j += nt) if (!pwrite_all_at(ofd, src + parts[j].from, parts[j].n, parts[j].at)) okv[w] = 0; };
+                    if (w + 1 == nt) work(); else th.emplace_back(work);
+                }
+                for (auto &x : th) x.join();
+                for (char o : okv) if (!o) {
+                    fprintf(stderr, "[ngsc -d] write to %s failed: %s\n", out_path, strerror(errno));
+                    set_fail(NGSC_ERR_IO);
+                    return;
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                t_write += dsec() - t;
+            }
+        });
+        for (size_t b = 0; b < batches.size(); ++b) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return fail || (uploaded > b && b < drained + nbuf); });
+                if (fail) break;
+            }
+            const double t = dsec();
+            Meta &M = meta[b];
+            const uint32_t nb = (uint32_t)M.off.size();
+            const int r = ngsc_decompress_device(c, d_in[b % nbuf], M.off.data(), M.len.data(), nb, d_text[b % nbuf], cap_text, M.toff.data(), nullptr, s_dec);
+            if (r) { set_fail(r); break; }
+            std::lock_guard<std::mutex> lk(mu);
+            t_dev += dsec() - t;
+            ++decoded;
+            cv.notify_all();
         }
-        t_write += dsec() - tr;
-        b0 = b1;
+        reader.join();
+        writer.join();
+        rc = fail;
+    }
+    if (s_up) (void)hipStreamDestroy(s_up);
+    if (s_dec) (void)hipStreamDestroy(s_dec);
+    if (s_down) (void)hipStreamDestroy(s_down);
+    for (uint32_t k = 0; k < 2; ++k) {
+        if (h_in[k]) (void)hipHostFree(h_in[k]);
+        if (h_text[k]) (void)hipHostFree(h_text[k]);
+        if (d_in[k]) (void)hipFree(d_in[k]);
+        if (d_text[k]) (void)hipFree(d_text[k]);
     }
     if (!rc)   // every rank must have filled its stretch of the file
         for (uint32_t w = 0; w < F.PS; ++w) if (written[w] != s_at[w + 1] - s_at[w]) { rc = NGSC_ERR_FORMAT; break; }
     if (!rc && ftruncate(ofd, (off_t)F.FS) != 0) rc = NGSC_ERR_IO;
-    if (h_in) (void)hipHostFree(h_in);
-    if (h_text) (void)hipHostFree(h_text);
-    if (d_in) (void)hipFree(d_in);
-    if (d_text) (void)hipFree(d_text);
     close(fd);
     if (close(ofd) != 0 && !rc) rc = NGSC_ERR_IO;
     if (seconds_out) { seconds_out[0] = t_read; seconds_out[1] = t_dev; seconds_out[2] = t_write; }
     if (getenv("NGSC_VERBOSE"))
-        fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks: read %.3f s, H2D+decode+D2H %.3f s, write %.3f s, total %.3f s\n", F.PS, F.BS,
-                order.size(), t_read, t_dev, t_write, dsec() - t0);
+        fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks in %zu batches: read + upload %.3f s, decode %.3f s, download + write %.3f s "
+                        "(overlapped), total %.3f s\n", F.PS, F.BS, order.size(), batches.size(), t_read, t_dev, t_write, dsec() - t0);
     return rc;
 }
 

@@ -59,6 +59,7 @@ struct ngsc_ctx {
 
     // workspace
     DevBuf small, tiles, recs, recs2, persb, zero, slots, misc, cscopy, dense;
+    DevBuf dec[4];                // the decoder's working memory (ngsc_ctx_scratch), kept between calls
     // pinned host staging
     void *h_pin = nullptr;
     size_t h_pin_cap = 0;
@@ -224,6 +225,7 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
     (void)hipSetDevice(c->device);
     for (DevBuf *b : {&c->small, &c->tiles, &c->recs, &c->recs2, &c->persb, &c->zero, &c->slots, &c->misc, &c->cscopy, &c->dense})
         if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : c->dec) if (b.p) (void)hipFree(b.p);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     collect_times(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -236,6 +238,22 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
 }
 
 const char *ngsc_last_hip_error(ngsc_ctx *c) { return c ? c->hip_err.c_str() : ""; }
+
+// Grow-only device memory of the context for the decoder (decode.cpp), slot 0..3: kept between calls, so that a file decoded
+// batch by batch does not pay a multi-gigabyte hipMalloc / hipFree - and the device-wide wait a free implies - per batch.
+// nullptr: no memory (the caller falls back or gives up).  Not part of the public ABI.
+void *ngsc_ctx_scratch(ngsc_ctx *c, uint32_t slot, size_t bytes)
+{
+    if (!c || slot >= 4) return nullptr;
+    DevBuf &b = c->dec[slot];
+    if (bytes <= b.cap) return b.p;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    if (hipMalloc(&b.p, bytes) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
+    b.cap = bytes;
+    return b.p;
+}
 
 int ngsc_ctx_device(ngsc_ctx *c) { return c ? c->device : -1; }
 
@@ -318,7 +336,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
     Carver cs;
     size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
-    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4);
+    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4), o_done = cs.take(4);
     size_t o_outtot = cs.take(8);
     size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
     size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
@@ -329,11 +347,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     int32_t *d_err = (int32_t *)(sm + o_err);
     uint32_t *d_total = (uint32_t *)(sm + o_total), *d_start = (uint32_t *)(sm + o_start);
     uint32_t *d_maxq = (uint32_t *)(sm + o_maxq), *d_slotc = (uint32_t *)(sm + o_slotc);
-    uint32_t *d_maxrec = (uint32_t *)(sm + o_maxrec), *d_maxtitle = (uint32_t *)(sm + o_maxtitle);
+    uint32_t *d_maxrec = (uint32_t *)(sm + o_maxrec), *d_maxtitle = (uint32_t *)(sm + o_maxtitle), *d_done = (uint32_t *)(sm + o_done);
     uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
     RankPlan *d_plans = (RankPlan *)(sm + o_plans);
     Cut *d_cuts = (Cut *)(sm + o_cuts);
-    HIPCHK(c, hipMemsetAsync(sm, 0, o_first, st));
+    launch_zero_range(st, sm, o_first);   // (a kernel of ours: the runtime's fill kernel left the GPU idle for ~20 us behind it)
 
     const uint32_t ntiles = index_num_tiles(len);
     // The record table is sized for the smallest possible record (5 bytes), so the line count never has to come back
@@ -371,12 +389,28 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask, buf_off + buf_len == file_size); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
     { KScope k(c, st, "k_nl_write"); launch_nl_write(st, d_nlmask, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_bound); }
+    bool zero_on_side = false;
+    if (out_prefix) {
+        // beside the cut planner / validation kernel (latency-bound: a chain of searches and a light pass over the record table),
+        // on the side stream; in the sync gap behind it the clearing only made the gap longer, and at the step's start it took
+        // bandwidth from the newline count
+        if (c->debug_sync || (c->profiling && c->profile_only.empty())) {
+            KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix);
+        } else {
+            HIPCHK(c, hipEventRecord(c->ev_fork, st));
+            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            launch_zero_range(c->side_stream, d_out, out_prefix);
+            HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+            zero_on_side = true;
+        }
+    }
     {
         KScope k(c, st, "k_cuts_validate");
         launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
                              max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr, from,
                              part ? buf_off + buf_len : 0);
     }
+    if (zero_on_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));   // (joined in front of the cut list copies: behind the sync the side stream is free)
     // ---- sync 2: cut list ----
     size_t plan_bytes = cs.off - o_plans;
     HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
@@ -384,8 +418,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // (round 3) while the host waits: the zero-initialised arena of this call, as large as the last call needed it
     void *const prezero_ptr = c->zero.p;
     const size_t prezero = std::min(c->zero_hint, c->zero.cap);
-    if (prezero) HIPCHK(c, hipMemsetAsync(c->zero.p, 0, prezero, st));
-    if (out_prefix) { KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix); }
+    if (prezero) launch_zero_range(st, c->zero.p, prezero);
     HIPCHK(c, hipStreamSynchronize(st));
     if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
     const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
@@ -487,7 +520,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t t_owner = ct.take(4 * (size_t)n_slots);
     rc = ensure(c, c->slots, ct.off);
     if (rc) return rc;
-    if (c->zero.p != prezero_ptr || cz.off > prezero) HIPCHK(c, hipMemsetAsync(c->zero.p, 0, cz.off, st));
+    if (c->zero.p != prezero_ptr || cz.off > prezero) launch_zero_range(st, c->zero.p, cz.off);
     c->zero_hint = cz.off;
 
     uint8_t *zb = (uint8_t *)c->zero.p, *pb = (uint8_t *)c->persb.p, *tb = (uint8_t *)c->slots.p;
@@ -542,15 +575,25 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // measure and pack read the file themselves, as in round 1
     A.dense_s = A.dense_q = nullptr;
     A.dstride = 0;
+    A.dtail_c = 0xffffffffu;
+    A.dtail_b = 16;
     {
         const char *de = getenv("NGSC_SQ_DENSE");
-        const uint64_t stride = ((uint64_t)max_q + 15) & ~15ull, need = 2 * stride * (uint64_t)n_rec_total;
+        uint64_t stride = ((uint64_t)max_q + 15) & ~15ull;
+        uint32_t tail_c = 0xffffffffu, tail_b = 16;
+        if (max_q && !getenv("NGSC_SQ_NO_TAIL")) {
+            const uint32_t lc = (max_q - 1) / 16, rem = max_q - 16 * lc;   // last chunk of the longest read and its bytes
+            if (rem <= 12) { tail_c = lc; tail_b = (rem + 3) & ~3u; stride = 16ull * lc + tail_b; }
+        }
+        const uint64_t per_stream = (stride * (uint64_t)n_rec_total + 15) & ~15ull, need = 2 * per_stream;
         if (!(de && !strcmp(de, "0")) && sq_reg && stride && need <= (uint64_t)len * 5 / 2) {
             rc = ensure(c, c->dense, (size_t)need + 64);
             if (rc) return rc;
             A.dense_s = (uint8_t *)c->dense.p;
-            A.dense_q = A.dense_s + stride * (uint64_t)n_rec_total;
+            A.dense_q = A.dense_s + per_stream;
             A.dstride = n_rec_total;
+            A.dtail_c = tail_c;
+            A.dtail_b = tail_b;
         }
     }
     A.out = (uint8_t *)d_out;
@@ -626,11 +669,22 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         // NGSC_OVERLAP=3 (experiment): the fork in front of the statistics kernels - the issue-bound title statistics beside
         // the texture-path-bound sequence/quality statistics
         const bool early = ov_env && !strcmp(ov_env, "3");
-        { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
-        if (early && (rc = fork_s())) return rc;
+        if (early) {
+            { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
+            if ((rc = fork_s())) return rc;
+        } else {
+            // (round 3) record 0's field table - one wave per sub-block, a serial walk over a title: 23 us - is needed by the title
+            // kernels only: on the side stream, beside the sequence/quality statistics instead of in front of them
+            if ((rc = fork_s())) return rc;
+            { KScope k(c, sts, "k_rec0_fields"); launch_rec0_fields(sts, A); }
+            HIPCHK(c, hipEventRecord(c->ev_zero, sts));
+        }
         hipStream_t sq0 = early ? sts : st;
         { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec, max_rec_bytes); }
-        if (!early && (rc = fork_s())) return rc;
+        if (!early) {
+            if ((rc = fork_s())) return rc;
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
+        }
         { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
         { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
         { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
@@ -664,9 +718,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     if ((rc = join())) return rc;
     }
-    if (R) { KScope k(c, st, "k_scan_tile"); launch_scan_tile(st, A, R); }
-    else { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
-    { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
+    if (R) { KScope k(c, st, "k_layout"); launch_layout(st, A, R, d_qrowoff, out_cap, d_outtot, d_done); }
+    else {
+        { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
+        { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
+    }
     // ---- sizes and layout are on the device now; their copies for the host travel behind the pack kernels (no sync here) ----
     // (staggered: the copies, the headers and the length tables beside the output clearing and the title pack kernel)
     if ((rc = fork_s())) return rc;
@@ -680,11 +736,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     { KScope k(c, sts, "k_write_headers"); launch_write_headers(sts, A, d_qrowoff); }
     { KScope k(c, sts, "k_pack_lentable"); launch_pack_lentable(sts, A, max_rec); }
-    // (round 3) staggered: the title pack kernel - latency-bound, 0.11 ms alone - follows the headers on the side stream, BESIDE the
-    // payload pack kernel, which starts as soon as the output is clear (they write different streams of the sub-blocks);
-    // NGSC_TPACK_ALONE=1: round 2's order, title pack in front of the payload pack
-    static const bool tpack_alone = getenv("NGSC_TPACK_ALONE") != nullptr;
-    const bool tpack_side = stagger && !tpack_alone;
+    // (round 3, measured and not kept: NGSC_TPACK_SIDE=1 puts the title pack kernel - latency-bound, 0.11 ms alone - behind the headers
+    // on the side stream, BESIDE the payload pack kernel.  The payload kernel then takes 0.55 ms instead of 0.40: it is bound by
+    // instruction issue and its LDS queue, and what it shares it loses - 452 against 462 GB/s)
+    static const bool tpack_side_env = getenv("NGSC_TPACK_SIDE") != nullptr;
+    const bool tpack_side = stagger && tpack_side_env;
     if ((rc = fork())) return rc;
     { hipStream_t tps = tpack_side ? sts : st2; KScope k(c, tps, "k_title_pack_reg"); launch_title_pack_reg(tps, A, max_rec); }
     if (!tpack_side && (rc = join_s())) return rc;

@@ -6,6 +6,7 @@
 // record's line start.  HBM-bound: 1 B read per input byte (twice: count + write), 12 B written per
 // record.  No MFMA - integer byte classification.
 #include "ngsc_kernels.h"
+#include <cstdlib>
 
 namespace ngsc {
 
@@ -76,12 +77,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile0 = blockIdx.x * TILE_BYTES;
     if (tile0 >= start && tile0 + TILE_BYTES <= len && tile0 + TILE_BYTES > tile0) {
+        // (round 3) A wave takes 16 contiguous KB of the tile, eight rows of 1 KB per trip.  Its 16-bit masks go through LDS, so that
+        // a lane leaves with the masks of eight CONSECUTIVE chunks: one 16-byte store per lane and trip (1 KB per wave
+        // instruction) instead of eight 2-byte ones (128 B per instruction - as many store instructions as loads, and the
+        // texture addresser was this kernel's busiest unit).
+        __shared__ __align__(16) uint16_t s_m[TILE_THREADS / 64][512];
+        const uint32_t wbase = tile0 + wave * (TILE_BYTES / (TILE_THREADS / 64));
 #pragma unroll
         for (uint32_t half = 0; half < 2; ++half) {
             uint4 v[PIECES];
 #pragma unroll
             for (uint32_t k = 0; k < PIECES; ++k)
-                v[k] = *reinterpret_cast<const uint4 *>(buf + tile0 + k * PIECE_BYTES + (wave * 2 + half) * 1024u + lane * 16u);
+                v[k] = *reinterpret_cast<const uint4 *>(buf + wbase + (half * PIECES + k) * 1024u + lane * 16u);
 #pragma unroll
             for (uint32_t k = 0; k < PIECES; ++k) {
                 const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
@@ -89,8 +96,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
 #pragma unroll
                 for (int i = 0; i < 4; ++i) m |= (((zero_bytes(w[i] ^ 0x0A0A0A0Au) >> 7) * 0x01020408u) >> 24) << (4 * i);
                 c += (uint32_t)__popc(m);
-                mask16[(tile0 + k * PIECE_BYTES + (wave * 2 + half) * 1024u + lane * 16u) / 16] = (uint16_t)m;
+                s_m[wave][k * 64 + lane] = (uint16_t)m;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 mm = *reinterpret_cast<const uint4 *>(&s_m[wave][lane * 8]);
+            *reinterpret_cast<uint4 *>(mask16 + (wbase + half * PIECES * 1024u) / 16 + lane * 8) = mm;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the next trip writes s_m again)
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
         for (uint32_t pc = 0; pc < PIECES; ++pc) {
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint32_t *nl_ma
 // The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
 __device__ __forceinline__ void validate_records(const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec,
                                                  uint32_t first, uint32_t stride, uint32_t *max_q, uint32_t *max_rec,
-                                                 uint32_t *max_title, int32_t *err)
+                                                 uint32_t *max_title, int32_t *err, bool vec)
 {
     uint32_t mq = 0, mr = 0, mt = 0;
     bool bad = false;
@@ -206,7 +219,8 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
         mt = TL > mt ? TL : mt;
     };
     // four consecutive records per thread and trip, their table entries with 16-byte loads (round 3: 0.068 -> ms)
-    const uint32_t n4 = n_rec & ~3u;
+    const uint32_t n4 = vec ? n_rec & ~3u : 0u;
+    if (!vec) for (uint32_t r = first; r < n_rec; r += stride) one(te[r], se[r], ls[r], ls[r + 1]);
     for (uint32_t r = 4 * first; r < n4; r += 4 * stride) {
         const uint4 t4 = *reinterpret_cast<const uint4 *>(te + r), s4 = *reinterpret_cast<const uint4 *>(se + r);
         const uint4 l4 = *reinterpret_cast<const uint4 *>(ls + r);
@@ -216,7 +230,7 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
         one(t4.z, s4.z, l4.z, l4.w);
         one(t4.w, s4.w, l4.w, l5);
     }
-    if (first == 0) for (uint32_t r = n4; r < n_rec; ++r) one(te[r], se[r], ls[r], ls[r + 1]);
+    if (vec && first == 0) for (uint32_t r = n4; r < n_rec; ++r) one(te[r], se[r], ls[r], ls[r + 1]);
     if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
                                                        const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                                                        uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
                                                        uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, PlanResume from,
-                                                       uint64_t buf_end_abs)
+                                                       uint64_t buf_end_abs, uint32_t flags)
 {
     const uint32_t n_rec_total = *total_lines / 4;
     // tail_buf: the job buffer when it ends where the file ends.  Two real newlines behind the last complete record (the
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
             const uint64_t D = bs > ov ? bs - ov : 0;
             const uint64_t n_ls = (uint64_t)n_rec_total + 1;
             const uint32_t last_ls = ls[n_rec_total];
-            if (bs == WINDOW && D && x0 >= buf_off && n_rec_total > 256) {
+            if (bs == WINDOW && D && x0 >= buf_off && n_rec_total > 256 && !(flags & 2u)) {
                 const uint64_t w = ((uint64_t)g.region + D - 1) / D + 1;
                 nwin = w < PL_WIN ? (uint32_t)w : PL_WIN;
             }
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
         return;
     }
     const uint32_t vb = blockIdx.x - n_ranks, nvb = gridDim.x - n_ranks;
-    validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err);
+    validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err, (flags & 1u) != 0);
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
@@ -528,8 +542,11 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
     uint32_t vblocks = (n_rec + 2047) / 2048;
     if (vblocks < 1) vblocks = 1;
     if (vblocks > 16384) vblocks = 16384;
+    // (experiments: NGSC_CV_VEC=1 four records per thread with 16-byte loads - measured SLOWER, see DESIGN.md;
+    // NGSC_CV_NOCACHE=1 the planner without its LDS cache of looked-ahead windows)
+    const uint32_t flags = (getenv("NGSC_CV_VEC") ? 1u : 0u) | (getenv("NGSC_CV_NOCACHE") ? 2u : 0u);
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs);
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs, flags);
 }
 
 }  // namespace ngsc

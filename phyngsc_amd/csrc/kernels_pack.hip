@@ -12,6 +12,7 @@
 // stored plainly, the first/last word of every 64-symbol step is merged with atomicOr.  HBM-bound
 // integer work, no MFMA: algorithmic traffic per record = its bytes read once + its code bits written.
 #include "ngsc_kernels.h"
+#include <algorithm>
 
 namespace ngsc {
 
@@ -161,11 +162,8 @@ __global__ __launch_bounds__(1024) void k_scan_tile(Arena A, uint32_t R)
 
 // One wave per sub-block: stream sizes.  qrow_off[s][row] = byte offset of tree `row` inside the quality header (a
 // prefix sum over up to max_q + 1 tree blobs: as a serial loop of one thread it was 150 dependent loads for 150-base reads).
-__global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
+__device__ __forceinline__ void sizes_wave(const Arena &A, uint32_t s, uint32_t lane, uint32_t *qrow_off)
 {
-    if (*A.err) return;
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
-    if (s >= A.n_sb) return;
     SbState &sb = A.sb[s];
     const uint32_t rows = sb.max_q + 1;
     uint32_t off = sb.nqual;  // alphabet bytes (tasks.cpp:577-581)
@@ -191,16 +189,23 @@ __global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
     sb.total = sb.info_len + sb.title_len + sb.qual_len + sb.dna_len;
 }
 
-// One wave: exclusive prefix sum of the sub-block sizes = their offsets in the output.
-__global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
+__global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
 {
     if (*A.err) return;
-    if (blockIdx.x) return;
-    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= A.n_sb) return;
+    sizes_wave(A, blockIdx.x, threadIdx.x, qrow_off);
+}
+
+// One wave: exclusive prefix sum of the sub-block sizes = their offsets in the output.
+// (fresh: the totals were written by other workgroups of the same launch - read them past the L1)
+template <bool FRESH>
+__device__ __forceinline__ void offsets_wave(const Arena &A, uint32_t lane, uint64_t out_cap, uint64_t *total_out)
+{
     uint64_t off = 0;
     for (uint32_t base = 0; base < A.n_sb; base += 64) {
         const uint32_t s = base + lane;
-        const uint64_t v = s < A.n_sb ? A.sb[s].total : 0ull;
+        uint64_t v = 0;
+        if (s < A.n_sb) v = FRESH ? (uint64_t)__hip_atomic_load(&A.sb[s].total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint64_t)A.sb[s].total;
         uint64_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -214,6 +219,42 @@ __global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint6
         *total_out = off;
         if (off > out_cap) atomicMin(A.err, (int32_t)ERR_CAPACITY);
     }
+}
+
+__global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
+{
+    if (*A.err) return;
+    if (blockIdx.x) return;
+    offsets_wave<false>(A, threadIdx.x, out_cap, total_out);
+}
+
+// (round 3) k_scan_tile, k_sizes and k_offsets as ONE launch for the lane-per-record path - three tiny kernels in a row on the
+// step's critical path cost more in launch gaps than in work: a workgroup scans its sub-block's tile and group totals, its first
+// wave derives the stream sizes, and the workgroup that finishes last (a counter in the step's small state) lays the
+// sub-blocks out.
+__global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done)
+{
+    if (*A.err) return;
+    __shared__ uint32_t s_wave[17];
+    __shared__ uint32_t s_last;
+    const uint32_t s = blockIdx.x;
+    {
+        SbState &sb = A.sb[s];
+        const uint32_t ntiles = (sb.n_rec + R - 1) / R;
+        const uint32_t tq = wg_scan_excl(A.wq + A.tile_lo[s], ntiles, s_wave);
+        const uint32_t td = wg_scan_excl(A.wd + A.tile_lo[s], ntiles, s_wave);
+        const uint32_t tg = wg_scan_excl(A.goff + A.grp_lo[s], (sb.n_rec + GROUP - 1) / GROUP, s_wave);
+        if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) sizes_wave(A, s, threadIdx.x, qrow_off);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    __threadfence();
+    offsets_wave<true>(A, threadIdx.x, out_cap, total_out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -461,9 +502,12 @@ void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, 
                        cleared >> 4);
 }
 
-void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes)
+void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes)   // bytes: a multiple of 16
 {
-    hipLaunchKernelGGL(k_zero_range, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), bytes >> 4);
+    const uint64_t n16 = bytes >> 4;
+    if (!n16) return;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (n16 + 255) / 256);
+    hipLaunchKernelGGL(k_zero_range, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), n16);
 }
 
 void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R)
@@ -493,6 +537,11 @@ void launch_scan_sb(hipStream_t st, const Arena &A)
 void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
 {
     hipLaunchKernelGGL(k_scan_tile, dim3(A.n_sb), dim3(1024), 0, st, A, R);
+}
+
+void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done)
+{
+    hipLaunchKernelGGL(k_layout, dim3(A.n_sb), dim3(1024), 0, st, A, R, qrow_off, out_cap, total_out, done);
 }
 
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out)

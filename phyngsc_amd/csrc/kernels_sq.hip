@@ -22,9 +22,20 @@
 namespace ngsc {
 
 // one 16-byte chunk of a record's bases or qualities: from the chunk-major copy the statistics kernel leaves (Arena::dstride) or the file
+struct __attribute__((packed, aligned(4))) U3a { uint32_t x, y, z; };
 __device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *dense, uint32_t g, uint32_t off, uint32_t file_pos)
 {
-    if (A.dstride) return *reinterpret_cast<const uint4 *>(dense + ((size_t)(off >> 4) * A.dstride + g) * 16);
+    if (A.dstride) {
+        const uint32_t c = off >> 4;
+        if (c == A.dtail_c) {   // the short last chunk (Arena::dtail_b bytes per record; the bytes behind them read as zero)
+            const uint8_t *p = dense + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
+            if (A.dtail_b == 4) return make_uint4(*reinterpret_cast<const uint32_t *>(p), 0, 0, 0);
+            if (A.dtail_b == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(p); return make_uint4(v.x, v.y, 0, 0); }
+            const U3a v = *reinterpret_cast<const U3a *>(p);
+            return make_uint4(v.x, v.y, v.z, 0);
+        }
+        return *reinterpret_cast<const uint4 *>(dense + ((size_t)c * A.dstride + g) * 16);
+    }
     return load16_unaligned(A.buf, file_pos + off, A.buf_len);
 }
 // aligned 16 bytes at a (a multiple of 16), zero behind the end of the job buffer
@@ -39,9 +50,18 @@ __device__ __forceinline__ uint4 load16_guarded_sq(const uint8_t *buf, uint32_t 
 __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32_t off, const uint4 &S, const uint4 &Q)
 {
     if (A.dstride) {
+        const uint32_t c = off >> 4;
+        if (c == A.dtail_c) {
+            uint8_t *ps = A.dense_s + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
+            uint8_t *pq = A.dense_q + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
+            if (A.dtail_b == 4) { *reinterpret_cast<uint32_t *>(ps) = S.x; *reinterpret_cast<uint32_t *>(pq) = Q.x; }
+            else if (A.dtail_b == 8) { *reinterpret_cast<uint2 *>(ps) = make_uint2(S.x, S.y); *reinterpret_cast<uint2 *>(pq) = make_uint2(Q.x, Q.y); }
+            else { *reinterpret_cast<U3a *>(ps) = U3a{S.x, S.y, S.z}; *reinterpret_cast<U3a *>(pq) = U3a{Q.x, Q.y, Q.z}; }
+            return;
+        }
         // (plain stores: with the non-temporal hint the kernel is no faster and the readers lose what the caches kept)
-        *reinterpret_cast<uint4 *>(A.dense_s + ((size_t)(off >> 4) * A.dstride + g) * 16) = S;
-        *reinterpret_cast<uint4 *>(A.dense_q + ((size_t)(off >> 4) * A.dstride + g) * 16) = Q;
+        *reinterpret_cast<uint4 *>(A.dense_s + ((size_t)c * A.dstride + g) * 16) = S;
+        *reinterpret_cast<uint4 *>(A.dense_q + ((size_t)c * A.dstride + g) * 16) = Q;
     }
 }
 
@@ -401,6 +421,331 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         const uint32_t row = k / SR_HCOLS, col = k % SR_HCOLS;
         const uint32_t x = s_hist[row * SR_HSTRIDE + col];
         if (x) atomicAdd(&qh[(size_t)row * 256 + 33 + col], x);
+    }
+    if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
+    if (tid == 0) {
+        atomicMax(&A.sb[s].max_q, s_red[0]);
+        atomicMax(&A.sb[s].max_s, s_red[1]);
+        atomicAdd(&A.sb[s].n_bases, s_red[2]);
+    }
+}
+
+// ====================================================================================================
+// (round 3) LONG reads, staged: LPR lanes per record.  With one lane per record the 64 records of a wave span 22 KB of the
+// file at 150 bases - too much LDS to stage them as the short-read form does - and every lane pulls its twenty 16-byte chunks
+// in with scattered loads (the texture path prices a wave instruction of those at ~200 cycles; the BURST form above hides
+// some of it).  Here a wave takes 64 / LPR records - a contiguous 5.6 KB at 150 bases and LPR = 4 - fetches them with
+// coalesced 1 KB rows into LDS like the short-read form, and lane j of a record's LPR lanes walks its chunks j, j + LPR, ...
+// Same statistics, same copies; what a record's lanes found (base counts, ambiguity codes and their positions) is put
+// together with shuffles inside the aligned lane group.  The body of a chunk is the masked general path of
+// k_sq_stats_reg (the lanes of a wave are at different positions of their reads, so no row offset is a constant).
+template <uint32_t LPR>
+__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_sq_stats_multi(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
+{
+    static_assert(LPR == 2 || LPR == 4 || LPR == 8, "lanes per record");
+    if (*A.err) return;
+    // Histogram: 16-bit counters, two positions per word - positions 16c + u and 16c + u + 8 (u < 8) share slot 8c + u, low and
+    // high half (a workgroup sees at most 1024 records, so no half can overflow): 15 KB instead of 30 for 150-base reads, which
+    // with the spans is the difference between two and four workgroups per CU.  lds_rows: rows of the sub-block's table (positions
+    // + 1) - the launcher only takes this kernel when all of them fit.
+    extern __shared__ __align__(16) uint32_t s_hist[];   // [slots][SR_HSTRIDE], 64 trash words, the waves' spans
+    __shared__ uint32_t s_occ[256];
+    __shared__ uint8_t s_amb[256];
+    __shared__ uint32_t s_red[3];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t first = blockIdx.x * rpw;
+    if (first >= n) return;
+    const uint32_t last = first + rpw < n ? first + rpw : n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t sub = (uint32_t)tid % LPR;          // this lane's place among its record's lanes
+    const uint32_t nslots = 8 * ((lds_rows + 14) / 16);   // rows 1 .. lds_rows - 1 = positions 0 .. lds_rows - 2
+    const uint32_t hwords = nslots * SR_HSTRIDE;
+    uint8_t *const span = reinterpret_cast<uint8_t *>(s_hist + ((hwords + 64 + 3) & ~3u)) + (size_t)(tid >> 6) * span_cap;
+    uint32_t span_lo = 0;
+
+    for (uint32_t k = tid; k < hwords; k += SR_THREADS) s_hist[k] = 0;
+    s_occ[tid] = 0;
+    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
+    if (tid < 3) s_red[tid] = 0;
+    __syncthreads();
+
+    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
+    uint8_t *hb = reinterpret_cast<uint8_t *>(s_hist);
+    const uint32_t trash = (hwords + lane) * 4;
+    uint32_t t0 = 0, t1 = 0, t01 = 0, nok = 0, mq = 0, ms = 0, sum_l = 0;
+    // rotation of the quality bytes among the lanes that are at the same positions (the lanes sub, sub + LPR, ...)
+    const uint32_t lj = ((uint32_t)lane / LPR) & 3;
+    uint32_t bsh[4], boff[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t bb = (b + (((uint32_t)lane / LPR) >> 2)) & 3;
+        bsh[b] = 8 * bb;
+        boff[b] = bb * SR_HSTRIDE * 4;
+    }
+    auto gsum = [](uint32_t v) __attribute__((always_inline)) {   // sum over the record's lanes
+#pragma unroll
+        for (uint32_t d = 1; d < LPR; d <<= 1) v += (uint32_t)__shfl_xor((int)v, (int)d);
+        return v;
+    };
+    auto gor = [](uint32_t v) __attribute__((always_inline)) {
+#pragma unroll
+        for (uint32_t d = 1; d < LPR; d <<= 1) v |= (uint32_t)__shfl_xor((int)v, (int)d);
+        return v;
+    };
+
+    constexpr uint32_t RPB = SR_THREADS / LPR;   // records per workgroup batch
+    for (uint32_t base = first; base < last; base += RPB) {
+        const uint32_t i = base + (uint32_t)tid / LPR;
+        const bool valid = i < last;
+        const uint32_t g = rec_lo + (valid ? i : first);
+        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t L = valid ? se - te - 1 : 0;
+        const uint32_t s0 = te + 1, q0 = se + 3;
+        if (valid && sub == 0) {
+            if (L == 0 && (load8_unaligned(A.buf, se, A.buf_len).x & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
+            if (i == 0 && L >= 1 && !A.cs_mode) {
+                if (cs_first_read(A.buf[s0], A.buf[s0 + 1])) atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+            }
+        }
+        {   // the wave's records -> LDS, 1 KB per row
+            const unsigned long long vm = __ballot(valid);
+            if (vm) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0) & ~15u;
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(q0 + L), (int)__builtin_popcountll(vm) - 1);
+                const uint32_t rows = (hi - lo + 1023u) >> 10;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t r0 = 0; r0 < rows; r0 += 4) {
+                    uint4 v[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (r0 + k < rows) v[k] = load16_guarded_sq(A.buf, lo + 1024u * (r0 + k) + 16u * lane, A.buf_len);
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (r0 + k < rows) *reinterpret_cast<uint4 *>(span + 1024u * (r0 + k) + 16u * lane) = v[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                span_lo = lo;
+            }
+        }
+        auto ld16 = [&](uint32_t pos) __attribute__((always_inline)) -> uint4 {
+            const U4u v = *reinterpret_cast<const U4u *>(span + (pos - span_lo));
+            return make_uint4(v.x, v.y, v.z, v.w);
+        };
+
+        const uint32_t b_t0 = t0, b_t1 = t1, b_t01 = t01, b_nok = nok;
+        uint32_t fl = 0, namb = 0;
+        uint32_t nall = 0, apos0 = 0, apos1 = 0;   // this LANE's non-ACGT bytes and the positions of its first four
+        for (uint32_t grp = 0; __any(16 * (LPR * grp + sub) < L); ++grp) {
+            const uint32_t ch = LPR * grp + sub;
+            const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
+            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
+            if (nv) {
+                S = ld16(s0 + 16 * ch);
+                Q = ld16(q0 + 16 * ch);
+                sq_chunk_keep(A, g, 16 * ch, S, Q);
+            }
+            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            if (nv != 0 && L <= 16 * ch + 16) {   // the end of the read: "\n+\n" follows
+                uint32_t two;
+                if (nv <= 13) {
+                    const uint32_t o = nv + 1, wi = o >> 2;
+                    const uint32_t lo = wi == 0 ? sw[0] : (wi == 1 ? sw[1] : (wi == 2 ? sw[2] : sw[3]));
+                    const uint32_t hi = wi == 0 ? sw[1] : (wi == 1 ? sw[2] : sw[3]);
+                    two = __builtin_amdgcn_alignbit(hi, lo, (o & 3) * 8) & 0xffffu;
+                } else {
+                    two = (load4_unaligned(A.buf, se) >> 8) & 0xffffu;
+                }
+                if (two != 0x0a2bu) atomicMin(A.err, (int32_t)ERR_FORMAT);
+            }
+            uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                const uint32_t w = (sw[k] & vm) | (0x41414141u & ~vm);
+                idx[k] = sr_idx(w);
+                d[k] = sr_not_acgt(w, idx[k]);
+                dacc |= d[k];
+                qbad |= sr_q_out(qw[k]) & vm;
+                const uint32_t p0 = idx[k] & 0x01010101u, p1 = (idx[k] >> 1) & 0x01010101u;
+                c0 += __builtin_popcount(p0);
+                c1 += __builtin_popcount(p1);
+                c01 += __builtin_popcount(p0 & p1);
+            }
+            const uint32_t rb = 8 * ch * SR_HSTRIDE * 4 - 33 * 4;   // (per lane: the lanes of a wave are at different positions)
+            if (!__any(nv != 0 && (nv != 16 || dacc != 0 || qbad != 0))) {
+                // every lane that still has bytes: sixteen plain qualities, only A/C/G/T
+                if (nv) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t j = (k + lj) & 3;
+                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                        const uint32_t joff = rb + (j & 1) * (4 * SR_HSTRIDE * 4), inc = 1u << (16 * (j >> 1));
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                            atomicAdd(reinterpret_cast<uint32_t *>(hb + joff + boff[b] + 4 * q), inc);
+                        }
+                    }
+                    t0 += c0; t1 += c1; t01 += c01; nok += 16;
+                }
+            } else {
+                uint32_t ambm = 0, qbm = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    ambm |= t_movemask(t_nonzero01(d[k])) << (4 * k);
+                    qbm |= t_movemask((sr_q_out(qw[k]) >> 7) & 0x01010101u) << (4 * k);
+                }
+                const uint32_t validm = (1u << nv) - 1u;
+                ambm &= validm;
+                const uint32_t okm = validm & ~ambm & ~qbm;          // (every row of the table has its slot)
+                const uint32_t glm = validm & ~ambm & ~okm;
+                if (ambm) {
+                    c0 = c1 = c01 = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t ok01 = t_nonzero01(d[k]) ^ 0x01010101u;
+                        const uint32_t p0 = idx[k] & ok01, p1 = (idx[k] >> 1) & ok01;
+                        c0 += __builtin_popcount(p0);
+                        c1 += __builtin_popcount(p1);
+                        c01 += __builtin_popcount(p0 & p1);
+                    }
+                }
+                // (bytes behind the read's end were counted as 'A' with both planes clear: nothing to take back)
+                t0 += c0; t1 += c1; t01 += c01; nok += nv - __builtin_popcount(ambm);
+                if (__any(okm)) {   // branch-free: bytes that do not count go to the lane's own trash word
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t j = (k + lj) & 3;
+                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                        const uint32_t joff = rb + (j & 1) * (4 * SR_HSTRIDE * 4), inc = 1u << (16 * (j >> 1));
+                        const uint32_t okw = okm >> (4 * j);
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                            const uint32_t a = ((okw >> (bsh[b] >> 3)) & 1u) ? joff + boff[b] + 4 * q : trash;
+                            atomicAdd(reinterpret_cast<uint32_t *>(hb + a), inc);
+                        }
+                    }
+                }
+                if (__any(glm)) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u)
+                        if ((glm >> u) & 1u) atomicAdd(&qh[(size_t)(16 * ch + u + 1) * 256 + sr_byte(qw, u)], 1u);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!__any((ambm >> (4 * k)) & 15u)) continue;
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        const uint32_t u = 4 * k + b;
+                        if ((ambm >> u) & 1u) {
+                            const uint32_t a = s_amb[sr_byte(sw, u)];
+                            if (a == 0) fl |= 2;
+                            else {
+                                const uint32_t q = sr_byte(qw, u);
+                                fl |= (q < 33 || q > 40) ? 2u : 1u;
+                                ++namb;
+                            }
+                            const uint32_t p16 = 16 * ch + u;
+                            const uint32_t pv = p16 << (16 * (nall & 1u));
+                            apos0 |= nall < 2 ? pv : 0u;
+                            apos1 |= (nall >= 2 && nall < 4) ? pv : 0u;
+                            ++nall;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the record's lanes put together what they found ----
+        const uint32_t fl_r = gor(fl), namb_r = gsum(namb), nall_r = gsum(nall < 8 ? nall : 8u);
+        const bool xfer = (fl_r & 1) && !(fl_r & 2);
+        const uint32_t kept = L - (xfer ? namb_r : 0);
+        {
+            // positions of up to four ambiguity codes of the record: every lane's list moves behind those of the lanes in front
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t d = 1; d < LPR; ++d) {
+                const uint32_t o = (uint32_t)__shfl((int)(nall < 8 ? nall : 8u), (int)(((uint32_t)lane & ~(LPR - 1)) + ((sub + LPR - d) % LPR)));
+                before += (sub >= d) ? o : 0u;   // lanes sub - d (those in front of this one)
+            }
+            uint64_t mine = ((uint64_t)apos1 << 32) | apos0;
+            mine = before < 4 ? mine << (16 * before) : 0ull;
+            uint32_t m0 = gor((uint32_t)mine), m1 = gor((uint32_t)(mine >> 32));
+            const uint32_t r0 = gsum(t0 - b_t0), r1 = gsum(t1 - b_t1), r01 = gsum(t01 - b_t01), rok = gsum(nok - b_nok);
+            if (valid && sub == 0) {
+                A.slen[g] = kept | ((nall_r < 7 ? nall_r : 7u) << 28) | ((uint32_t)xfer << 31);
+                if (nall_r >= 1 && nall_r <= 4) A.apos[g] = AmbPos{m0, m1};
+                A.bcnt[g] = (uint64_t)(rok - r0 - r1 + r01) | ((uint64_t)(r0 - r01) << 16) | ((uint64_t)(r1 - r01) << 32) | ((uint64_t)r01 << 48);
+                mq = L > mq ? L : mq;
+                ms = kept > ms ? kept : ms;
+                sum_l += L;
+            }
+        }
+        // ---- the ambiguous positions, now that the record's transfer decision is known (phyNGSC.cpp:573-599): each lane its own ----
+        for (uint32_t k = 0; k < 4 && __any(nall > k && nall_r <= 4); ++k) {
+            if (nall > k && nall_r <= 4) {
+                const uint32_t pos = ((k < 2 ? apos0 : apos1) >> (16 * (k & 1))) & 0xffffu, row = pos + 1;
+                const uint32_t c = A.buf[s0 + pos], q = A.buf[q0 + pos];
+                const uint32_t a = s_amb[c];
+                if (xfer && a > 1) {
+                    atomicAdd(&qh[(size_t)row * 256 + transfer_quality(a, (uint8_t)q)], 1u);
+                } else {
+                    const uint32_t col = q - 33;
+                    if (col < SR_HCOLS && row < lds_rows) atomicAdd(&s_hist[(8 * (pos >> 4) + (pos & 7)) * SR_HSTRIDE + col], 1u << (2 * (pos & 8)));
+                    else atomicAdd(&qh[(size_t)row * 256 + q], 1u);
+                    atomicAdd(&s_occ[c], 1u);
+                }
+            }
+        }
+        if (__any(nall_r > 4)) {   // records with many ambiguity codes: rescanned by their first lane
+            for (uint32_t ch = 0; __any(nall_r > 4 && sub == 0 && 16 * ch < L); ++ch) {
+                if (nall_r > 4 && sub == 0 && 16 * ch < L) {
+                    const uint32_t nv = L - 16 * ch < 16 ? L - 16 * ch : 16;
+                    const uint4 S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
+                    const uint4 Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
+                    const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+                    const uint32_t ambm = sr_amb_mask(sw, nv);
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u) {
+                        if ((ambm >> u) & 1u) {
+                            const uint32_t c = sr_byte(sw, u), q = sr_byte(qw, u), row = 16 * ch + u + 1;
+                            const uint32_t a = s_amb[c];
+                            if (xfer && a > 1) {
+                                atomicAdd(&qh[(size_t)row * 256 + transfer_quality(a, (uint8_t)q)], 1u);
+                            } else {
+                                const uint32_t col = q - 33;
+                                const uint32_t pos = row - 1;
+                                if (col < SR_HCOLS && row < lds_rows) atomicAdd(&s_hist[(8 * (pos >> 4) + (pos & 7)) * SR_HSTRIDE + col], 1u << (2 * (pos & 8)));
+                                else atomicAdd(&qh[(size_t)row * 256 + q], 1u);
+                                atomicAdd(&s_occ[c], 1u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- workgroup totals ----
+    {
+        const uint32_t nG = t01, nC = t0 - t01, nT = t1 - t01, nA = nok - t0 - t1 + t01;
+        const uint32_t wa = sr_wsum(nA), wc = sr_wsum(nC), wg = sr_wsum(nG), wt = sr_wsum(nT);
+        const uint32_t wq = sr_wmax(mq), wms = sr_wmax(ms), wl = sr_wsum(sum_l);
+        if (lane == 0) {
+            atomicAdd(&s_occ['A'], wa); atomicAdd(&s_occ['C'], wc); atomicAdd(&s_occ['G'], wg); atomicAdd(&s_occ['T'], wt);
+            atomicMax(&s_red[0], wq); atomicMax(&s_red[1], wms); atomicAdd(&s_red[2], wl);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nslots * SR_HCOLS; k += SR_THREADS) {
+        const uint32_t slot = k / SR_HCOLS, col = k % SR_HCOLS;
+        const uint32_t x = s_hist[slot * SR_HSTRIDE + col];
+        const uint32_t row = 16 * (slot >> 3) + (slot & 7) + 1;   // the low half's row; the high half's is eight further on
+        if (x & 0xffffu) atomicAdd(&qh[(size_t)row * 256 + 33 + col], x & 0xffffu);
+        if (x >> 16) atomicAdd(&qh[(size_t)(row + 8) * 256 + 33 + col], x >> 16);
     }
     if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
     if (tid == 0) {
@@ -1121,6 +1466,25 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
     if (staged) lds = ((lds + 15) & ~(size_t)15) + (size_t)(SR_THREADS / 64) * span_cap;
     else if (lds < (24u << 10)) lds = 24u << 10;
+    // (round 3) long reads whose whole table fits the packed LDS histogram: four lanes per record on staged spans
+    // (NGSC_SQ_MULTI=0: the burst form; =2 / 4 / 8: that many lanes per record)
+    if (!staged && sr_burst(A) && max_rec_bytes) {
+        static const int forced = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;
+        const uint32_t lpr = forced > 0 ? (uint32_t)forced : 4u;
+        const uint32_t mcap = ((64u / lpr) * max_rec_bytes + 48u + 1023u) & ~1023u;
+        const uint32_t nslots = 8 * ((A.qrows + 14) / 16);
+        const size_t mlds = ((((size_t)nslots * SR_HSTRIDE + 64) * 4 + 15) & ~(size_t)15) + (size_t)(SR_THREADS / 64) * mcap;
+        if (forced != 0 && (lpr == 2 || lpr == 4 || lpr == 8) && mlds <= (64u << 10)) {
+            // records per workgroup: batches of SR_THREADS / lpr
+            const uint32_t rpb = SR_THREADS / lpr;
+            uint32_t mrpw = rpw < rpb ? rpb : rpw / rpb * rpb;
+            dim3 mgrid((max_rec + mrpw - 1) / mrpw, A.n_sb);
+            auto mk = lpr == 2 ? k_sq_stats_multi<2> : (lpr == 4 ? k_sq_stats_multi<4> : k_sq_stats_multi<8>);
+            if (mlds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mk), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+            hipLaunchKernelGGL(mk, mgrid, dim3(SR_THREADS), mlds, st, A, A.qrows, mrpw, mcap);
+            return;
+        }
+    }
     auto kern = staged ? k_sq_stats_reg<false, true> : (sr_burst(A) ? k_sq_stats_reg<true, false> : k_sq_stats_reg<false, false>);
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw, span_cap);

@@ -318,6 +318,10 @@ struct Arena {
     // instead of 16 bytes each at addresses a whole record apart.  dstride == 0: off
     uint8_t *dense_s, *dense_q;
     uint32_t dstride;
+    // (round 3) the LAST chunk of the job's longest read, when it holds at most 12 bytes (36 bases: 16 + 16 + 4), is kept as
+    // dtail_b = 4 / 8 / 12 bytes per record instead of 16: chunk dtail_c of record g at dense_x + dtail_c * dstride * 16 + g * dtail_b
+    // (a quarter of the copies' bytes at 36 bases).  dtail_c == 0xffffffff: every chunk is 16 bytes
+    uint32_t dtail_c, dtail_b;
     uint8_t *out;           // output buffer
 };
 

@@ -652,6 +652,12 @@ def test_decompress_file_shared_records_and_cli(eng, tmp_path):
     r = subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True)
     assert r.returncode == 0, r.stderr
     assert back.read_bytes() == big.tobytes()
+    # the same file in batches of three sub-blocks: reader, decoder and writer threads with two buffers between each pair
+    back.unlink()
+    r = subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True, env=dict(os.environ, NGSC_DEC_BATCH="3", NGSC_VERBOSE="1"))
+    assert r.returncode == 0, r.stderr
+    assert b"batches" in r.stderr and b" in 1 batches" not in r.stderr, r.stderr
+    assert back.read_bytes() == big.tobytes()
     raw = mid.read_bytes()
     mid.write_bytes(raw[:len(raw) // 2])          # (the format has no checksums: what can be refused is a broken structure)
     assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
@@ -723,7 +729,10 @@ def test_record_shared_by_two_ranks(eng):
         res, out = _gpu(eng, data, P)
         want, _ = orc.compress_file(data, P)
         assert out == want, P
-        shared += sum(sb.n_records for sb in res.subblocks) - len(recs) > 0
+        is_shared = sum(sb.n_records for sb in res.subblocks) - len(recs) > 0
+        shared += is_shared
+        # both public decode entry points place a rank's text at its stretch of the file: the shared record comes out once
+        assert api.decompress_bytes(out, engine=eng) == data, (P, is_shared)
     assert shared, "no rank split of this input shares a record: the test input lost its point"
 
 
