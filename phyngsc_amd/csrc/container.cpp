@@ -458,16 +458,21 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                 const size_t acc0 = acc.size();
                 for (size_t k = 0; k < res.ranks.size(); ++k) {
                     const ngsc_rank_t &rk = res.ranks[k];
+                    // (round 3) a rank walked in parts whose blocks are written as they fill (jb.stream) keeps only what is left over
+                    // behind the last written block (less than a block): its new bytes are written straight from the pinned buffer.
+                    // Until round 3 every byte of such a rank went through a std::vector first - a single-threaded copy of the whole
+                    // output, which is what the compress thread was waiting for ("output buffer" in the log).
+                    const bool direct = jb.part && jb.stream;
                     if (jb.part && !jb.first_part) {   // the same rank goes on
                         RankAcc &ra = acc.back();
                         ra.sb.insert(ra.sb.end(), res.sb_sizes.begin(), res.sb_sizes.end());
-                        ra.carry.insert(ra.carry.end(), hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
+                        if (!direct) ra.carry.insert(ra.carry.end(), hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
                     } else {
                         RankAcc ra;
                         ra.rank = rk.rank;
                         ra.ov = jb.part ? res.part.overlap_used : rk.overlap_used;
                         ra.sb.assign(res.sb_sizes.begin() + rk.first_subblock, res.sb_sizes.begin() + rk.first_subblock + rk.n_subblocks);
-                        if (!single_job_group) ra.carry.assign(hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
+                        if (!single_job_group && !direct) ra.carry.assign(hb + rk.stream_off, hb + rk.stream_off + rk.stream_bytes);
                         acc.push_back(std::move(ra));
                     }
                 }
@@ -482,11 +487,27 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                     if ((rc = plan(ra))) break;
                     const bool done = res.part.done != 0;
                     const uint32_t upto = done ? (uint32_t)blocks.size() : (blocks.empty() ? 0 : (uint32_t)blocks.size() - 1);
+                    // the rank's stream so far: [carry_base, new_base) in ra.carry, [new_base, new_base + new_len) in the pinned buffer
+                    const uint8_t *newp = hb + res.ranks[0].stream_off;
+                    const uint64_t new_len = res.ranks[0].stream_bytes, new_base = ra.carry_base + ra.carry.size();
                     uint64_t drop_to = ra.carry_base;
                     std::vector<WriteItem> items;
+                    std::vector<std::vector<uint8_t>> joined;   // a block that begins in the carry: its bytes put together (one per job at most)
+                    joined.reserve(upto > ra.emitted ? upto - ra.emitted : 0);
                     for (uint32_t k = ra.emitted; k < upto; ++k) {
                         const ngsc_block_t &b = blocks[k];
-                        items.push_back({sink->cursor, b.header, b.header_len, ra.carry.data() + (b.stream_off - ra.carry_base), b.payload});
+                        const uint8_t *src;
+                        if (b.stream_off >= new_base) src = newp + (b.stream_off - new_base);
+                        else {
+                            const uint64_t from_carry = std::min<uint64_t>(b.payload, new_base - b.stream_off);
+                            joined.emplace_back();
+                            std::vector<uint8_t> &t = joined.back();
+                            t.resize(b.payload);
+                            memcpy(t.data(), ra.carry.data() + (b.stream_off - ra.carry_base), from_carry);
+                            if (b.payload > from_carry) memcpy(t.data() + from_carry, newp, b.payload - from_carry);
+                            src = t.data();
+                        }
+                        items.push_back({sink->cursor, b.header, b.header_len, src, b.payload});
                         sink->cursor += b.size;            // (this worker holds the turn: nobody else moves the cursor)
                         sink->cbo.push_back(ra.rank);
                         ra.last_size = b.size;
@@ -494,7 +515,12 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                     }
                     if (!write_items(sink->fd, items)) { rc = NGSC_ERR_IO; break; }
                     ra.emitted = upto;
-                    ra.carry.erase(ra.carry.begin(), ra.carry.begin() + (size_t)(drop_to - ra.carry_base));
+                    // what is left for the next part: the stream behind the last written block
+                    if (drop_to >= new_base) ra.carry.assign(newp + (drop_to - new_base), newp + new_len);
+                    else {
+                        ra.carry.erase(ra.carry.begin(), ra.carry.begin() + (size_t)(drop_to - ra.carry_base));
+                        ra.carry.insert(ra.carry.end(), newp, newp + new_len);
+                    }
                     ra.carry_base = drop_to;
                     if (done) {
                         sink->ov[ra.rank] = ra.ov; sink->lbs[ra.rank] = ra.last_size; sink->nblocks[ra.rank] = ra.emitted;
@@ -633,6 +659,13 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     Sink sink;
     sink.fd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (sink.fd < 0) return NGSC_ERR_IO;
+    // (round 3) room for the output is reserved up front - a guess of 40 % of the input, cut back to the real size at the end:
+    // on the GPU box's file system eight threads write preallocated page-cache pages at 16 GB/s and fresh ones at 10.5
+    // (tools/ubench_write.c, profiles/r03_ubench_write.txt).  fallocate(2), not posix_fallocate: a file system without it says
+    // so instead of being filled with zeros.  NGSC_FALLOCATE=0: off
+    bool reserved = false;
+    if (!(getenv("NGSC_FALLOCATE") && !strcmp(getenv("NGSC_FALLOCATE"), "0")))
+        reserved = ::fallocate(sink.fd, 0, 0, (off_t)(FS / 5 * 2 + (16u << 20))) == 0;
     sink.ov.assign(P, 0);
     sink.lbs.assign(P, 0);
     sink.nblocks.assign(P, 0);
@@ -658,6 +691,7 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
         std::vector<uint8_t> footer(256 + 4 * (size_t)n_blocks_total + 8 * (size_t)P);
         uint32_t fl = ngsc_make_footer(footer.data(), P, FS, n_blocks_total, sink.n_sub_total, sink.ov.data(), sink.cbo.data(), sink.lbs.data());
         okw = pwrite_all(sink.fd, footer.data(), fl, sink.cursor);
+        if (okw && reserved && ::ftruncate(sink.fd, (off_t)(sink.cursor + fl)) != 0) okw = false;
     }
     ::close(sink.fd);
     double t3 = now_s();

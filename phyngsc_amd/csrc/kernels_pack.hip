@@ -236,7 +236,6 @@ __global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *
 {
     if (*A.err) return;
     __shared__ uint32_t s_wave[17];
-    __shared__ uint32_t s_last;
     const uint32_t s = blockIdx.x;
     {
         SbState &sb = A.sb[s];
@@ -247,12 +246,13 @@ __global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *
         if (threadIdx.x == 0) { sb.qbits = tq; sb.dbits = td; sb.title_body = tg; }
     }
     __syncthreads();
-    if (threadIdx.x < 64) sizes_wave(A, s, threadIdx.x, qrow_off);
+    if (threadIdx.x >= 64) return;   // the rest is one wave's work (no barrier behind this line)
+    sizes_wave(A, s, threadIdx.x, qrow_off);
     __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 64) return;
+    uint32_t last = 0;
+    if (threadIdx.x == 0) last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    last = (uint32_t)__shfl((int)last, 0);
+    if (!last) return;
     __threadfence();
     offsets_wave<true>(A, threadIdx.x, out_cap, total_out);
 }

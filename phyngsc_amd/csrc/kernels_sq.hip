@@ -1451,7 +1451,7 @@ static bool sr_staged(const Arena &A, uint32_t max_rec_bytes, uint32_t &span_cap
     return span_cap <= (10u << 10);
 }
 
-void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes)
+void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes, uint32_t n_rec_total)
 {
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
@@ -1468,7 +1468,12 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     else if (lds < (24u << 10)) lds = 24u << 10;
     // (round 3) long reads whose whole table fits the packed LDS histogram: four lanes per record on staged spans
     // (NGSC_SQ_MULTI=0: the burst form; =2 / 4 / 8: that many lanes per record)
-    if (!staged && sr_burst(A) && max_rec_bytes) {
+    // Only where the reads are about equally long (the job's average record is at least 3/4 of its longest): a record's lanes
+    // walk ceil(chunks / 4) trips whatever the other records of the wave need, and on 36..150-base reads the form lost 25 %
+    // (0.39 -> 0.53 ms per 400 MB) where it gains 8 % on 150-base reads (0.324 -> 0.298)
+    const bool even = (uint64_t)A.buf_len / (n_rec_total ? n_rec_total : 1u) * 4 >= (uint64_t)max_rec_bytes * 3;
+    static const int forced_any = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;
+    if (!staged && sr_burst(A) && max_rec_bytes && (even || forced_any > 0)) {
         static const int forced = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;
         const uint32_t lpr = forced > 0 ? (uint32_t)forced : 4u;
         const uint32_t mcap = ((64u / lpr) * max_rec_bytes + 48u + 1023u) & ~1023u;

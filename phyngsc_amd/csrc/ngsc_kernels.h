@@ -22,7 +22,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           uint64_t buf_end_abs);
 
 // ---- kernels_sq.hip ----
-void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes);
+void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes, uint32_t n_rec_total);
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t stage_q_words, uint32_t stage_d_words);
 
