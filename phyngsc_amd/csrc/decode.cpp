@@ -25,7 +25,7 @@ void launch_dec_head(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off,
                      uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, bool allow_spec, uint32_t *summary);
 void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
                         uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, uint16_t *hop, const uint64_t *hop_off,
-                        uint32_t max_tiles, uint32_t spec_max_q);
+                        uint32_t max_tiles, uint32_t spec_max_q, uint32_t spec_max_nq);
 size_t dec_ctl_bytes();
 uint32_t dec_qspec_tile();
 uint32_t dec_sub_spec(const void *h, uint32_t s);
@@ -117,15 +117,15 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
             hipMemcpyAsync(d_len, sb_len + b0, 4ull * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(d_hoff, hoff.data(), 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         if (use_hop && hipMemsetAsync(d_hop, 0xFF, 2ull * hpos, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-        uint32_t spec_max_q = 0;
-        if (hipMemsetAsync(d_sum, 0, 4, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
+        uint32_t spec_sum[2] = {0, 0};   // longest read, largest quality alphabet among the sub-blocks the speculative kernels take
+        if (hipMemsetAsync(d_sum, 0, 8, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         launch_dec_head(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop, d_sum);
-        if (use_hop && (hipMemcpyAsync(&spec_max_q, d_sum, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        if (use_hop && (hipMemcpyAsync(spec_sum, d_sum, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
             rc = NGSC_ERR_HIP;
             break;
         }
         launch_dec_streams(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop ? d_hop : nullptr,
-                           d_hoff, max_tiles, spec_max_q);
+                           d_hoff, max_tiles, spec_sum[0], spec_sum[1]);
         if (hipMemcpyAsync(h_res.data(), d_res, rb * nb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = NGSC_ERR_HIP;
             break;
@@ -355,7 +355,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     uint64_t max_in = 0;
     uint32_t max_nb = 0;
     {
-        const uint32_t per = getenv("NGSC_DEC_BATCH") ? (uint32_t)std::max(1, atoi(getenv("NGSC_DEC_BATCH"))) : 512u;   // (tests: small batches)
+        const uint32_t per = getenv("NGSC_DEC_BATCH") ? (uint32_t)std::max(1, atoi(getenv("NGSC_DEC_BATCH"))) : 256u;   // (tests: small batches; 256: pinning the buffers of 512 took longer than the larger batches saved)
         for (size_t b0 = 0; b0 < order.size();) {
             size_t b1 = b0; uint64_t bytes = 0;
             while (b1 < order.size() && b1 - b0 < per && bytes + order[b1]->bytes + 32 <= (2ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }

@@ -15,6 +15,7 @@
 //   k_dec_tail      what is left of the serial streams: qualities of unequal reads, Huffman-coded bases
 //   k_dec_assemble  per record: title \n bases \n + \n qualities \n
 // Integer / bit work; bounded by dependent-load latency of one lane per wave (no MFMA, no bandwidth to speak of).
+#include <cstring>
 #include "ngsc_kernels.h"
 #include "ngsc_swar.h"
 
@@ -299,6 +300,13 @@ struct DecCtl {   // state of one sub-block's decode: lane 0 -> wave inside a ke
     uint32_t chain_i, pad1_;
     uint64_t pool_off;       // bump offset of the pool behind the head kernel
     uint64_t t_head;
+    // Huffman-coded bases, decoded in parallel (k_dec_dna_*): 0 not taken, 1 waiting for the kernels, 2 decoded, 3 they gave up
+    uint32_t dna_spec, dna_maxlen, dna_nseg, dna_bad;
+    uint64_t dna_p0, dna_total;      // first bit of the code stream; symbols in it
+    const uint16_t *dna_tab;         // its DEC_K-bit table in global memory (entries carry the output byte)
+    uint32_t dna_n, dna_root;        // the tree, for the serial fallback
+    uint16_t *dna_lc, *dna_rc;
+    uint64_t t_qual;
     uint8_t qsym[256];       // quality alphabet: symbol index -> byte
 };
 
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     if (lane == 0) {
         O.err = OK; O.text_bytes = 0; O.n_rec = 0;
         ctl[s].err = ERR_FORMAT;   // (overwritten with the whole state when the head has gone through)
-        C.spec = 0; C.spec_bad = 0;
+        C.spec = 0; C.spec_bad = 0; C.dna_spec = 0; C.dna_bad = 0;
         stack = (uint16_t *)pool.take(2 * (2 * 512 + 2));
         C.err = dec_info(r, D, O, rec_cap, C);
         if (C.err) O.err = C.err;
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     __syncthreads();
     if (C.err) return;
     for (uint32_t k = lane; k < sizeof(DecCtl) / 4; k += 64) reinterpret_cast<uint32_t *>(&ctl[s])[k] = reinterpret_cast<const uint32_t *>(&C)[k];
-    if (lane == 0 && C.spec) atomicMax(&summary[0], C.max_q);   // the longest read the speculative kernels will meet: their LDS tables
+    if (lane == 0 && C.spec) { atomicMax(&summary[0], C.max_q); atomicMax(&summary[1], C.nqual); }   // the longest read / largest alphabet the speculative kernels will meet: their LDS
 }
 
 // ---- the quality stream of equally long reads, decoded speculatively ------------------------------------------------------------
@@ -978,12 +986,74 @@ __device__ __forceinline__ uint32_t qs_record(const uint32_t *p32, uint32_t ndw,
     return total;
 }
 
+// (round 3) Kernel A only needs code LENGTHS: a table of bytes (K bits of look-ahead per row, the code's length, 0 = longer than K)
+// takes half the LDS of the entries with symbols - three workgroups per CU instead of two at 150 bases - and leaves room for
+// the trees themselves (child tables as bytes: alphabets of up to 128 symbols), so that a code longer than K bits is walked in
+// LDS, not in global memory: with K = 8 at 150 bases one lane in four hundred steps meets such a code, i.e. one wave in six at
+// every step, and the whole wave waited ~10 dependent memory round trips for it (0.15 s of the 0.6 s a 400 MB file of 150-base
+// reads took).  Returns the record's bits from bit offset b, or ~0u.
+struct QsLenTabs {
+    const uint8_t *len;      // [rows << K]
+    const uint8_t *lc, *rc;  // [rows][nq] children of internal node nq + i of the row's tree (byte node ids), or nullptr
+    const uint8_t *root;     // [rows]
+    uint32_t K, nq;
+};
+__device__ __forceinline__ uint32_t qs_record_len(const uint32_t *p32, uint32_t ndw, uint64_t b, uint32_t L, const QsLenTabs &T, const DTree *qt)
+{
+    uint32_t d = (uint32_t)(b >> 5);
+    const uint32_t sh = (uint32_t)(b & 31);
+    auto dw = [&](uint32_t k) -> uint32_t { return k < ndw ? __builtin_bswap32(p32[k]) : 0u; };
+    const uint64_t w0 = (((uint64_t)dw(d) << 32) | dw(d + 1)) << sh;
+    uint32_t hi = (uint32_t)(w0 >> 32), lo = (uint32_t)w0, have = 64 - sh, total = 0;
+    d += 2;
+    const uint32_t ksh = 32 - T.K;
+    for (uint32_t j = 0; j < L; ++j) {
+        uint32_t len = T.len[((j + 1) << T.K) + (hi >> ksh)];
+        if (!len) {   // a code longer than K bits (or a one-symbol tree, whose codes have no bits): walk the tree
+            uint64_t w = ((uint64_t)hi << 32) | lo;
+            uint32_t hv = have, dd = d;
+            if (T.lc) {
+                const uint32_t nq = T.nq, rowo = (j + 1) * nq;
+                uint32_t node = T.root[j + 1];
+                while (node >= nq) {
+                    if (len >= 32 || hv == 0) return ~0u;
+                    node = (w >> 63) ? T.rc[rowo + node - nq] : T.lc[rowo + node - nq];
+                    w <<= 1; --hv; ++len;
+                    if (hv < 32) { w |= (uint64_t)dw(dd) << (32 - hv); hv += 32; ++dd; }
+                }
+            } else {
+                const DTree &Q = qt[j + 1];
+                uint32_t node = Q.root;
+                while (node >= Q.n) {
+                    if (len >= 32 || hv == 0) return ~0u;
+                    node = (w >> 63) ? Q.rc[node - Q.n] : Q.lc[node - Q.n];
+                    w <<= 1; --hv; ++len;
+                    if (hv < 32) { w |= (uint64_t)dw(dd) << (32 - hv); hv += 32; ++dd; }
+                }
+            }
+        }
+        if (len) {
+            hi = len < 32 ? __builtin_amdgcn_alignbit(hi, lo, 32 - len) : lo;
+            lo = len < 32 ? lo << len : 0u;
+        }
+        have -= len;
+        total += len;
+        while (have <= 32) {
+            const uint32_t x = dw(d++);
+            hi |= have < 32 ? x >> have : 0u;
+            lo = have ? x << (32 - have) : 0u;
+            have += 32;
+        }
+    }
+    return total;
+}
+
 // A: hop[b - q0] for the bit offsets q0 + [cov_lo, cov_hi) of a sub-block.  The stream's end is not known before it is
 // decoded; with two-bit bases it is at least (sub-block end - what the bases can take at most), which is what the first
 // phase covers; the chain kernel asks for more (records with transferred bases make the quality stream longer and the
 // base stream shorter) and later phases deliver it.
 __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, const DecCtl *ctl,
-                                                            uint16_t *hop, const uint64_t *hop_off, uint32_t lds_entries)
+                                                            uint16_t *hop, const uint64_t *hop_off, uint32_t lds_entries, uint32_t with_trees)
 {
     const uint32_t s = blockIdx.y;
     const DecCtl &C = ctl[s];
@@ -991,10 +1061,34 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, 
     const uint64_t nbits = (uint64_t)sb_len[s] * 8, q0 = C.pos;
     const uint64_t first = C.cov_lo + (uint64_t)blockIdx.x * QS_TILE;   // (relative to q0)
     if (first >= C.cov_hi) return;
-    extern __shared__ __align__(16) uint16_t s_qtab[];
-    const uint32_t L = C.max_q;
-    const uint32_t Kl = dec_fill_lds_table(s_qtab, lds_entries, C.qtab, C.Kq, L + 1);
-    if (!Kl) return;   // (the chain kernel finds the hops missing: hop[] is cleared to "invalid" beforehand)
+    extern __shared__ __align__(16) uint8_t s_len[];   // [rows << Kl] code lengths, then (alphabets of up to 128 symbols) the trees
+    const uint32_t L = C.max_q, rows = L + 1, Kq = C.Kq, nq = C.nqual;
+    uint32_t Kl = Kq;
+    while (Kl > 5 && ((uint64_t)rows << Kl) > lds_entries) --Kl;
+    if (((uint64_t)rows << Kl) > lds_entries) return;   // (the chain kernel finds the hops missing: hop[] is cleared to "invalid" beforehand)
+    {
+        const uint32_t total = rows << Kl, shq = Kq - Kl;
+        const uint16_t *qtab = C.qtab;
+        for (uint32_t k = threadIdx.x; k < total; k += QS_THREADS) {
+            const uint32_t row = k >> Kl, x = k & ((1u << Kl) - 1u);
+            const uint32_t ln = qtab[((size_t)row << Kq) + (x << shq)] >> 12;
+            s_len[k] = ln <= Kl ? (uint8_t)ln : (uint8_t)0;
+        }
+    }
+    QsLenTabs T = {s_len, nullptr, nullptr, nullptr, Kl, nq};
+    if (with_trees && nq >= 2 && nq <= 128) {
+        uint8_t *lc = s_len + (((size_t)rows << Kl) + 15 & ~(size_t)15), *rc = lc + (size_t)rows * nq, *root = rc + (size_t)rows * nq;
+        for (uint32_t k = threadIdx.x; k < rows * nq; k += QS_THREADS) {
+            const uint32_t row = k / nq, i = k % nq;
+            const DTree &Q = C.qt[row];
+            const bool in = Q.n == nq && i + 1 < nq;   // internal nodes nq .. 2 nq - 2
+            lc[k] = in ? (uint8_t)Q.lc[i] : (uint8_t)0;
+            rc[k] = in ? (uint8_t)Q.rc[i] : (uint8_t)0;
+        }
+        for (uint32_t k = threadIdx.x; k < rows; k += QS_THREADS) root[k] = (uint8_t)C.qt[k].root;
+        T.lc = lc; T.rc = rc; T.root = root;
+    }
+    __syncthreads();
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(sub + sb_off[s]);
     const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
     uint16_t *h = hop + hop_off[s];
@@ -1004,7 +1098,7 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, 
         const uint64_t rel = first + threadIdx.x + (uint64_t)o * QS_THREADS;
         if (rel >= cov_hi) break;
         const uint64_t b = q0 + rel;
-        const uint32_t t = qs_record<false>(p32, ndw, b, L, s_qtab, Kl, C.qt, C.qsym, nullptr, nullptr);
+        const uint32_t t = qs_record_len(p32, ndw, b, L, T, C.qt);
         h[rel] = (t == ~0u || t >= QS_INVALID || b + t > nbits) ? (uint16_t)QS_INVALID : (uint16_t)t;
     }
 }
@@ -1085,9 +1179,12 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_c(const uint8_t *sub, 
 
 // One wave per sub-block, behind the head kernel (and the speculative quality kernels): the quality stream if it is still
 // to be decoded, then the bases.
+// mode 0: everything.  mode 1 (the parallel base decoder is available): everything but the code stream of a Huffman-coded base
+// alphabet whose codes all fit the table - the kernels k_dec_dna_a/b/c take that; mode 2: behind them - the sub-blocks they
+// decoded are closed, those they gave up on are decoded here after all.
 __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb,
                                                  uint8_t *scratch, uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap,
-                                                 DecSub *out, DecCtl *ctl, uint32_t lds_entries)
+                                                 DecSub *out, DecCtl *ctl, uint32_t lds_entries, uint32_t mode)
 {
     const uint32_t s = blockIdx.x;
     if (s >= n_sb) return;
@@ -1112,6 +1209,29 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
     const uint32_t n = C.n;
     const uint64_t t1 = wall_clock64();
     uint8_t *d_qual = D.titles + D.lay[0], *d_seq = D.titles + D.lay[1];
+    __shared__ DTree s_dt;
+    if (mode == 2) {
+        if (C.dna_spec == 0) return;   // (closed by the first call)
+        const bool good = C.dna_spec == 2 && !C.dna_bad;
+        if (!good) {   // the code stream serially, from what the first call left
+            for (uint32_t k = lane; k < (1u << DEC_K); k += 64) s_dtab[k] = C.dna_tab[k];
+            if (lane == 0) {
+                s_dt.n = C.dna_n; s_dt.root = C.dna_root; s_dt.lc = C.dna_lc; s_dt.rc = C.dna_rc; s_dt.tab = s_dtab;
+                C.pos = C.dna_p0;
+            }
+            for (uint32_t k = lane; k < 256; k += 64) s_map[k] = k < O.nsym ? O.dsym[k] : (uint8_t)0;
+            __syncthreads();
+            dec_symbols_wave<false>(r.p, r.nbits, C, s_dtab, DEC_K, &s_dt, D.slen, n, d_seq, nullptr, s_map, s_in, s_out, 1);
+            __syncthreads();
+            if (C.err) { if (lane == 0) O.err = C.err; return; }
+        }
+        if (lane == 0) {
+            O.dna_bitpos = C.pos;
+            O.t_head = C.t_head; O.t_qual = C.t_qual; O.t_dna = wall_clock64() - t1;
+            O.spec = (C.spec == 2 && !C.spec_bad) ? 1u : 0u;
+        }
+        return;
+    }
     if (!(C.spec == 2 && !C.spec_bad)) {   // the quality stream, serially
         s_map[lane] = C.qsym[lane]; s_map[lane + 64] = C.qsym[lane + 64]; s_map[lane + 128] = C.qsym[lane + 128]; s_map[lane + 192] = C.qsym[lane + 192];
         if (C.spec == 2 && lane == 0) C.pos -= D.rs[n];   // (the chain had moved it to the stream's end)
@@ -1125,7 +1245,6 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
 
     // ---- DNA (cf. FetchDNA tasks.cpp:957-1033): alphabet; a Huffman-coded alphabet is decoded here, two-bit codes by the assembly kernel ----
     const uint64_t t2 = wall_clock64();
-    __shared__ DTree s_dt;
     {   // bases kept per record -> their total (every lane its share)
         uint64_t bases = 0;
         for (uint32_t i = lane; i < n; i += 64) bases += D.slen[i];
@@ -1152,6 +1271,34 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
     }
     __syncthreads();
     if (C.err) return;
+    if (!O.plain && mode == 1) {
+        // hand the code stream to the parallel kernels when every code fits the table (a zero entry is a longer code)
+        __shared__ uint32_t s_ml;
+        if (lane == 0) s_ml = 0;
+        __syncthreads();
+        uint32_t ml = 0, hole = 0;
+        for (uint32_t k = lane; k < (1u << DEC_K); k += 64) { const uint32_t e = s_dtab[k]; hole |= e == 0; ml = (e >> 12) > ml ? (e >> 12) : ml; }
+        if (hole) ml = 0xffu;
+        atomicMax(&s_ml, ml);
+        __syncthreads();
+        const uint32_t maxlen = s_ml;
+        uint16_t *gtab = nullptr;
+        if (lane == 0 && maxlen >= 1 && maxlen <= DEC_K && C.qual_total_bases) gtab = (uint16_t *)pool.take(2u << DEC_K);
+        gtab = (uint16_t *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)gtab >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)gtab));
+        if (gtab) {
+            for (uint32_t k = lane; k < (1u << DEC_K); k += 64) gtab[k] = s_dtab[k];
+            if (lane == 0) {
+                DecCtl &G = ctl[s];
+                G.dna_spec = 1; G.dna_maxlen = maxlen; G.dna_nseg = 0; G.dna_bad = 0;
+                G.dna_p0 = C.pos; G.dna_total = C.qual_total_bases; G.dna_tab = gtab;
+                G.dna_n = s_dt.n; G.dna_root = s_dt.root; G.dna_lc = s_dt.lc; G.dna_rc = s_dt.rc;
+                G.t_qual = t2 - t1;
+                G.pos = C.pos; G.err = C.err; G.qual_total_bases = C.qual_total_bases; G.spec = C.spec; G.spec_bad = C.spec_bad;
+            }
+            return;
+        }
+    }
     if (!O.plain) {
         dec_symbols_wave<false>(r.p, r.nbits, C, s_dtab, DEC_K, &s_dt, D.slen, n, d_seq, nullptr, s_map, s_in, s_out, 1);
         __syncthreads();
@@ -1161,8 +1308,149 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
         O.dna_bitpos = C.pos;
         O.t_head = C.t_head; O.t_qual = t2 - t1; O.t_dna = wall_clock64() - t2;
         O.spec = (C.spec == 2 && !C.spec_bad) ? 1u : 0u;
+        if (mode == 1) ctl[s].dna_spec = 0;
     }
 }
+
+// ---- Huffman-coded bases in parallel -------------------------------------------------------------------------------------------
+// The base stream of a sub-block with more than four symbols (an N that keeps its quality is enough) is ONE Huffman-coded bit
+// string (tasks.cpp:544-557): 3.6 million codes per 8 MiB window of 150-base reads, which one wave decoded in 0.39 s - two
+// thirds of the decoder's time on such files.  Unlike the qualities it has one tree for all positions, so where a code starts
+// is the only state, and a stretch of the stream can be entered in at most `maxlen` ways (the code in front of it began less
+// than a code length before its first bit):
+//   A  a lane per (segment of DS_SEG bits, entry offset e < maxlen) walks the segment from e: where the walk leaves it (exit
+//      offset into the next segment) and how many codes it met.  ~maxlen times the stream's codes in lookups, all independent;
+//   B  one wave per sub-block follows the true chain - segment g is entered where segment g - 1 was left - and writes down each
+//      segment's entry offset and the number of bases in front of it;
+//   C  a lane per segment decodes its codes to their place in the output.
+// A code longer than the table's DEC_K bits never gets here (k_dec_tail hands over only complete tables); a chain that does
+// not add up (a damaged stream) marks the sub-block and the serial decoder of k_dec_tail reports what is wrong with it.
+constexpr uint32_t DS_SEG = 1024;     // bits per segment
+constexpr uint32_t DS_EP = 16;        // entry slots per segment (maxlen <= DEC_K = 9 of them used)
+constexpr uint32_t DS_A_SEGS = 256 / DS_EP;   // segments per workgroup of kernel A
+constexpr uint16_t DS_INVALID = 0xFFFFu;
+
+// the 32 stream bits starting at bit `a` of a staged stretch (dwords of 32 stream bits each, MSB first)
+__device__ __forceinline__ uint32_t ds_peek32(const uint32_t *s_in, uint32_t a)
+{
+    const uint32_t d = a >> 5, sh = a & 31;
+    return sh ? __builtin_amdgcn_alignbit(s_in[d], s_in[d + 1], 32 - sh) : s_in[d];
+}
+
+__global__ __launch_bounds__(256) void k_dec_dna_a(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, const DecCtl *ctl,
+                                                   uint16_t *hop, const uint64_t *hop_off)
+{
+    const uint32_t s = blockIdx.y;
+    const DecCtl &C = ctl[s];
+    if (C.err || C.dna_spec != 1) return;
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8, p0 = C.dna_p0;
+    const uint64_t nseg = (nbits - p0 + DS_SEG - 1) / DS_SEG;
+    const uint64_t g0 = (uint64_t)blockIdx.x * DS_A_SEGS;
+    if (g0 >= nseg) return;
+    __shared__ uint32_t s_in[DS_A_SEGS * (DS_SEG / 32) + 4];
+    __shared__ uint16_t s_tab[1u << DEC_K];
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(sub + sb_off[s]);
+    const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
+    const uint64_t bit0 = p0 + g0 * DS_SEG;
+    const uint32_t d0 = (uint32_t)(bit0 >> 5);
+    for (uint32_t k = threadIdx.x; k < DS_A_SEGS * (DS_SEG / 32) + 4; k += 256) s_in[k] = d0 + k < ndw ? __builtin_bswap32(p32[d0 + k]) : 0u;
+    for (uint32_t k = threadIdx.x; k < (1u << DEC_K); k += 256) s_tab[k] = C.dna_tab[k];
+    __syncthreads();
+    const uint32_t seg = threadIdx.x / DS_EP, e = threadIdx.x % DS_EP;
+    if (g0 + seg >= nseg || e >= C.dna_maxlen) return;
+    const uint32_t rel0 = (uint32_t)(bit0 & 31) + seg * DS_SEG;   // the segment's first bit inside the staged stretch
+    uint32_t pos = e, cnt = 0;
+    bool bad = false;
+    while (pos < DS_SEG) {
+        const uint32_t ent = s_tab[ds_peek32(s_in, rel0 + pos) >> (32 - DEC_K)];
+        if (!ent) { bad = true; break; }
+        pos += ent >> 12;
+        ++cnt;
+    }
+    hop[hop_off[s] + (g0 + seg) * DS_EP + e] = bad ? DS_INVALID : (uint16_t)(((pos - DS_SEG) << 12) | cnt);
+}
+
+// B: per segment, (bases in front of it) << 4 | entry offset, written behind the table of A (u32 entries)
+__global__ __launch_bounds__(64) void k_dec_dna_b(const uint32_t *sb_len, DecCtl *ctl, uint16_t *hop, const uint64_t *hop_off)
+{
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    DecCtl &C = ctl[s];
+    if (C.err || C.dna_spec != 1) return;
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8, p0 = C.dna_p0;
+    const uint32_t nseg = (uint32_t)((nbits - p0 + DS_SEG - 1) / DS_SEG);
+    const uint16_t *T = hop + hop_off[s];
+    uint32_t *E = reinterpret_cast<uint32_t *>(hop + hop_off[s] + (((uint64_t)nseg * DS_EP + 7) & ~7ull));
+    constexpr uint32_t CH = 256;   // segments staged at a time
+    __shared__ __align__(16) uint16_t s_t[CH * DS_EP];
+    __shared__ uint32_t s_e[CH];
+    auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    const uint64_t total = ((uint64_t)U((uint32_t)(C.dna_total >> 32)) << 32) | U((uint32_t)C.dna_total);
+    uint64_t out = 0;
+    uint32_t e = 0, g = 0, bad = 0;
+    for (uint32_t base = 0; base < nseg && out < total && !bad; base += CH) {
+        const uint32_t cnt = nseg - base < CH ? nseg - base : CH;
+        __syncthreads();
+        for (uint32_t t = lane; t < cnt * DS_EP / 8; t += 64) reinterpret_cast<uint4 *>(s_t)[t] = reinterpret_cast<const uint4 *>(T + (uint64_t)base * DS_EP)[t];
+        __syncthreads();
+        uint32_t k = 0;
+        for (; k < cnt && out < total; ++k) {
+            const uint32_t t = U((uint32_t)s_t[k * DS_EP + e]);
+            if (t == DS_INVALID || out >= (1ull << 28)) { bad = 1; break; }
+            s_e[k] = ((uint32_t)out << 4) | e;
+            out += t & 0xfffu;
+            e = t >> 12;
+        }
+        __syncthreads();
+        for (uint32_t t = lane; t < k; t += 64) E[base + t] = s_e[t];
+        g = base + k;
+    }
+    if (lane == 0) {
+        if (bad || out < total) { C.dna_spec = 3; }
+        else { C.dna_nseg = g; C.dna_spec = 2; }
+    }
+}
+
+// C: a lane per segment; a workgroup's 64 segments staged in LDS
+constexpr uint32_t DS_C_SEGS = 64;
+__global__ __launch_bounds__(64) void k_dec_dna_c(const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, DecCtl *ctl, uint8_t *scratch,
+                                                  uint64_t stride, uint32_t rec_cap, uint64_t tcap, const uint16_t *hop, const uint64_t *hop_off)
+{
+    const uint32_t s = blockIdx.y;
+    DecCtl &C = ctl[s];
+    if (C.err || C.dna_spec != 2) return;
+    const uint32_t g0 = blockIdx.x * DS_C_SEGS;
+    if (g0 >= C.dna_nseg) return;
+    const uint64_t nbits = (uint64_t)sb_len[s] * 8, p0 = C.dna_p0, total = C.dna_total;
+    const uint32_t nseg_all = (uint32_t)((nbits - p0 + DS_SEG - 1) / DS_SEG);
+    const uint32_t *E = reinterpret_cast<const uint32_t *>(hop + hop_off[s] + (((uint64_t)nseg_all * DS_EP + 7) & ~7ull));
+    __shared__ uint32_t s_in[DS_C_SEGS * (DS_SEG / 32) + 4];
+    __shared__ uint16_t s_tab[1u << DEC_K];
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(sub + sb_off[s]);
+    const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
+    const uint64_t bit0 = p0 + (uint64_t)g0 * DS_SEG;
+    const uint32_t d0 = (uint32_t)(bit0 >> 5);
+    for (uint32_t k = threadIdx.x; k < DS_C_SEGS * (DS_SEG / 32) + 4; k += 64) s_in[k] = d0 + k < ndw ? __builtin_bswap32(p32[d0 + k]) : 0u;
+    for (uint32_t k = threadIdx.x; k < (1u << DEC_K); k += 64) s_tab[k] = C.dna_tab[k];
+    __syncthreads();
+    const uint32_t g = g0 + threadIdx.x;
+    if (g >= C.dna_nseg) return;
+    DecScratch D = dec_scratch(scratch, stride, s, rec_cap, tcap, 0);
+    uint8_t *dst = D.titles + D.lay[1];
+    const uint32_t ent0 = E[g];
+    uint64_t out = ent0 >> 4;
+    uint32_t pos = ent0 & 15u;
+    const uint32_t rel0 = (uint32_t)(bit0 & 31) + threadIdx.x * DS_SEG;
+    const uint64_t seg_bit0 = bit0 + (uint64_t)threadIdx.x * DS_SEG;
+    while (pos < DS_SEG && out < total) {
+        const uint32_t ent = s_tab[ds_peek32(s_in, rel0 + pos) >> (32 - DEC_K)];
+        if (!ent) { atomicOr(&C.dna_bad, 1u); return; }
+        pos += ent >> 12;
+        if (seg_bit0 + pos > nbits) { atomicOr(&C.dna_bad, 1u); return; }   // a code that runs past the sub-block's end
+        dst[out++] = (uint8_t)ent;
+    }
+    if (out >= total && (pos < DS_SEG || g + 1 == C.dna_nseg)) ctl[s].pos = seg_bit0 + pos;   // (the lane that decodes the last code: where the stream ends)
+}
+
 
 // One workgroup per sub-block: the four lines of every record, records dealt to the threads.
 __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch,
@@ -1289,7 +1577,7 @@ void launch_dec_head(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off,
 
 void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, const uint32_t *sb_len, uint32_t n_sb, uint8_t *scratch,
                         uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, uint16_t *hop, const uint64_t *hop_off,
-                        uint32_t max_tiles, uint32_t spec_max_q)
+                        uint32_t max_tiles, uint32_t spec_max_q, uint32_t spec_max_nq)
 {
     const uint32_t lds_entries = 30u << 10;   // 60 KB of 16-bit table entries: the per-position tables of reads up to 59 bases
     double t0 = 0;
@@ -1305,10 +1593,19 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_qspec_c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_cap));
         // phases: what the first one leaves uncovered is small when few bases were transferred to the quality stream (each
         // moves the stream's end by a few bits), so the next ones are small; the last takes whatever is left
+        // kernel A: byte entries (lengths only) - as many look-ahead bits as 60 KB of them allow - and the trees (up to 128
+        // symbols: rows x 128 x 2 + rows bytes at most; NGSC_DEC_LDS_TREES=0: long codes walk the trees in global memory)
+        uint32_t Ka = DEC_K;
+        while (Ka > 5 && ((uint64_t)rows << Ka) > lds_cap) --Ka;
+        const uint32_t lds_a_entries = (uint32_t)std::min<uint64_t>(lds_cap, (uint64_t)rows << Ka);
+        static const bool lds_trees = !(getenv("NGSC_DEC_LDS_TREES") && !strcmp(getenv("NGSC_DEC_LDS_TREES"), "0"));
+        const uint32_t nq_cap = spec_max_nq < 2 ? 2u : (spec_max_nq > 128 ? 128u : spec_max_nq);
+        const size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
+        const size_t lds_a = ((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes;
         const uint32_t phase_tiles[4] = {max_tiles, 16, 256, max_tiles};
         for (int ph = 0; ph < 4; ++ph) {
-            hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), 2 * lds_spec, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
-                               hop, hop_off, lds_spec);
+            hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), lds_a, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
+                               hop, hop_off, lds_a_entries, lds_trees && lds_a <= (120u << 10) ? 1u : 0u);
             if (ph == 0) dec_lap(st, t0, "k_dec_qspec_a");
             hipLaunchKernelGGL(k_dec_qspec_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off, scratch, stride, rec_cap, tcap,
                                ph < 3 ? phase_tiles[ph + 1] : 0u);
@@ -1320,9 +1617,23 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         dec_lap(st, t0, "k_dec_qspec_c");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_entries));
+    static const bool dna_par = !(getenv("NGSC_DEC_DNA_PAR") && !strcmp(getenv("NGSC_DEC_DNA_PAR"), "0"));
+    const uint32_t mode = hop && dna_par ? 1u : 0u;   // (the parallel base decoder keeps its tables in the hop area)
     hipLaunchKernelGGL(k_dec_tail, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
-                       (DecSub *)out, (DecCtl *)ctl, lds_entries);
+                       (DecSub *)out, (DecCtl *)ctl, lds_entries, mode);
     dec_lap(st, t0, "k_dec_tail");
+    if (mode) {
+        // segments of the longest sub-block of the batch: max_tiles counts QS_TILE bit offsets of a whole sub-block
+        const uint32_t max_seg = (uint32_t)(((uint64_t)max_tiles * QS_TILE + DS_SEG - 1) / DS_SEG) + 1;
+        hipLaunchKernelGGL(k_dec_dna_a, dim3((max_seg + DS_A_SEGS - 1) / DS_A_SEGS, n_sb), dim3(256), 0, st, sub, sb_off, sb_len, (const DecCtl *)ctl, hop, hop_off);
+        hipLaunchKernelGGL(k_dec_dna_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off);
+        hipLaunchKernelGGL(k_dec_dna_c, dim3((max_seg + DS_C_SEGS - 1) / DS_C_SEGS, n_sb), dim3(64), 0, st, sub, sb_off, sb_len, (DecCtl *)ctl, scratch, stride,
+                           rec_cap, tcap, hop, hop_off);
+        dec_lap(st, t0, "k_dec_dna a+b+c");
+        hipLaunchKernelGGL(k_dec_tail, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
+                           (DecSub *)out, (DecCtl *)ctl, lds_entries, 2u);
+        dec_lap(st, t0, "k_dec_tail (close)");
+    }
 }
 
 void launch_dec_assemble(hipStream_t st, const uint8_t *sub, const uint64_t *sb_off, uint32_t n_sb, uint8_t *scratch, uint64_t stride,
