@@ -555,7 +555,16 @@ __device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qs
     if (!qt) return ERR_NOMEM;
     // the per-position tables, DEC_K bits wide, in the pool: the kernels that decode the symbols copy what fits into LDS
     // (narrower if need be: dec_fill_lds_table)
-    const uint32_t Kq = DEC_K;
+    // (as wide as the pool allows next to the trees themselves - two child tables of nqual + 1 entries each - and what the base
+    // stream needs later: reads of 3 000 bases and more have 3 001 trees, whose 9-bit tables alone are 3.4 MB of the 4 MB pool;
+    // found by the round-3 fuzz run, seeds 400796 / 400922: NGSC_ERR_NOMEM for such files)
+    uint32_t Kq = DEC_K;
+    {
+        const uint64_t rows = (uint64_t)max_q + 1;
+        const uint64_t trees = rows * (4ull * (nqual + 2) + 16) + (96u << 10);
+        const uint64_t room = pool.cap > pool.off + trees ? pool.cap - pool.off - trees : 0;
+        while (Kq > 5 && ((rows << Kq) * 2) > room) --Kq;
+    }
     (void)s_qtab; (void)lds_entries;
     uint16_t *qtab = (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
     if (!qtab) return ERR_NOMEM;
@@ -1600,12 +1609,13 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         const uint32_t lds_a_entries = (uint32_t)std::min<uint64_t>(lds_cap, (uint64_t)rows << Ka);
         static const bool lds_trees = !(getenv("NGSC_DEC_LDS_TREES") && !strcmp(getenv("NGSC_DEC_LDS_TREES"), "0"));
         const uint32_t nq_cap = spec_max_nq < 2 ? 2u : (spec_max_nq > 128 ? 128u : spec_max_nq);
-        const size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
+        size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
+        if (((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes > (120u << 10)) tree_bytes = 0;   // (long reads: no room for the trees)
         const size_t lds_a = ((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes;
         const uint32_t phase_tiles[4] = {max_tiles, 16, 256, max_tiles};
         for (int ph = 0; ph < 4; ++ph) {
             hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), lds_a, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
-                               hop, hop_off, lds_a_entries, lds_trees && lds_a <= (120u << 10) ? 1u : 0u);
+                               hop, hop_off, lds_a_entries, tree_bytes ? 1u : 0u);
             if (ph == 0) dec_lap(st, t0, "k_dec_qspec_a");
             hipLaunchKernelGGL(k_dec_qspec_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off, scratch, stride, rec_cap, tcap,
                                ph < 3 ? phase_tiles[ph + 1] : 0u);

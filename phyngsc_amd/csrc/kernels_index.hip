@@ -500,6 +500,18 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
     validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err, (flags & 1u) != 0);
 }
 
+// The validation pass alone (round 3): without the planner's 24 KB of LDS in every workgroup, on a stream of its own beside the
+// planner's chain.
+__global__ __launch_bounds__(256) void k_validate_records(const uint32_t *te, const uint32_t *se, const uint32_t *ls, const uint32_t *total_lines,
+                                                          uint32_t *max_q, uint32_t *max_rec, uint32_t *max_title, int32_t *err,
+                                                          const uint8_t *tail_buf, uint32_t flags)
+{
+    const uint32_t n_rec_total = *total_lines / 4;
+    if (tail_buf && blockIdx.x == 0 && threadIdx.x == 0 && (*total_lines & 3u) == 3u && tail_buf[ls[n_rec_total]] != '\n')
+        atomicMin(err, (int32_t)ERR_FORMAT);   // (see k_cuts_validate)
+    validate_records(te, se, ls, n_rec_total, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, max_q, max_rec, max_title, err, (flags & 1u) != 0);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------
 uint32_t index_num_tiles(uint32_t len) { return len / TILE_BYTES + 1; }   // covers position len itself (assumed final newline)
 
@@ -535,7 +547,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
                           uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
-                          uint64_t buf_end_abs)
+                          uint64_t buf_end_abs, hipStream_t validate_stream)
 {
     // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
     // wave per 64 records
@@ -545,6 +557,13 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
     // (experiments: NGSC_CV_VEC=1 four records per thread with 16-byte loads - measured SLOWER, see DESIGN.md;
     // NGSC_CV_NOCACHE=1 the planner without its LDS cache of looked-ahead windows)
     const uint32_t flags = (getenv("NGSC_CV_VEC") ? 1u : 0u) | (getenv("NGSC_CV_NOCACHE") ? 2u : 0u);
+    if (validate_stream) {   // the planner's chain here, the validation pass on its own stream (the caller joins it)
+        hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
+                           ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs, flags);
+        hipLaunchKernelGGL(k_validate_records, dim3(vblocks), dim3(256), 0, validate_stream, te, se, ls, total_lines, max_q, max_rec, max_title, err,
+                           tail_buf, flags);
+        return;
+    }
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
                        ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs, flags);
 }
