@@ -55,6 +55,7 @@ struct ngsc_ctx {
     bool cs_retry = false;        // the job is run again on a copy in which colour-space reads are decoded
     uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
+    bool big_alphabets = false;   // the last call met a quality / base alphabet of more than 64 symbols (grid of the 512-symbol Huffman instance)
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
 
@@ -699,9 +700,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
         }
         { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
-        { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A); }
+        { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
         { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
-        if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec); }
+        if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
         else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
         { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
         { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
@@ -712,7 +713,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     } else {
     if ((rc = fork())) return rc;
     { KScope k(c, st2, "k_rec0_fields"); launch_rec0_fields(st2, A); }
-    if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec); }
+    if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec, max_title); }
     else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
     { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
     { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec, t_swar); }
@@ -809,8 +810,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (*(int32_t *)hfin) return *(int32_t *)hfin;
     c->res_sb.resize(S);
     c->qbits_x16 = c->dbits_x16 = 0;
+    c->big_alphabets = false;
     for (uint32_t s = 0; s < S; ++s) {
         const SbState &x = h_sb[s];
+        if (x.nqual > 64 || x.nsym > 64) c->big_alphabets = true;
         if (x.n_bases) {
             c->qbits_x16 = std::max<uint32_t>(c->qbits_x16, (uint32_t)(((uint64_t)x.qbits * 16 + x.n_bases - 1) / x.n_bases));
             c->dbits_x16 = std::max<uint32_t>(c->dbits_x16, (uint32_t)(((uint64_t)x.dbits * 16 + x.n_bases - 1) / x.n_bases));

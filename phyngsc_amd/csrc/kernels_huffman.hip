@@ -174,12 +174,13 @@ void launch_huffman_sb(hipStream_t st, const Arena &A)
 
 // The same trees in two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
 // sequence/quality statistics only, the numeric title field trees the title statistics only.
-void launch_huffman_sq(hipStream_t st, const Arena &A)
+void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected)
 {
     launch_huffman_range(st, A, true, 0, A.qrows + 1);
     // (quality alphabets of more than 64 symbols are rare: a workgroup per CU - each needs 26 KB of LDS that the title statistics
-    // kernel beside it is holding, and a thousand of them took 166 us to find out that they had nothing to do)
-    launch_huffman_range(st, A, false, 0, A.qrows + 1, 256);
+    // kernel beside it is holding, and a thousand of them took 166 us to find out that they had nothing to do.  A context whose
+    // last call met such an alphabet launches six per CU: the trees are real work then)
+    launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256);
 }
 void launch_huffman_fields(hipStream_t st, const Arena &A)
 {

@@ -16,6 +16,7 @@
 // Everything else (read tails, ambiguity codes, odd quality bytes, rows past the LDS histogram) takes a
 // masked general path chosen per 16-byte chunk with a wave-uniform branch.
 #include "ngsc_kernels.h"
+#include <cstring>
 #include "ngsc_swar.h"
 #include "ngsc_sq.h"
 
@@ -71,8 +72,9 @@ __device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32
 // the aligned ones and keep the kernel off the HBM roofline) - parks it in LDS, and every lane reads its own record's chunks
 // back with unaligned 16-byte LDS reads.  Same bytes, same logic behind the loads.  span_cap: bytes of LDS per wave,
 // >= 64 x the job's longest record + 48.
-template <bool BURST, bool STAGED>
-__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
+// (THREADS: 256; 512 for the staged form - eight spans beside one histogram, see launch_sq_stats_reg)
+template <bool BURST, bool STAGED, uint32_t THREADS = SR_THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_stats_reg(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
 {
     static_assert(!(BURST && STAGED), "the staged form is for short records");
     if (*A.err) return;
@@ -91,9 +93,8 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     uint8_t *const span = reinterpret_cast<uint8_t *>(s_hist + ((hwords + 64 + 3) & ~3u)) + (size_t)(tid >> 6) * span_cap;
     uint32_t span_lo = 0;   // file offset of span[0] (wave-uniform)
 
-    for (uint32_t k = tid; k < hwords; k += SR_THREADS) s_hist[k] = 0;
-    s_occ[tid] = 0;
-    s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
+    for (uint32_t k = tid; k < hwords; k += THREADS) s_hist[k] = 0;
+    if (tid < 256) { s_occ[tid] = 0; s_amb[tid] = (uint8_t)amb_code((uint8_t)tid); }
     if (tid < 3) s_red[tid] = 0;
     __syncthreads();
 
@@ -112,12 +113,12 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 
     uint32_t te_n = 0, se_n = 0;   // the next batch's record table entries are fetched one batch ahead
     if (first + tid < last) { te_n = A.te[rec_lo + first + tid]; se_n = A.se[rec_lo + first + tid]; }
-    for (uint32_t base = first; base < last; base += SR_THREADS) {
+    for (uint32_t base = first; base < last; base += THREADS) {
         const uint32_t i = base + tid;
         const bool valid = i < last;
         const uint32_t g = rec_lo + (valid ? i : first);
         const uint32_t te = te_n, se = se_n;
-        if (i + SR_THREADS < last) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; }
+        if (i + THREADS < last) { te_n = A.te[g + THREADS]; se_n = A.se[g + THREADS]; }
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
         if (valid) {
@@ -417,12 +418,12 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     __syncthreads();
-    for (uint32_t k = tid; k < lds_rows * SR_HCOLS; k += SR_THREADS) {
+    for (uint32_t k = tid; k < lds_rows * SR_HCOLS; k += THREADS) {
         const uint32_t row = k / SR_HCOLS, col = k % SR_HCOLS;
         const uint32_t x = s_hist[row * SR_HSTRIDE + col];
         if (x) atomicAdd(&qh[(size_t)row * 256 + 33 + col], x);
     }
-    if (s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
+    if (tid < 256 && s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
     if (tid == 0) {
         atomicMax(&A.sb[s].max_q, s_red[0]);
         atomicMax(&A.sb[s].max_s, s_red[1]);
@@ -1489,6 +1490,17 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
             hipLaunchKernelGGL(mk, mgrid, dim3(SR_THREADS), mlds, st, A, A.qrows, mrpw, mcap);
             return;
         }
+    }
+    // 512 threads per workgroup for the staged form: eight spans beside one histogram, 80 KB, two workgroups = four waves per SIMD
+    // instead of three (44 KB x 3): +1 % on the step (496-500 against 482-492 GB/s).  NGSC_SQ_STATS_512=0: 256 threads
+    if (staged && !(getenv("NGSC_SQ_STATS_512") && !strcmp(getenv("NGSC_SQ_STATS_512"), "0"))) {
+        const size_t lds5 = ((((size_t)rows * SR_HSTRIDE + 64) * 4 + 15) & ~(size_t)15) + (size_t)8 * span_cap;
+        const uint32_t rpw5 = rpw < 512 ? 512 : rpw / 512 * 512;
+        dim3 grid5((max_rec + rpw5 - 1) / rpw5, A.n_sb);
+        auto k5 = k_sq_stats_reg<false, true, 512>;
+        if (lds5 > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k5), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+        hipLaunchKernelGGL(k5, grid5, dim3(512), lds5, st, A, rows, rpw5, span_cap);
+        return;
     }
     auto kern = staged ? k_sq_stats_reg<false, true> : (sr_burst(A) ? k_sq_stats_reg<true, false> : k_sq_stats_reg<false, false>);
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);

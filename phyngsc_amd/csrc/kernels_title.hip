@@ -11,6 +11,8 @@
 //                        area, one coalesced copy-out per 256 records            (tasks.cpp:427-507)
 // Algorithmic traffic: the title bytes once per kernel (stats, measure) + 4 B per cached field and record.
 #include "ngsc_kernels.h"
+#include <cstring>
+#include <cstdlib>
 #include "ngsc_swar.h"
 
 namespace ngsc {
@@ -693,16 +695,51 @@ typedef const __attribute__((address_space(4))) Rec0Tab *crec0p;
 template <uint32_t W>
 __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32_t tlen, uint32_t (*s_w)[TT_THREADS], int tid,
                                              uint64_t (&sepmask)[W], uint64_t (&digmask)[W], cu32p r0w, uint64_t (&diffmask)[W],
-                                             cu32p sep0, cu32p dig0)
+                                             cu32p sep0, cu32p dig0, uint32_t z, bool t_quad)   // z: rows of s_w that hold title dwords; row z is the zero row
 {
     uint32_t sp32[2 * W], dg32[2 * W], df32[2 * W];
 #pragma unroll
     for (uint32_t k = 0; k < 2 * W; ++k) sp32[k] = dg32[k] = df32[k] = 0;
+    // (round 3) FOUR lanes fetch a record's title, 16 bytes each of 64 consecutive ones: a load instruction of the wave then reaches
+    // for 16 stretches of 64 bytes instead of 64 stretches of 16 (a title a lane, a whole record apart) - the texture addresser, at
+    // 77 % the busiest unit of this kernel once it ran at full occupancy, prices an instruction by the cache lines it touches.  The
+    // dwords go to the record's column of s_w, where the field code below wants them anyway, and every lane reads its own title
+    // back from there (one conflict-free LDS read per dword).  NGSC_TS_QUAD=0 (t_quad false): a lane loads its own title.
+    const uint32_t lane = (uint32_t)tid & 63u, wave0 = (uint32_t)tid & ~63u;
+    if (t_quad) {
+        const uint32_t sub = lane & 3u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t rl = 16 * j + (lane >> 2);                       // the record (lane of this wave) this lane fetches for
+            const uint32_t ls_r = (uint32_t)__shfl((int)ls, (int)rl), tl_r = (uint32_t)__shfl((int)tlen, (int)rl);
+#pragma unroll
+            for (uint32_t h = 0; h < W; ++h) {
+                const uint32_t c = 4 * h + sub;                             // chunk of the title
+                if (!__any(16 * c < tl_r)) continue;
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (16 * c < tl_r) q = load16_unaligned(A.buf, ls_r + 16 * c, A.buf_len);
+                uint32_t *col = &s_w[0][wave0 + rl];
+                if (4 * c + 0 < z) col[(4 * c + 0) * TT_THREADS] = q.x;
+                if (4 * c + 1 < z) col[(4 * c + 1) * TT_THREADS] = q.y;
+                if (4 * c + 2 < z) col[(4 * c + 2) * TT_THREADS] = q.z;
+                if (4 * c + 3 < z) col[(4 * c + 3) * TT_THREADS] = q.w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (uint32_t m = 0; m < 4 * W; ++m) {
         uint4 q = make_uint4(0, 0, 0, 0);
         if (__any(16 * m < tlen)) {
-            if (16 * m < tlen) q = load16_unaligned(A.buf, ls + 16 * m, A.buf_len);
+            if (t_quad) {   // (rows behind the title of THIS lane hold zeros or what its quad did not fetch: never used beyond tlen)
+                if (16 * m < tlen) {
+                    q.x = 4 * m + 0 < z ? s_w[4 * m + 0][tid] : 0u;
+                    q.y = 4 * m + 1 < z ? s_w[4 * m + 1][tid] : 0u;
+                    q.z = 4 * m + 2 < z ? s_w[4 * m + 2][tid] : 0u;
+                    q.w = 4 * m + 3 < z ? s_w[4 * m + 3][tid] : 0u;
+                }
+            } else if (16 * m < tlen) q = load16_unaligned(A.buf, ls + 16 * m, A.buf_len);
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
@@ -722,12 +759,14 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
                 }
             }
         }
-        s_w[4 * m + 0][tid] = q.x;
-        s_w[4 * m + 1][tid] = q.y;
-        s_w[4 * m + 2][tid] = q.z;
-        s_w[4 * m + 3][tid] = q.w;
+        if (!t_quad || !(16 * m < tlen)) {   // (the quad form has the title's rows in place already; rows behind it are cleared here)
+            if (4 * m + 0 < z) s_w[4 * m + 0][tid] = q.x;
+            if (4 * m + 1 < z) s_w[4 * m + 1][tid] = q.y;
+            if (4 * m + 2 < z) s_w[4 * m + 2][tid] = q.z;
+            if (4 * m + 3 < z) s_w[4 * m + 3][tid] = q.w;
+        }
     }
-    s_w[16 * W][tid] = 0;
+    s_w[z][tid] = 0;
 #pragma unroll
     for (uint32_t k = 0; k < W; ++k) {
         const uint64_t keep = t_lowbits(tlen > 64 * k ? tlen - 64 * k : 0);
@@ -739,9 +778,9 @@ __device__ __forceinline__ void t_load_title(const Arena &A, uint32_t ls, uint32
 
 // eight bytes of the lane's title starting at byte position pos (rows past the title read the zero row)
 template <uint32_t W>
-__device__ __forceinline__ void t_field8(uint32_t (*s_w)[TT_THREADS], int tid, uint32_t pos, uint32_t &w0, uint32_t &w1)
+__device__ __forceinline__ void t_field8(uint32_t (*s_w)[TT_THREADS], int tid, uint32_t pos, uint32_t &w0, uint32_t &w1, uint32_t Z)
 {
-    constexpr uint32_t Z = 16 * W;   // the zero row
+    // Z: the zero row (behind the rows that hold title dwords)
     const uint32_t r = pos >> 2, sh = (pos & 3) * 8;
     const uint32_t x0 = s_w[r < Z ? r : Z][tid], x1 = s_w[r + 1 < Z ? r + 1 : Z][tid], x2 = s_w[r + 2 < Z ? r + 2 : Z][tid];
     w0 = __builtin_amdgcn_alignbit(x1, x0, sh);
@@ -749,9 +788,14 @@ __device__ __forceinline__ void t_field8(uint32_t (*s_w)[TT_THREADS], int tid, u
 }
 
 template <uint32_t W>
-__global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
+// (round 3) z_rows, nf_cap: the job's longest title in dwords and the most fields a title of that length can have - the title
+// rows and the field statistics live in dynamic LDS sized by them: 19.7 KB instead of 24.1 for cfg2's 50-byte titles, i.e. eight
+// workgroups per CU (the CU's wave limit) instead of six.  The hardware counters put the kernel at 60 % VALU and 48 % scalar
+// issue with LDS and scalar-load waits between them: more resident waves is what it can use.
+__global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A, uint32_t z_rows, uint32_t nf_cap_flags)
 {
     if (*A.err) return;
+    const uint32_t nf_cap = nf_cap_flags & 0xffffu;   // (bit 16: quad-cooperative title loads)
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
@@ -764,16 +808,17 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
     // field statistics in LDS: the 18 words of a FieldStat that this kernel updates (scalars 0..9, Hamming words 10..17), not
     // its 24-word global layout - with 64 fields the difference is what lets a sixth workgroup onto the CU
     constexpr uint32_t SW = 18;
-    __shared__ uint32_t s_stat[MAX_FIELDS * SW];
+    extern __shared__ __align__(16) uint32_t s_dyn[];   // [nf_cap * SW] field statistics, then [z_rows + 1][TT_THREADS] title dwords
+    uint32_t *const s_stat = s_dyn;
     // value deltas between neighbouring records (tasks.cpp:149-166): inside a wave by shuffle, across the three wave
     // boundaries of the workgroup through these (last lane's value / first lane's value, per numeric candidate)
     __shared__ uint32_t s_last[NUM_CAND_CAP][TT_THREADS / 64], s_first[NUM_CAND_CAP][TT_THREADS / 64];
     __shared__ fmask_t s_nm_last[TT_THREADS / 64], s_nm_first[TT_THREADS / 64];
-    __shared__ uint32_t s_w[TS_ROWS<W>][TT_THREADS];
+    uint32_t (*const s_w)[TT_THREADS] = reinterpret_cast<uint32_t (*)[TT_THREADS]>(s_dyn + ((nf_cap * SW + 3) & ~3u));
     // record 0's field table: scalar loads straight from global memory (written by k_rec0_fields, read-only here)
     const crec0p R0 = (crec0p)(uintptr_t)(A.rec0 + s);
     const uint32_t r0_nf0 = R0->nf0;
-    const uint32_t nf0 = r0_nf0 < MAX_FIELDS ? r0_nf0 : MAX_FIELDS;
+    const uint32_t nf0 = r0_nf0 < nf_cap ? r0_nf0 : nf_cap;   // (more separators than the record 0 table holds is an error already)
 
     for (uint32_t k = tid; k < nf0 * SW; k += TT_THREADS) s_stat[k] = 0;
     __syncthreads();
@@ -787,7 +832,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
 
     uint64_t sepmask[W], digmask[W], diffmask[W];
     t_load_title<W>(A, ls, tlen, s_w, tid, sepmask, digmask, (cu32p)(uintptr_t)(A.rec0[s].title), diffmask,
-                    (cu32p)(uintptr_t)(A.rec0[s].sepm), (cu32p)(uintptr_t)(A.rec0[s].digm));
+                    (cu32p)(uintptr_t)(A.rec0[s].sepm), (cu32p)(uintptr_t)(A.rec0[s].digm), z_rows, (nf_cap_flags >> 16) != 0);
     uint32_t nsep = 0;
 #pragma unroll
     for (uint32_t k = 0; k < W; ++k) {
@@ -848,7 +893,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
                 if (owned && (uint32_t)(hm >> 32)) t_lds_or(&s_stat[f * SW + 11], (uint32_t)(hm >> 32));
             }
             if (kk != 0xff && __any(valid && !(len == len0 && diff == 0))) {   // the value parser below wants the field's first bytes
-                t_field8<W>(s_w, tid, pos, w0, w1);
+                t_field8<W>(s_w, tid, pos, w0, w1, z_rows);
                 const uint64_t km = t_lowbytes(len);
                 w0 &= (uint32_t)km;
                 w1 &= (uint32_t)(km >> 32);
@@ -856,7 +901,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A)
         } else
         do {
             uint32_t x0, x1;
-            t_field8<W>(s_w, tid, pos + 8 * c8, x0, x1);
+            t_field8<W>(s_w, tid, pos + 8 * c8, x0, x1, z_rows);
             const uint32_t left = len > 8 * c8 ? len - 8 * c8 : 0;
             const uint64_t km = t_lowbytes(left);
             x0 &= (uint32_t)km;
@@ -978,11 +1023,20 @@ void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(k_title_stats_reg, grid, dim3(TT_THREADS), 0, st, A);
 }
 
-void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec)
+void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_title)
 {
     dim3 grid((max_rec + TT_THREADS - 2) / (TT_THREADS - 1), A.n_sb);
-    if (A.tsep_words == 2) hipLaunchKernelGGL(k_title_stats_swar<2>, grid, dim3(TT_THREADS), 0, st, A);
-    else hipLaunchKernelGGL(k_title_stats_swar<1>, grid, dim3(TT_THREADS), 0, st, A);
+    // LDS by the job's longest title: its dwords (+ the zero row) and the fields it can have at most (one per separator byte)
+    const uint32_t W = A.tsep_words == 2 ? 2u : 1u;
+    uint32_t z = (max_title + 3) / 4;
+    if (z > 16 * W) z = 16 * W;
+    if (z < 1) z = 1;
+    uint32_t nfc = max_title < MAX_FIELDS ? (max_title < 1 ? 1u : max_title) : MAX_FIELDS;
+    if (getenv("NGSC_TS_FULL_LDS")) { z = 16 * W; nfc = MAX_FIELDS; }   // (round 2's footprint, for the comparison)
+    const size_t lds = ((size_t)((nfc * 18 + 3) & ~3u) + (size_t)(z + 1) * TT_THREADS) * 4;
+    const uint32_t quad = getenv("NGSC_TS_QUAD") && !strcmp(getenv("NGSC_TS_QUAD"), "0") ? 0u : 1u;
+    if (W == 2) hipLaunchKernelGGL(k_title_stats_swar<2>, grid, dim3(TT_THREADS), lds, st, A, z, nfc | (quad << 16));
+    else hipLaunchKernelGGL(k_title_stats_swar<1>, grid, dim3(TT_THREADS), lds, st, A, z, nfc | (quad << 16));
 }
 
 void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar)

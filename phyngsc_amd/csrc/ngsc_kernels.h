@@ -37,7 +37,7 @@ void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool us
 
 // ---- kernels_huffman.hip ----
 void launch_huffman_sb(hipStream_t st, const Arena &A);
-void launch_huffman_sq(hipStream_t st, const Arena &A);
+void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected = false);   // quality / DNA trees (both instances)
 void launch_huffman_fields(hipStream_t st, const Arena &A);
 void launch_huffman_text(hipStream_t st, const Arena &A);
 
@@ -57,7 +57,7 @@ void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 // ---- kernels_title.hip (register-resident title path) ----
 void launch_rec0_fields(hipStream_t st, const Arena &A);
 void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
-void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_title);
 void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar);
 void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 

@@ -12,7 +12,7 @@ run() {
     sfx=$1; shift
     echo "pass $sfx: $*" >> $out/pmc_${tag}_progress.txt
     timeout -k 5 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_${tag}_$sfx -- \
-        python3 $repo/${PMC_SCRIPT:-bench.py} ${PMC_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-verify} > $out/pmc_${tag}_$sfx.log 2>&1 || { echo "pass $sfx failed" >> $out/pmc_${tag}_progress.txt; return 1; }
+        python3 $repo/${PMC_SCRIPT:-bench.py} ${PMC_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs} > $out/pmc_${tag}_$sfx.log 2>&1 || { echo "pass $sfx failed" >> $out/pmc_${tag}_progress.txt; return 1; }
     python3 $repo/tools/pmc_summary.py $out/pmc_${tag}_$sfx > $out/pmc_${tag}_$sfx.json
     find $out/pmc_${tag}_$sfx -name "*.csv" -size +8M -delete
 }

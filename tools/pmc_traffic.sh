@@ -9,7 +9,7 @@ out=$repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_$c -- \
-        python3 $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $out/pmc_${tag}_$c.log 2>&1
+        python3 $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $out/pmc_${tag}_$c.log 2>&1
     python3 $repo/tools/pmc_summary.py $out/pmc_${tag}_$c > $out/pmc_${tag}_$c.json
     find $out/pmc_${tag}_$c -name "*.csv" -size +8M -delete
 done
