@@ -148,7 +148,7 @@ static double now_s()
 static unsigned io_threads()
 {
     const char *e = getenv("NGSC_IO_THREADS");
-    const int v = e ? atoi(e) : 8;
+    const int v = e ? atoi(e) : 12;   // (round 3 sweep on the 50 GB file, 64 ranks: 4 / 6 / 8 / 12 threads = 3.3 / 3.0 / 3.0 / 2.7 s)
     return (unsigned)std::max(1, std::min(v, 16));
 }
 

@@ -122,32 +122,50 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
-// Single workgroup exclusive scan of the tile counts (n up to ~524k); total -> *total_out.
+// Single workgroup exclusive scan of the tile counts (n up to ~64k: a job is < 4 GiB); total -> *total_out.
+// (round 3) the counts come into LDS with coalesced loads and leave the same way; a thread scans its stretch there - with the
+// stretches read straight from global memory every thread walked 15 addresses 60 bytes apart, twice (0.017 ms on the index chain)
+constexpr uint32_t SCAN_LDS = 15 * 1024;   // counts held in LDS (a 1 GB job has 15 259 tiles); larger jobs take several rounds
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t *tile_cnt, uint32_t n, uint32_t *total_out)
 {
     __shared__ uint32_t s_wave[16];
-    const uint32_t per = (n + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per;
-    const uint32_t hi = lo + per < n ? lo + per : n;
-    uint32_t sum = 0;
-#pragma unroll 8
-    for (uint32_t i = lo; i < hi; ++i) sum += tile_cnt[i];
-    uint32_t incl = wave_scan_incl(sum);
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        uint32_t v = threadIdx.x < 16 ? s_wave[threadIdx.x] : 0;
-        uint32_t sc = wave_scan_incl(v);
-        if (threadIdx.x < 16) s_wave[threadIdx.x] = sc - v;  // exclusive wave offsets
-        if (threadIdx.x == 15) *total_out = sc;
+    __shared__ uint32_t s_c[SCAN_LDS];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += SCAN_LDS) {
+        const uint32_t m = n - base < SCAN_LDS ? n - base : SCAN_LDS;
+        for (uint32_t k = threadIdx.x; k < m; k += 1024) s_c[k] = tile_cnt[base + k];
+        __syncthreads();
+        const uint32_t per = (m + 1023) / 1024;
+        const uint32_t lo = threadIdx.x * per < m ? threadIdx.x * per : m;
+        const uint32_t hi = lo + per < m ? lo + per : m;
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; ++i) sum += s_c[i];
+        const uint32_t incl = wave_scan_incl(sum);
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t round_total = 0;
+        if (threadIdx.x < 64) {
+            const uint32_t v = threadIdx.x < 16 ? s_wave[threadIdx.x] : 0;
+            const uint32_t sc = wave_scan_incl(v);
+            if (threadIdx.x < 16) s_wave[threadIdx.x] = sc - v;  // exclusive wave offsets
+        }
+        __syncthreads();
+        uint32_t run = carry + s_wave[threadIdx.x >> 6] + incl - sum;
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t c = s_c[i];
+            s_c[i] = run;
+            run += c;
+        }
+        // the round's total = the last thread's running sum (every stretch is accounted for: empty ones add nothing)
+        __syncthreads();
+        if (threadIdx.x == 1023) s_wave[0] = run;
+        __syncthreads();
+        round_total = s_wave[0];
+        for (uint32_t k = threadIdx.x; k < m; k += 1024) tile_cnt[base + k] = s_c[k];
+        carry = round_total;
+        __syncthreads();
     }
-    __syncthreads();
-    uint32_t run = s_wave[threadIdx.x >> 6] + incl - sum;
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t c = tile_cnt[i];
-        tile_cnt[i] = run;
-        run += c;
-    }
+    if (threadIdx.x == 0) *total_out = carry;
 }
 
 // Writes the record table.  Line L (0-based from *start_ptr) ends at a newline; L&3 == 0: title end of
