@@ -1607,7 +1607,7 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         uint32_t Ka = DEC_K;
         while (Ka > 5 && ((uint64_t)rows << Ka) > lds_cap) --Ka;
         const uint32_t lds_a_entries = (uint32_t)std::min<uint64_t>(lds_cap, (uint64_t)rows << Ka);
-        static const bool lds_trees = !(getenv("NGSC_DEC_LDS_TREES") && !strcmp(getenv("NGSC_DEC_LDS_TREES"), "0"));
+        const bool lds_trees = !(getenv("NGSC_DEC_LDS_TREES") && !strcmp(getenv("NGSC_DEC_LDS_TREES"), "0"));   // (per call: the tests switch it)
         const uint32_t nq_cap = spec_max_nq < 2 ? 2u : (spec_max_nq > 128 ? 128u : spec_max_nq);
         size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
         if (((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes > (120u << 10)) tree_bytes = 0;   // (long reads: no room for the trees)
@@ -1627,7 +1627,7 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         dec_lap(st, t0, "k_dec_qspec_c");
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_dec_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds_entries));
-    static const bool dna_par = !(getenv("NGSC_DEC_DNA_PAR") && !strcmp(getenv("NGSC_DEC_DNA_PAR"), "0"));
+    const bool dna_par = !(getenv("NGSC_DEC_DNA_PAR") && !strcmp(getenv("NGSC_DEC_DNA_PAR"), "0"));
     const uint32_t mode = hop && dna_par ? 1u : 0u;   // (the parallel base decoder keeps its tables in the hop area)
     hipLaunchKernelGGL(k_dec_tail, dim3(n_sb), dim3(64), 2 * lds_entries, st, sub, sb_off, sb_len, n_sb, scratch, stride, rec_cap, tcap, qcap,
                        (DecSub *)out, (DecCtl *)ctl, lds_entries, mode);

@@ -1473,9 +1473,9 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     // walk ceil(chunks / 4) trips whatever the other records of the wave need, and on 36..150-base reads the form lost 25 %
     // (0.39 -> 0.53 ms per 400 MB) where it gains 8 % on 150-base reads (0.324 -> 0.298)
     const bool even = (uint64_t)A.buf_len / (n_rec_total ? n_rec_total : 1u) * 4 >= (uint64_t)max_rec_bytes * 3;
-    static const int forced_any = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;
+    const int forced_any = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;   // (read per call: the tests switch it)
     if (!staged && sr_burst(A) && max_rec_bytes && (even || forced_any > 0)) {
-        static const int forced = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;
+        const int forced = forced_any;
         const uint32_t lpr = forced > 0 ? (uint32_t)forced : 4u;
         const uint32_t mcap = ((64u / lpr) * max_rec_bytes + 48u + 1023u) & ~1023u;
         const uint32_t nslots = 8 * ((A.qrows + 14) / 16);

@@ -153,6 +153,37 @@ def test_kernel_paths_agree(eng, monkeypatch, sq_path):
         assert ok, f"{name} (sq_path={sq_path}): {msg}"
 
 
+ROUND3_SWITCHES = [("NGSC_TS_QUAD", "0"), ("NGSC_TS_FULL_LDS", "1"), ("NGSC_SQ_STATS_512", "0"), ("NGSC_SQ_NO_TAIL", "1"),
+                   ("NGSC_NO_EARLY_ZERO", "1"), ("NGSC_CV_VEC", "1"), ("NGSC_CV_NOCACHE", "1"), ("NGSC_CV_SPLIT", "1"),
+                   ("NGSC_SQ_MULTI", "0"), ("NGSC_SQ_MULTI", "2"), ("NGSC_SQ_MULTI", "8"), ("NGSC_OVERLAP", "0"), ("NGSC_OVERLAP", "3")]
+
+
+@pytest.mark.parametrize("switch", ROUND3_SWITCHES, ids=[f"{k}={v}" for k, v in ROUND3_SWITCHES])
+def test_round3_switches_agree(eng, monkeypatch, switch):
+    """Every alternative form round 3 left behind a switch - a lane's own title loads instead of the quad-cooperative ones, round 2's
+    LDS footprint of the title statistics, 256-thread staged statistics, 16-byte last chunks in the copies, no early clearing,
+    the validation pass with 16-byte loads / on its own stream, the planner without its LDS cache, the statistics kernels for long
+    reads with 1 / 2 / 8 lanes per record, the serial and the early-fork schedules - reproduces the reference on committed goldens
+    and the oracle on generated 36-base, 150-base and mixed-length inputs (two calls each: the second one runs on the first one's
+    arena and output hints)."""
+    monkeypatch.setenv(*switch)
+    for name in PATH_CASES:
+        stem, P = name.rsplit(".p", 1)
+        with open(os.path.join(GOLDEN, "small", stem + ".fastq"), "rb") as f:
+            data = f.read()
+        with open(os.path.join(GOLDEN, "small", name + ".ngsc"), "rb") as f:
+            ref = f.read()
+        _, out = _gpu(eng, data, int(P))
+        ok, msg = nf.equivalent(ref, out)
+        assert ok, f"{name} ({switch}): {msg}"
+    for cfg, size, P in ((fastq_gen.CFG2, 24_000_000, 4), (fastq_gen.CFG3, 30_000_000, 3), (fastq_gen.CFG5_300, 20_000_000, 5)):
+        data = fastq_gen.generate(cfg, target_bytes=size)
+        want, _ = orc.compress_file(data, P, threads=8)
+        for _ in range(2):
+            _, out = _gpu(eng, data, P)
+            assert out == want, (switch, cfg)
+
+
 @pytest.mark.parametrize("title_path", ["reg", "swar"])
 def test_title_paths_agree(eng, monkeypatch, title_path):
     """Titles of at most 64 bytes take the word-parallel title kernels (separator/digit masks from v_perm nibble
@@ -663,6 +694,19 @@ def test_decompress_file_shared_records_and_cli(eng, tmp_path):
     assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
     mid.write_bytes(raw[:8 << 20] + raw[(8 << 20) + 5:])
     assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
+
+
+@pytest.mark.parametrize("switch", [("NGSC_DEC_DNA_PAR", "0"), ("NGSC_DEC_LDS_TREES", "0"), ("NGSC_DEC_SPEC", "0")],
+                         ids=["serial_bases", "trees_in_global_memory", "serial_qualities"])
+def test_gpu_decoder_switches_agree(eng, monkeypatch, switch):
+    """The decoder's round-3 forms against their predecessors: Huffman-coded bases decoded by one wave instead of in parallel,
+    long quality codes walked in global memory instead of LDS, the quality stream decoded serially - each must give the input
+    back (150-base reads with N bases: Huffman-coded bases, equally long reads; mixed lengths: no speculation anyway)."""
+    monkeypatch.setenv(*switch)
+    for cfg, size, P in ((fastq_gen.CFG3, 30_000_000, 3), (fastq_gen.CFG5_300, 12_000_000, 2), (fastq_gen.CFG2, 20_000_000, 2)):
+        data = fastq_gen.generate(cfg, target_bytes=size)
+        _, out = _gpu(eng, data, P)
+        assert api.decompress_bytes(out, engine=eng) == data.tobytes(), (switch, cfg)
 
 
 def test_gpu_decoder_refuses_garbage(eng):
