@@ -11,6 +11,7 @@
 // Latency-bound, negligible bytes: no roofline claim attached to this kernel.
 #include "ngsc_kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace ngsc {
 
@@ -56,10 +57,118 @@ __device__ void build_tree_wave(Tree &T, uint32_t n)
     __syncthreads();
 }
 
+// (round 3) Trees of at most 64 symbols - every quality / base tree of an ordinary file - are built in REGISTERS: the sorted leaves,
+// the internal nodes' frequencies and children and the traversal stack are arrays with one element per lane, read and written with
+// v_readlane / v_writelane at scalar indices, the loop state lives in scalar registers (every lane runs the same uniform code).
+// The serial part of a tree - 40 merge steps, 81 nodes written out in pre-order - was ~500 dependent LDS round trips of one lane
+// (~30 us, the whole launch's time since all trees of a job are in flight at once); code lengths and codes come from a parallel
+// walk of every leaf up its parent chain instead of the top-down pass over the internal nodes.  Same tree, same blob
+// (huffman.cpp:18-118): ties go to the smaller node id as in huffman_sequential(), which stays the path for larger alphabets.
+__device__ __forceinline__ uint32_t hw_rl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// (an element written at a scalar index: a compare against the lane id and a select - two VALU instructions, no hazards; this
+// compiler has no v_writelane builtin and the instruction takes a single SGPR operand on gfx9)
+#define hw_wl(val, idx, old) ((lane == (uint32_t)(idx)) ? (uint32_t)(val) : (uint32_t)(old))
+
+__device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    const uint32_t n = U(n_in);
+    __syncthreads();
+    // rank sort (as in build_tree_wave): lane r ends up with the r-th smallest (frequency, symbol) key
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint64_t k = T.keys[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += T.keys[j] < k;
+        T.sorted[rank] = k;
+    }
+    __syncthreads();
+    const uint64_t key = lane < n ? T.sorted[lane] : ~0ull;
+    const uint32_t vf = (uint32_t)(key >> 32), vs = (uint32_t)(key & 0xffffu);
+    // compact: zero frequencies go while more than two symbols remain (huffman.cpp:44-50); sorted, so they are the first lanes
+    const uint32_t zeros = (uint32_t)__popcll(__ballot(lane < n && vf == 0));
+    const uint32_t drop = n > 2 ? (zeros < n - 2 ? zeros : n - 2) : 0;
+    const uint32_t present = n - drop;
+    // ---- merge: two queues, leaves (lane order) and internal nodes (creation order) ----
+    uint32_t vif = 0, vlc = 0, vrc = 0;           // per internal node k (lane k): frequency, children (node ids)
+    uint32_t par_l = 0xffu, par_i = 0xffu;        // parent (creation index) of leaf `lane` (by SYMBOL) / of internal node `lane`; 0xff: none
+    uint32_t right_l = 0, right_i = 0;            // ... and whether the node is its parent's right child
+    uint32_t lq = drop, iq = 0, made = 0;
+    for (uint32_t k = 0; k + 1 < present; ++k) {
+        uint32_t f2[2], id2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t lf = lq < n ? hw_rl(vf, lq) : 0u, inf = iq < made ? hw_rl(vif, iq) : 0u;
+            const bool take_leaf = (lq < n && iq < made) ? lf <= inf : lq < n;
+            if (take_leaf) { f2[t] = lf; id2[t] = hw_rl(vs, lq); ++lq; }
+            else { f2[t] = inf; id2[t] = n + iq; ++iq; }
+        }
+        vif = hw_wl(f2[0] + f2[1], made, vif);
+        vlc = hw_wl(id2[0], made, vlc);
+        vrc = hw_wl(id2[1], made, vrc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (id2[t] < n) { par_l = hw_wl(made, id2[t], par_l); right_l = hw_wl((uint32_t)t, id2[t], right_l); }
+            else { par_i = hw_wl(made, id2[t] - n, par_i); right_i = hw_wl((uint32_t)t, id2[t] - n, right_i); }
+        }
+        ++made;
+    }
+    const uint32_t root = n + present - 2;        // (node id; for a single symbol: leaf 0)
+    // ---- code of every leaf: up its parent chain (huffman.cpp:73-79 gives a child its parent's code << 1 | right) ----
+    uint32_t code = 0, len = 0;
+    {
+        uint32_t p = lane < n ? par_l : 0xffu, bit = right_l;
+        while (__any(p != 0xffu)) {
+            const uint32_t np = (uint32_t)__shfl((int)par_i, (int)(p & 63u)), nb = (uint32_t)__shfl((int)right_i, (int)(p & 63u));
+            if (p != 0xffu) { code |= bit << len; ++len; p = np; bit = nb; }
+        }
+    }
+    uint32_t mx = len, mn = (lane < n && len > 0) ? len : 0xffffffffu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)mx, d), b = (uint32_t)__shfl_xor((int)mn, d);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    if (lane < n) { T.code[lane] = code; T.len[lane] = (uint8_t)len; }
+    // ---- blob (huffman.cpp:88-118): root id, symbol count, shortest code, the tree in pre-order ----
+    uint32_t bits_per_id = 0;
+    while ((2u << bits_per_id) <= n) ++bits_per_id;
+    if (n & (n - 1)) ++bits_per_id;
+    const uint32_t min_len = mn == 0xffffffffu ? n : U(mn);
+    uint8_t *blob = T.blob;
+    if (lane == 0) {
+        blob[0] = (uint8_t)(root >> 24); blob[1] = (uint8_t)(root >> 16); blob[2] = (uint8_t)(root >> 8); blob[3] = (uint8_t)root;
+        blob[4] = (uint8_t)(n >> 24); blob[5] = (uint8_t)(n >> 16); blob[6] = (uint8_t)(n >> 8); blob[7] = (uint8_t)n;
+        blob[8] = (uint8_t)min_len;
+    }
+    uint32_t pos = 9, nacc = 0;
+    uint64_t acc = 0;
+    uint32_t vstack = 0, sp = 0;                  // the stack: lane i holds entry i (at most n entries are pending at a time)
+    vstack = hw_wl(root, 0, vstack); sp = 1;
+    while (sp) {
+        const uint32_t node = hw_rl(vstack, --sp);
+        uint32_t v, nb;
+        if (node < n) { v = (1u << bits_per_id) | node; nb = 1 + bits_per_id; }
+        else {
+            v = 0; nb = 1;
+            vstack = hw_wl(hw_rl(vrc, node - n), sp, vstack); ++sp;
+            vstack = hw_wl(hw_rl(vlc, node - n), sp, vstack); ++sp;
+        }
+        acc = (acc << nb) | v;
+        nacc += nb;
+        while (nacc >= 8) { if (lane == 0) blob[pos] = (uint8_t)(acc >> (nacc - 8)); ++pos; nacc -= 8; }
+        acc &= (1ull << nacc) - 1ull;
+    }
+    if (nacc) { if (lane == 0) blob[pos] = (uint8_t)(acc << (8 - nacc)); ++pos; }
+    if (lane == 0) { T.blob_len = pos; T.max_len = U(mx); }
+    __syncthreads();
+}
+
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
 template <bool SMALL, class Tree>
-__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t)
+__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t, bool regs)
 {
     const int lane = threadIdx.x;
     const SbState &sb = A.sb[s];
@@ -71,7 +180,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nqual;
         const uint32_t *row = A.qhist + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)row[sb.qualities[j]] << 32) | j;
-        build_tree_wave(T, n);
+        if constexpr (SMALL) { if (regs) build_tree_regs(T, n); else build_tree_wave(T, n); } else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.qcodes + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[j] = (T.code[j] << 5) | T.len[j];
@@ -84,7 +193,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nsym;
         const uint32_t *occ = A.dna_occ + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)occ[sb.symbols[j]] << 32) | j;
-        build_tree_wave(T, n);
+        if constexpr (SMALL) { if (regs) build_tree_regs(T, n); else build_tree_wave(T, n); } else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.dcodes + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[sb.symbols[j]] = (T.code[j] << 5) | T.len[j];
@@ -117,14 +226,14 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
 // its sub-block's alphabets fit the small instance and it has nothing to do - 4560 such workgroups queued behind the title
 // statistics kernel's LDS for 260 us of the staggered schedule, and the measure kernel behind them (round 3).
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt)
+__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t regs)
 {
     if (*A.err) return;
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     __shared__ Tree T;
     const uint32_t pairs = nt * A.n_sb;
     for (uint32_t p = blockIdx.x; p < pairs; p += gridDim.x) {
-        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt);
+        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt, regs != 0);
         __syncthreads();   // (T is used again)
     }
 }
@@ -162,8 +271,9 @@ static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uin
 {
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
-    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3(pairs), dim3(64), 0, st, A, t0, nt);
-    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt);
+    const uint32_t regs = getenv("NGSC_HUFF_LDS") ? 0u : 1u;   // (NGSC_HUFF_LDS=1: round 2's LDS form of the small instance)
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3(pairs), dim3(64), 0, st, A, t0, nt, regs);
+    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt, 0u);
 }
 
 void launch_huffman_sb(hipStream_t st, const Arena &A)
