@@ -500,6 +500,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_fdesc = cp.take(sizeof(FieldDesc) * (size_t)S * MAX_FIELDS);
     size_t p_grplo = cp.take(4 * (size_t)S);
     size_t p_qcodes = cp.take(4 * (size_t)S * qrows * 256);
+    size_t p_qfmt = cp.take(sq_qfmt_bytes(qrows, S));
     size_t p_qblob = cp.take((size_t)S * qrows * BLOB_SLOT_256);
     size_t p_qblen = cp.take(4 * (size_t)S * qrows);
     size_t p_qrowoff = cp.take(4 * (size_t)S * qrows);
@@ -567,6 +568,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.qhist = (uint32_t *)(zb + z_qhist);
     A.nhist = (uint32_t *)(zb + z_nhist);
     A.qcodes = (uint32_t *)(pb + p_qcodes);
+    A.qfmt = (uint32_t *)(pb + p_qfmt);
+    A.qfmt_stride = (uint32_t)sq_qfmt_words(qrows);
     A.qblob = pb + p_qblob;
     A.qblob_len = (uint32_t *)(pb + p_qblen);
     A.dcodes = (uint32_t *)(pb + p_dcodes);

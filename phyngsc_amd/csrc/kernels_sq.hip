@@ -801,6 +801,64 @@ __device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const S
     }
 }
 
+// (round 3) The same table from its ready-made copy in global memory (Arena::qfmt, k_sq_format_qtab): rows row_lo .. of the
+// sub-block's table as they lie there - a straight 8-byte copy instead of a clearing pass, a barrier and one division per
+// entry, which the windowed pack kernel paid once per window and tile (five times per tile of 150-base reads).  The rows behind
+// lds_rows hold the table's next rows instead of zeros: nothing reads their values (see SQ_QROWS_EXTRA).
+// (the byte tables lie behind the dword tables: 16-byte multiples per sub-block, the pad bytes never written nor used)
+__device__ __host__ __forceinline__ uint32_t sq_qfmt8_stride(uint32_t qrows) { return ((qrows + SQ_QROWS_EXTRA) * SQ_QS + 15u) & ~15u; }
+__device__ __forceinline__ uint8_t *sq_qfmt8(const Arena &A, uint32_t s)
+{
+    return reinterpret_cast<uint8_t *>(A.qfmt + (size_t)A.n_sb * A.qfmt_stride) + (size_t)s * sq_qfmt8_stride(A.qrows);
+}
+// the measure kernel's table: the first lds_rows + SQ_QROWS_EXTRA rows of the byte table, 16 bytes per step (the LDS area is
+// a 16-byte multiple, see launch_sq_measure_reg)
+__device__ __forceinline__ void sq_copy_qtab8(const Arena &A, uint32_t s, uint8_t *s_qlen, uint32_t lds_rows)
+{
+    const uint32_t bytes = ((lds_rows + SQ_QROWS_EXTRA) * SQ_QS + 15u) & ~15u;   // (<= the sub-block's stride: lds_rows <= qrows)
+    const uint4 *src = reinterpret_cast<const uint4 *>(sq_qfmt8(A, s));
+    for (uint32_t k = threadIdx.x; k < bytes / 16; k += SR_THREADS) reinterpret_cast<uint4 *>(s_qlen)[k] = src[k];
+}
+
+__device__ __forceinline__ void sq_copy_qtab(const Arena &A, uint32_t s, uint32_t *s_qtab, uint32_t lds_rows, uint32_t row_lo)
+{
+    const uint32_t words = (lds_rows + SQ_QROWS_EXTRA) * SQ_QS, lim = (A.qrows + SQ_QROWS_EXTRA) * SQ_QS, src0 = row_lo * SQ_QS;
+    const uint32_t *src = A.qfmt + (size_t)s * A.qfmt_stride;
+    for (uint32_t k = 2 * threadIdx.x; k < words; k += 2 * SR_THREADS) {   // (row_lo is even - 0 or a multiple of the window: so is src0)
+        uint2 v = make_uint2(0, 0);
+        if (src0 + k + 1 < lim) v = *reinterpret_cast<const uint2 *>(src + src0 + k);
+        else if (src0 + k < lim) v.x = src[src0 + k];
+        if (k + 1 < words) *reinterpret_cast<uint2 *>(s_qtab + k) = v;
+        else s_qtab[k] = v.x;
+    }
+}
+
+__global__ __launch_bounds__(SR_THREADS) void k_sq_format_qtab(Arena A)
+{
+    if (*A.err) return;
+    __shared__ uint16_t s_inv[SQ_QS];   // column -> alphabet index + 1
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    if (threadIdx.x < SQ_QS) s_inv[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x < sb.nqual) {
+        const uint32_t qv = sb.qualities[threadIdx.x];
+        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : qv - 33u;   // (as sq_fill_qtab)
+        if (col < SR_HCOLS || (col >= SQ_NCOL0 && col < SQ_QS)) s_inv[col] = (uint16_t)(threadIdx.x + 1);
+    }
+    __syncthreads();
+    const uint32_t words = (A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
+    const uint32_t *qg = A.qcodes + (size_t)s * A.qrows * 256;
+    uint32_t *dst = A.qfmt + (size_t)s * A.qfmt_stride;
+    uint8_t *dst8 = sq_qfmt8(A, s);   // (the measure kernel's table: the code lengths alone, a byte each)
+    for (uint32_t k = blockIdx.x * SR_THREADS + threadIdx.x; k < words; k += gridDim.x * SR_THREADS) {
+        const uint32_t row = k / SQ_QS, inv = s_inv[k % SQ_QS];
+        const uint32_t e = (inv && row < A.qrows) ? qg[(size_t)row * 256 + inv - 1] : 0u;
+        dst[k] = e;
+        dst8[k] = (uint8_t)(e & 31u);
+    }
+}
+
 // May the lean paths run on this sub-block?  Every alphabet symbol below 128 has a table column (the symbols from 128 on are
 // transferred qualities, or raw bytes with the high bit set, which the lean paths test for per chunk) and every row is in
 // the table.  Whole workgroup; thread = alphabet index.
@@ -824,8 +882,9 @@ __device__ __forceinline__ uint32_t sq_qentry_slow(const SqTabs &T, uint32_t row
 
 // ---- measure: payload bits per record and per 256-record tile ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw)
+__global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw, uint32_t fmt)
 {
+    // fmt != 0: the length table comes from its ready-made copy (sq_copy_qtab8)
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_qlen[];   // [lds_rows][64] code lengths
     __shared__ uint32_t s_dcode[256];
@@ -844,7 +903,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
     s_qcode[tid] = sb.qua_code[tid];
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
     if (tid < 2) s_tot[tid] = 0;
-    sq_fill_qtab(A, s, sb, s_qlen, lds_rows);
+    if (fmt) sq_copy_qtab8(A, s, s_qlen, lds_rows);
+    else sq_fill_qtab(A, s, sb, s_qlen, lds_rows);
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
@@ -995,7 +1055,11 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     const uint32_t q = A.buf[q0 + pos], col = q - 33;
                     const uint32_t l_tab = (col < SR_HCOLS && row < lds_rows) ? s_qlen[row * SQ_QS + col] : (sq_qentry_slow(T, row, q) & 31u);
                     const uint32_t qt = transfer_quality(s_amb[A.buf[s0 + pos]], (uint8_t)q);   // phyNGSC.cpp:579
-                    qb += (sq_qentry_slow(T, row, qt) & 31u) - l_tab;
+                    // (round 3) a transferred N - by far the usual ambiguity code - has its columns in the LDS table (SQ_NCOL0 ..): no
+                    // two dependent global lookups per N, which 26 % of 150-base records carry at 0.2 % N
+                    const uint32_t ncol = qt - 208u;
+                    const uint32_t l_new = (ncol < 8u && row < lds_rows) ? s_qlen[row * SQ_QS + SQ_NCOL0 + ncol] : (sq_qentry_slow(T, row, qt) & 31u);
+                    qb += l_new - l_tab;
                 }
             }
         }
@@ -1039,8 +1103,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 
 // ---- pack ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
+__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win, uint32_t fmt)
 {
+    // fmt != 0: the table comes from its ready-made copy (sq_copy_qtab)
     // win != 0 (long reads): the table holds one WINDOW of win positions (rows r0 .. r0 + win, lds_rows = win + 1), refilled
     // window after window for every tile - a [301][49] table plus staging left room for two workgroups per CU, a window
     // of 48 rows leaves room for four, and the lean path no longer needs the whole table to fit.
@@ -1063,7 +1128,10 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
     s_qcode[tid] = sb.qua_code[tid];
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
-    if (!win) sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
+    if (!win) {
+        if (fmt) sq_copy_qtab(A, s, s_qtab, lds_rows, 0);
+        else sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
+    }
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const uint32_t n_win = win ? (sb.max_q + win - 1) / win : 1u, win_chunks = win ? win / 16 : ~0u;   // (uniform over the workgroup)
@@ -1130,7 +1198,8 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         const uint32_t r0 = w * win;
         if (win) {   // (whole workgroup: n_win comes from the sub-block's longest read)
             __syncthreads();
-            sq_fill_qtab(A, s, sb, s_qtab, lds_rows, r0);
+            if (fmt) sq_copy_qtab(A, s, s_qtab, lds_rows, r0);
+            else sq_fill_qtab(A, s, sb, s_qtab, lds_rows, r0);
             __syncthreads();
         }
         for (uint32_t grp = w * (win_chunks / NBX); (!win || grp < (w + 1) * (win_chunks / NBX)) && __any(16 * NBX * grp < L); ++grp) {
@@ -1419,9 +1488,11 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 // Records per workgroup: enough to amortise the table fill / histogram flush (1024), but never so many that the job
 // has fewer than ~8 workgroups per CU - long reads mean few records per byte, and a 1024-record workgroup of
 // 150-bp reads left the 256 CUs with four workgroups each.  (NGSC_SQ_RECORDS_PER_WG overrides.)
-static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024)
+static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024, const char *own_env = nullptr)
 {
-    static const uint32_t forced = getenv("NGSC_SQ_RECORDS_PER_WG") ? (uint32_t)atoi(getenv("NGSC_SQ_RECORDS_PER_WG")) : 0;
+    // (developer knobs: NGSC_SQ_RECORDS_PER_WG for the three kernels together, NGSC_SQ_RPW_STATS / _MEASURE / _PACK for one)
+    const char *e = own_env && getenv(own_env) ? getenv(own_env) : getenv("NGSC_SQ_RECORDS_PER_WG");
+    const uint32_t forced = e ? (uint32_t)atoi(e) : 0;
     if (forced) return forced < SR_THREADS ? SR_THREADS : forced / SR_THREADS * SR_THREADS;
     const uint64_t records = (uint64_t)max_rec * A.n_sb;   // upper estimate of the job's records
     // (most: measure and pack, which fill a code table per workgroup, gain another 3-6 % from 2048 / 4096 records per
@@ -1457,7 +1528,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
     if (rows > max_rows) rows = max_rows;
-    const uint32_t rpw = sr_records_per_wg(A, max_rec);
+    const uint32_t rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS");
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
     uint32_t span_cap = 0;
     const bool staged = sr_staged(A, max_rec_bytes, span_cap);
@@ -1507,6 +1578,12 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw, span_cap);
 }
 
+// Arena::qfmt: per sub-block a dword table (a multiple of 4 dwords) and, behind all of those, a byte table (16-byte multiples)
+size_t sq_qfmt_words(uint32_t qrows) { return (((size_t)qrows + SQ_QROWS_EXTRA) * SQ_QS + 3) & ~(size_t)3; }
+size_t sq_qfmt_bytes(uint32_t qrows, uint32_t n_sb) { return (size_t)n_sb * (4 * sq_qfmt_words(qrows) + sq_qfmt8_stride(qrows)); }
+// the tables in their LDS layouts, once per sub-block (NGSC_SQ_QFMT=0: every workgroup gathers them from the code table itself)
+static bool sq_qfmt_on() { return !(getenv("NGSC_SQ_QFMT") && !strcmp(getenv("NGSC_SQ_QFMT"), "0")); }   // (read per call: the tests switch it)
+
 static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)
 {
     const uint32_t max_rows = budget / (SQ_QS * entry_bytes) - SQ_QROWS_EXTRA;
@@ -1516,10 +1593,15 @@ static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budge
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
-    const uint32_t tpw = sr_records_per_wg(A, max_rec, 2048) / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec, 2048, "NGSC_SQ_RPW_MEASURE") / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     auto kern = sr_burst(A) ? k_sq_measure_reg<true> : k_sq_measure_reg<false>;
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw);
+    const bool fmt = sq_qfmt_on();
+    if (fmt) {   // (here: behind the Huffman kernel, ahead of both readers)
+        const uint32_t words = (uint32_t)(A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
+        hipLaunchKernelGGL(k_sq_format_qtab, dim3((words + 4 * SR_THREADS - 1) / (4 * SR_THREADS), A.n_sb), dim3(SR_THREADS), 0, st, A);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw, fmt ? 1u : 0u);
 }
 
 // Long reads: a table of one window of positions (NGSC_SQ_WINDOW rows, a multiple of 16; 0 = never) once the whole table
@@ -1537,7 +1619,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     const uint32_t rows = win ? win + 1 : sr_rows_for(A.qrows, 4, 48u << 10);
     if (sw_q > 8192) sw_q = 8192;
     if (sw_d > 6144) sw_d = 6144;
-    const uint32_t tpw = sr_records_per_wg(A, max_rec, 4096) / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec, 4096, "NGSC_SQ_RPW_PACK") / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     const size_t lds = ((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + sw_q + sw_d) * 4;
     // one chunk per trip: with NB chunks fetched back to back this kernel is 8-10 % slower on every configuration (it
@@ -1546,7 +1628,8 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     // mixed reads - 0.340 against 0.334 ms, 0.530 / 0.530 - and cost 16 % at 36 bases)
     auto kern = k_sq_pack_reg<false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win);
+    const bool fmt = sq_qfmt_on();   // (the tables: written by launch_sq_measure_reg's first kernel)
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win, fmt ? 1u : 0u);
 }
 
 }  // namespace ngsc

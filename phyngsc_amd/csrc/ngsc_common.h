@@ -322,6 +322,10 @@ struct Arena {
     // dtail_b = 4 / 8 / 12 bytes per record instead of 16: chunk dtail_c of record g at dense_x + dtail_c * dstride * 16 + g * dtail_b
     // (a quarter of the copies' bytes at 36 bases).  dtail_c == 0xffffffff: every chunk is 16 bytes
     uint32_t dtail_c, dtail_b;
+    // (round 3) the quality code table of every sub-block in the layout the pack kernel keeps in LDS (k_sq_format_qtab):
+    // [qrows + 17][57] dwords, qfmt_stride dwords per sub-block
+    uint32_t *qfmt;
+    uint32_t qfmt_stride;
     uint8_t *out;           // output buffer
 };
 

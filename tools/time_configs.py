@@ -9,7 +9,7 @@ from phyngsc_amd import api, fastq_gen
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000_000
 eng = api.Engine(0)
 only = os.environ.get("NGSC_TC_ONLY")
-for name, cfg in (("cfg1", fastq_gen.CFG1), ("cfg2", fastq_gen.CFG2), ("cfg3_150bp", fastq_gen.CFG3), ("cfg5_mixed", fastq_gen.CFG5)):
+for name, cfg in (("cfg1", fastq_gen.CFG1), ("cfg2", fastq_gen.CFG2), ("cfg3_150bp", fastq_gen.CFG3), ("cfg5_mixed", fastq_gen.CFG5), ("cfg5_36_300", fastq_gen.CFG5_300)):
     if only and only != name:
         continue
     data = fastq_gen.generate(cfg, target_bytes=size)
