@@ -36,25 +36,34 @@ using TreeLds = TreeLdsT<MAX_NUM_HUF, BLOB_SLOT_512>;
 constexpr uint32_t SMALL_TREE = 64;
 using TreeLdsSmall = TreeLdsT<SMALL_TREE, 160>;
 
+// A tree is one wave's work, whatever else its workgroup holds: LDS traffic of a wave is processed in order, so a tree's
+// phases need the compiler's order and the wave's lanes together again, not a workgroup barrier.
+__device__ __forceinline__ void tree_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // keys[0..n) must be filled (by all lanes) before the call.  Leaves T.code/T.len/T.blob/T.blob_len.
 template <class Tree>
 __device__ void build_tree_wave(Tree &T, uint32_t n)
 {
     const int lane = threadIdx.x & 63;
-    __syncthreads();
+    tree_sync();
     for (uint32_t i = lane; i < n; i += 64) {
         uint64_t k = T.keys[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < n; ++j) rank += T.keys[j] < k;
         T.sorted[rank] = k;
     }
-    __syncthreads();
+    tree_sync();
     if (lane == 0) {
         uint32_t mx = 0;
         T.blob_len = huffman_sequential(T.sorted, n, T.ifreq, T.lc, T.rc, T.code, T.len, T.stack, T.blob, &mx);
         T.max_len = mx;
     }
-    __syncthreads();
+    tree_sync();
 }
 
 // (round 3) Trees of at most 64 symbols - every quality / base tree of an ordinary file - are built in REGISTERS: the sorted leaves,
@@ -74,7 +83,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     const uint32_t lane = threadIdx.x & 63;
     auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
     const uint32_t n = U(n_in);
-    __syncthreads();
+    tree_sync();
     // rank sort (as in build_tree_wave): lane r ends up with the r-th smallest (frequency, symbol) key
     for (uint32_t i = lane; i < n; i += 64) {
         const uint64_t k = T.keys[i];
@@ -82,7 +91,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
         for (uint32_t j = 0; j < n; ++j) rank += T.keys[j] < k;
         T.sorted[rank] = k;
     }
-    __syncthreads();
+    tree_sync();
     const uint64_t key = lane < n ? T.sorted[lane] : ~0ull;
     const uint32_t vf = (uint32_t)(key >> 32), vs = (uint32_t)(key & 0xffffu);
     // compact: zero frequencies go while more than two symbols remain (huffman.cpp:44-50); sorted, so they are the first lanes
@@ -162,7 +171,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     }
     if (nacc) { if (lane == 0) blob[pos] = (uint8_t)(acc << (8 - nacc)); ++pos; }
     if (lane == 0) { T.blob_len = pos; T.max_len = U(mx); }
-    __syncthreads();
+    tree_sync();
 }
 
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
@@ -170,7 +179,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
 template <bool SMALL, class Tree>
 __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t, bool regs)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const SbState &sb = A.sb[s];
     const bool fits_small = sb.nqual <= SMALL_TREE && sb.nsym <= SMALL_TREE;
     if (t <= A.qrows && fits_small != SMALL) return;
@@ -225,16 +234,23 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
 // small grid: its 26 KB of LDS per (single-wave) workgroup must be free on a CU before a workgroup can even find out that
 // its sub-block's alphabets fit the small instance and it has nothing to do - 4560 such workgroups queued behind the title
 // statistics kernel's LDS for 260 us of the staggered schedule, and the measure kernel behind them (round 3).
+// (round 3) The small instance: FOUR trees per workgroup, a wave each.  One single-wave workgroup per tree was bound by the rate at
+// which workgroups are dispatched - 10 000 to 37 000 of them per launch left the SIMDs with less than one resident wave on
+// average (SQ_WAVE_CYCLES / kernel time, profiles/r03_pmc_final_cfg2_a.json), and behind 150- and 300-base statistics nothing
+// runs beside this kernel.
+constexpr uint32_t SMALL_TREES_PER_WG = 4;
 template <bool SMALL>
-__global__ __launch_bounds__(64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t regs)
+__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t regs)
 {
     if (*A.err) return;
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
-    __shared__ Tree T;
+    constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
+    __shared__ Tree Ts[TPW];
+    Tree &T = Ts[threadIdx.x >> 6];
     const uint32_t pairs = nt * A.n_sb;
-    for (uint32_t p = blockIdx.x; p < pairs; p += gridDim.x) {
+    for (uint32_t p = blockIdx.x * TPW + (threadIdx.x >> 6); p < pairs; p += gridDim.x * TPW) {
         huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt, regs != 0);
-        __syncthreads();   // (T is used again)
+        tree_sync();   // (T is used again)
     }
 }
 
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A)
         uint8_t *bd = A.tblob + tix * BLOB_SLOT_256;
         for (uint32_t k = lane; k < T.blob_len; k += 64) bd[k] = T.blob[k];
         if (lane == 0) A.tblob_len[tix] = T.blob_len;
-        __syncthreads();
+        tree_sync();
     }
 }
 
@@ -272,7 +288,7 @@ static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uin
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
     const uint32_t regs = getenv("NGSC_HUFF_LDS") ? 0u : 1u;   // (NGSC_HUFF_LDS=1: round 2's LDS form of the small instance)
-    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3(pairs), dim3(64), 0, st, A, t0, nt, regs);
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt, regs);
     else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt, 0u);
 }
 

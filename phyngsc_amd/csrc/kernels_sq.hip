@@ -793,8 +793,10 @@ __device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const S
     for (uint32_t k = threadIdx.x; k < have * nq; k += SR_THREADS) {
         const uint32_t row = k / nq, ci = k % nq;
         const uint32_t qv = sb.qualities[ci];
-        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : qv - 33u;   // (208..215: a transferred N)
-        if (col < SR_HCOLS || (col >= SQ_NCOL0 && col < SQ_QS)) {
+        // (208..215: a transferred N.  The raw bytes 82..89, which would land on those columns, have none: the measure kernel
+        // reads the N columns whatever else the alphabet holds)
+        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : (qv - 33u < SR_HCOLS ? qv - 33u : ~0u);
+        if (col < SQ_QS) {
             const uint32_t e = qg[(size_t)(row_lo + row) * 256 + ci];
             s_qtab[row * SQ_QS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
         }
@@ -843,8 +845,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_format_qtab(Arena A)
     __syncthreads();
     if (threadIdx.x < sb.nqual) {
         const uint32_t qv = sb.qualities[threadIdx.x];
-        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : qv - 33u;   // (as sq_fill_qtab)
-        if (col < SR_HCOLS || (col >= SQ_NCOL0 && col < SQ_QS)) s_inv[col] = (uint16_t)(threadIdx.x + 1);
+        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : (qv - 33u < SR_HCOLS ? qv - 33u : ~0u);   // (as sq_fill_qtab)
+        if (col < SQ_QS) s_inv[col] = (uint16_t)(threadIdx.x + 1);
     }
     __syncthreads();
     const uint32_t words = (A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
@@ -1488,7 +1490,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 // Records per workgroup: enough to amortise the table fill / histogram flush (1024), but never so many that the job
 // has fewer than ~8 workgroups per CU - long reads mean few records per byte, and a 1024-record workgroup of
 // 150-bp reads left the 256 CUs with four workgroups each.  (NGSC_SQ_RECORDS_PER_WG overrides.)
-static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024, const char *own_env = nullptr)
+static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024, const char *own_env = nullptr, uint32_t min_wgs = 2048)
 {
     // (developer knobs: NGSC_SQ_RECORDS_PER_WG for the three kernels together, NGSC_SQ_RPW_STATS / _MEASURE / _PACK for one)
     const char *e = own_env && getenv(own_env) ? getenv(own_env) : getenv("NGSC_SQ_RECORDS_PER_WG");
@@ -1498,7 +1500,7 @@ static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t mos
     // (most: measure and pack, which fill a code table per workgroup, gain another 3-6 % from 2048 / 4096 records per
     // workgroup on jobs large enough to keep 2048 workgroups: 0.388 -> 0.365 ms and 0.154 -> 0.143 ms on the 1 GB job)
     uint32_t rpw = most;
-    while (rpw > SR_THREADS && records / rpw < 2048) rpw /= 2;
+    while (rpw > SR_THREADS && records / rpw < min_wgs) rpw /= 2;
     return rpw;
 }
 
@@ -1528,7 +1530,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
     if (rows > max_rows) rows = max_rows;
-    const uint32_t rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS");
+    uint32_t rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS");
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
     uint32_t span_cap = 0;
     const bool staged = sr_staged(A, max_rec_bytes, span_cap);
@@ -1561,6 +1563,14 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
             hipLaunchKernelGGL(mk, mgrid, dim3(SR_THREADS), mlds, st, A, A.qrows, mrpw, mcap);
             return;
         }
+    }
+    // A histogram of 40 KB and more (reads beyond 200 bases) leaves room for two or three workgroups per CU, and every workgroup
+    // clears and flushes all of it: one and a half rounds of resident workgroups are enough then (36..300-base reads, 400 MB:
+    // 256 / 512 / 1024 / 2048 records per workgroup 0.620 / 0.566 / 0.537 / 0.635 ms - the rule above chose 256)
+    if (!staged && lds >= (40u << 10)) {
+        const uint32_t resident = 256u * (uint32_t)((160u << 10) / lds);
+        rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS", resident + resident / 2);
+        grid = dim3((max_rec + rpw - 1) / rpw, A.n_sb);
     }
     // 512 threads per workgroup for the staged form: eight spans beside one histogram, 80 KB, two workgroups = four waves per SIMD
     // instead of three (44 KB x 3): +1 % on the step (496-500 against 482-492 GB/s).  NGSC_SQ_STATS_512=0: 256 threads
