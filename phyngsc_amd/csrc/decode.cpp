@@ -344,6 +344,16 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     for (uint32_t w = 0; w < F.PS; ++w) if (s_at[w + 1] < s_at[w]) { close(fd); return NGSC_ERR_FORMAT; }
     const int ofd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (ofd < 0) { close(fd); return NGSC_ERR_IO; }
+    // the file's size is known: its pages are reserved up front (as the compress driver does: preallocated page-cache pages take
+    // writes 1.5x faster on the GPU box's file system, profiles/r03_ubench_write.txt).  NGSC_FALLOCATE=0: off
+    // (a file system that has no room says so here and not after the whole file has been decoded; one without fallocate - EOPNOTSUPP -
+    // is written as before)
+    if (!(getenv("NGSC_FALLOCATE") && !strcmp(getenv("NGSC_FALLOCATE"), "0")) && ::fallocate(ofd, 0, 0, (off_t)F.FS) != 0 && errno == ENOSPC) {
+        fprintf(stderr, "[ngsc -d] no room for %llu bytes of output in %s\n", (unsigned long long)F.FS, out_path);
+        close(fd);
+        close(ofd);
+        return NGSC_ERR_IO;
+    }
     // batches: at most 512 sub-blocks (two decoder waves per CU) or 2 GiB of compressed bytes
     std::vector<const SubIn *> order;
     for (uint32_t w = 0; w < F.PS; ++w) for (const SubIn &x : subs[w]) order.push_back(&x);
@@ -355,7 +365,9 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     uint64_t max_in = 0;
     uint32_t max_nb = 0;
     {
-        const uint32_t per = getenv("NGSC_DEC_BATCH") ? (uint32_t)std::max(1, atoi(getenv("NGSC_DEC_BATCH"))) : 256u;   // (tests: small batches; 256: pinning the buffers of 512 took longer than the larger batches saved)
+        const uint32_t per = getenv("NGSC_DEC_BATCH") ? (uint32_t)std::max(1, atoi(getenv("NGSC_DEC_BATCH"))) : 128u;   // (tests: small batches.  10 GB of 36-base reads, 64 / 96 / 128 / 192 / 256 sub-blocks per batch:
+                                                                                                                             //  2.16 / 1.85 / 1.90 / 2.16 / 3.1 s; 150-base reads 4.33 / - / 4.39 / - / 4.74 s - the buffers of a batch are pinned
+                                                                                                                             //  and unpinned at ~6 GB/s, which larger batches' faster kernels do not win back; profiles/r03_decode_batch_sweep.txt)
         for (size_t b0 = 0; b0 < order.size();) {
             size_t b1 = b0; uint64_t bytes = 0;
             while (b1 < order.size() && b1 - b0 < per && bytes + order[b1]->bytes + 32 <= (2ull << 30)) { bytes += (order[b1]->bytes + 15u) & ~15ull; ++b1; }
@@ -376,8 +388,12 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     const uint32_t nbuf = batches.size() > 1 ? 2u : 1u;
     for (uint32_t k = 0; k < nbuf && !rc; ++k)
         if (hipHostMalloc((void **)&h_in[k], max_in, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_in[k], max_in) != hipSuccess ||
-            hipHostMalloc((void **)&h_text[k], cap_text, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&d_text[k], cap_text) != hipSuccess)
+            hipMalloc((void **)&d_text[k], cap_text) != hipSuccess)
             rc = NGSC_ERR_NOMEM;
+    // (the pinned text buffers - 2.5 GB each at 256 short-read sub-blocks, ~0.4 s of page pinning apiece - come from a thread of
+    // their own beside the first batches' read, upload and decode; inside the writer thread, which is the slowest stage, they
+    // cost the pipeline their full time: 3.0 -> 3.4 s on 10 GB)
+    const double t_setup = dsec() - t0;
     if (!rc && (hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s_dec, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking) != hipSuccess))
         rc = NGSC_ERR_HIP;
@@ -389,8 +405,20 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     int fail = NGSC_OK;
     const int dev = ngsc_ctx_device(c);
     auto set_fail = [&](int code) { std::lock_guard<std::mutex> lk(mu); if (!fail) fail = code; cv.notify_all(); };
-    std::thread reader, writer;
+    std::thread reader, downloader, writer, pinner;
+    size_t text_ready = 0;   // pinned text buffers allocated so far
+    size_t downloaded = 0, wrote = 0;
+    double t_down = 0;
     if (!rc) {
+        pinner = std::thread([&]() {
+            (void)hipSetDevice(dev);
+            for (uint32_t k = 0; k < nbuf; ++k) {
+                if (hipHostMalloc((void **)&h_text[k], cap_text, hipHostMallocDefault) != hipSuccess) { h_text[k] = nullptr; set_fail(NGSC_ERR_NOMEM); return; }
+                std::lock_guard<std::mutex> lk(mu);
+                ++text_ready;
+                cv.notify_all();
+            }
+        });
         reader = std::thread([&]() {
             (void)hipSetDevice(dev);
             const unsigned nt = std::max(1u, std::min(8u, getenv("NGSC_IO_THREADS") ? (unsigned)atoi(getenv("NGSC_IO_THREADS")) : 8u));
@@ -437,12 +465,35 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
                 cv.notify_all();
             }
         });
-        writer = std::thread([&]() {
+        // download and write are stages of their own: batch b + 1 comes down while batch b is being written (the writes are the
+        // slowest stage of a short-read file, and the download was a sixth of their thread's time)
+        downloader = std::thread([&]() {
             (void)hipSetDevice(dev);
+            for (size_t b = 0; b < batches.size(); ++b) {
+                {   // decoded, a pinned buffer exists, and the batch that used it last has been written
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return fail || (decoded > b && text_ready > b % nbuf && b < wrote + nbuf); });
+                    if (fail) return;
+                }
+                const double t = dsec();
+                const uint32_t nb = (uint32_t)(batches[b].b1 - batches[b].b0);
+                if (hipMemcpyAsync(h_text[b % nbuf], d_text[b % nbuf], meta[b].toff[nb], hipMemcpyDeviceToHost, s_down) != hipSuccess ||
+                    hipStreamSynchronize(s_down) != hipSuccess) {
+                    set_fail(NGSC_ERR_HIP);
+                    return;
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                t_down += dsec() - t;
+                ++drained;   // the decoder may fill this device buffer again
+                ++downloaded;
+                cv.notify_all();
+            }
+        });
+        writer = std::thread([&]() {
             for (size_t b = 0; b < batches.size(); ++b) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return fail || decoded > b; });
+                    cv.wait(lk, [&] { return fail || downloaded > b; });
                     if (fail) return;
                 }
                 const double t = dsec();
@@ -450,15 +501,6 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
                 const uint32_t nb = (uint32_t)(B.b1 - B.b0);
                 const Meta &M = meta[b];
                 uint8_t *src = h_text[b % nbuf];
-                if (hipMemcpyAsync(src, d_text[b % nbuf], M.toff[nb], hipMemcpyDeviceToHost, s_down) != hipSuccess || hipStreamSynchronize(s_down) != hipSuccess) {
-                    set_fail(NGSC_ERR_HIP);
-                    return;
-                }
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    ++drained;   // the decoder may fill this device buffer again (the pinned copy is this thread's own until its writes are done)
-                    cv.notify_all();
-                }
                 struct Run { uint64_t at, from, n; };
                 std::vector<Run> runs;
                 for (uint32_t k = 0; k < nb; ++k) {   // (consecutive sub-blocks of a rank are consecutive in the text: one write per run)
@@ -475,7 +517,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
                 std::vector<Run> parts;
                 for (const Run &r : runs)
                     for (uint64_t o = 0; o < r.n; o += 64ull << 20) parts.push_back({r.at + o, r.from + o, std::min<uint64_t>(64ull << 20, r.n - o)});
-                const unsigned nt = std::max(1u, std::min(8u, getenv("NGSC_IO_THREADS") ? (unsigned)atoi(getenv("NGSC_IO_THREADS")) : 8u));
+                const unsigned nt = std::max(1u, std::min(16u, getenv("NGSC_IO_THREADS") ? (unsigned)atoi(getenv("NGSC_IO_THREADS")) : 12u));   // (as container.cpp's io_threads())
                 std::vector<char> okv(nt, 1);
                 std::vector<std::thread> th;
                 for (unsigned w = 0; w < nt; ++w) {
@@ -490,6 +532,8 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
                 }
                 std::lock_guard<std::mutex> lk(mu);
                 t_write += dsec() - t;
+                ++wrote;
+                cv.notify_all();
             }
         });
         for (size_t b = 0; b < batches.size(); ++b) {
@@ -509,9 +553,12 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
             cv.notify_all();
         }
         reader.join();
+        downloader.join();
         writer.join();
+        pinner.join();
         rc = fail;
     }
+    const double t_pipe = dsec() - t0;
     if (s_up) (void)hipStreamDestroy(s_up);
     if (s_dec) (void)hipStreamDestroy(s_dec);
     if (s_down) (void)hipStreamDestroy(s_down);
@@ -526,10 +573,10 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     if (!rc && ftruncate(ofd, (off_t)F.FS) != 0) rc = NGSC_ERR_IO;
     close(fd);
     if (close(ofd) != 0 && !rc) rc = NGSC_ERR_IO;
-    if (seconds_out) { seconds_out[0] = t_read; seconds_out[1] = t_dev; seconds_out[2] = t_write; }
+    if (seconds_out) { seconds_out[0] = t_read; seconds_out[1] = t_dev; seconds_out[2] = t_down + t_write; }
     if (getenv("NGSC_VERBOSE"))
-        fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks in %zu batches: read + upload %.3f s, decode %.3f s, download + write %.3f s "
-                        "(overlapped), total %.3f s\n", F.PS, F.BS, order.size(), batches.size(), t_read, t_dev, t_write, dsec() - t0);
+        fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks in %zu batches: read + upload %.3f s, decode %.3f s, download %.3f s, write %.3f s "
+                        "(overlapped), buffers and streams %.3f s, pipeline done at %.3f s, total %.3f s\n", F.PS, F.BS, order.size(), batches.size(), t_read, t_dev, t_down, t_write, t_setup, t_pipe, dsec() - t0);
     return rc;
 }
 

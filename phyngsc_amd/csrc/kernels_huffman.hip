@@ -33,7 +33,6 @@ struct TreeLdsT {
     uint32_t max_len;
 };
 using TreeLds = TreeLdsT<MAX_NUM_HUF, BLOB_SLOT_512>;
-constexpr uint32_t SMALL_TREE = 64;
 using TreeLdsSmall = TreeLdsT<SMALL_TREE, 160>;
 
 // A tree is one wave's work, whatever else its workgroup holds: LDS traffic of a wave is processed in order, so a tree's
@@ -243,6 +242,9 @@ template <bool SMALL>
 __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t regs)
 {
     if (*A.err) return;
+    // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
+    // used to find that out pair by pair, 40-60 dependent loads each: 35-64 us behind the small instance on the same stream)
+    if (!SMALL && t0 + nt <= A.qrows + 1 && !*A.big_trees) return;
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
     __shared__ Tree Ts[TPW];

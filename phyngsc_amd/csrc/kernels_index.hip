@@ -63,12 +63,10 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
 // last quality line that has none (also an empty one, after "+\n"), as the reference does by working from positions
 // (phyNGSC.cpp:308-312); behind a complete file it opens a fifth line that no record owns and nothing reads.
 __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, uint32_t len, const uint32_t *start_ptr,
-                                                           uint32_t *tile_cnt, uint32_t *nl_mask, uint32_t at_file_end, uint32_t nt, uint32_t tpwg)
+                                                           uint32_t *tile_cnt, uint32_t *nl_mask, uint32_t at_file_end)
 {
     __shared__ uint32_t s_part[TILE_THREADS / 64];
     const uint32_t start = *start_ptr;
-    // tpwg consecutive tiles per workgroup (NGSC_NL_TPWG)
-    for (uint32_t tile = blockIdx.x * tpwg; tile < nt && tile < (blockIdx.x + 1) * tpwg; ++tile) {
     uint32_t c = 0;
     // Every load instruction of a wave covers one contiguous KB (16 bytes per lane), and a tile that lies inside [start, len)
     // - all but the job's first and last - takes a branch-free path with eight loads in flight per lane: behind the
@@ -77,7 +75,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
     // are half a mask word.
     uint16_t *mask16 = reinterpret_cast<uint16_t *>(nl_mask);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t tile0 = tile * TILE_BYTES;
+    const uint32_t tile0 = blockIdx.x * TILE_BYTES;
     if (tile0 >= start && tile0 + TILE_BYTES <= len && tile0 + TILE_BYTES > tile0) {
         // (round 3) A wave takes 16 contiguous KB of the tile, eight rows of 1 KB per trip.  Its 16-bit masks go through LDS, so that
         // a lane leaves with the masks of eight CONSECUTIVE chunks: one 16-byte store per lane and trip (1 KB per wave
@@ -121,9 +119,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
     c = wave_reduce_add(c);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[tile] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    __syncthreads();   // (s_part is written again)
-    }
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
 // Single workgroup exclusive scan of the tile counts (n up to ~64k: a job is < 4 GiB); total -> *total_out.
@@ -548,8 +544,7 @@ void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uin
                      bool at_file_end)
 {
     uint32_t nt = index_num_tiles(len);
-    static const uint32_t tpwg = getenv("NGSC_NL_TPWG") && atoi(getenv("NGSC_NL_TPWG")) > 0 ? (uint32_t)atoi(getenv("NGSC_NL_TPWG")) : 1u;
-    hipLaunchKernelGGL(k_nl_count, dim3((nt + tpwg - 1) / tpwg), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt, nl_mask, at_file_end ? 1u : 0u, nt, tpwg);
+    hipLaunchKernelGGL(k_nl_count, dim3(nt), dim3(TILE_THREADS), 0, st, buf, len, start_rel, tile_cnt, nl_mask, at_file_end ? 1u : 0u);
 }
 
 size_t index_mask_words(uint32_t len) { return (size_t)index_num_tiles(len) * (TILE_BYTES / BYTES_PER_THREAD); }

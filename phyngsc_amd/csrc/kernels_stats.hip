@@ -123,35 +123,28 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
 }
 
 // One workgroup of 256 threads per sub-block; thread = byte value.
-// 1024 threads: the column sums over the sub-block's rows in four parts of the rows, four loads in flight per thread (one
-// thread per column walked 300 rows of 36..300-base reads in 95 us, on the chain statistics -> trees -> measure with nothing
-// beside it); the first 256 threads do the rest.
-__global__ __launch_bounds__(1024) void k_sq_finalize(Arena A)
+// The column sums over the sub-block's rows with eight loads in flight per thread (one load at a time walked the 300 rows of
+// 36..300-base reads in 95 us, on the chain statistics -> trees -> measure with nothing beside it).  256 threads: a 1024-thread
+// form with the rows in four parts was faster alone and SLOWER in the step - beside the title statistics kernel a workgroup of
+// sixteen waves waited 200-300 us for a CU with room (kernel trace, profiles/r03_final_kernel_stats.csv history).
+__global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.x;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     SbState &sb = A.sb[s];
     __shared__ uint32_t s_cnt[2][4];
-    __shared__ uint32_t s_part[3][256];
     uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
     const uint32_t max_q = sb.max_q;
     uint32_t tot = 0;
     {
-        const uint32_t part = threadIdx.x >> 8;
-        uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, row = 1 + part;
-        for (; row + 12 <= max_q; row += 16) {
-            t0 += qh[(size_t)row * 256 + tid];
-            t1 += qh[(size_t)(row + 4) * 256 + tid];
-            t2 += qh[(size_t)(row + 8) * 256 + tid];
-            t3 += qh[(size_t)(row + 12) * 256 + tid];
+        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, row = 1;
+        for (; row + 7 <= max_q; row += 8) {
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) t[k] += qh[(size_t)(row + k) * 256 + tid];
         }
-        for (; row <= max_q; row += 4) t0 += qh[(size_t)row * 256 + tid];
-        tot = t0 + t1 + t2 + t3;
-        if (part) s_part[part - 1][tid] = tot;
-        __syncthreads();
-        if (part) return;   // (whole waves leave: the barrier below counts the remaining four)
-        tot += s_part[0][tid] + s_part[1][tid] + s_part[2][tid];
+        for (; row <= max_q; ++row) t[0] += qh[(size_t)row * 256 + tid];
+        tot = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     }
     qh[tid] = tot;  // row 0: position-independent histogram (quality_stats[0], tasks.cpp:283)
     const bool hasq = tot != 0;
@@ -185,6 +178,7 @@ __global__ __launch_bounds__(1024) void k_sq_finalize(Arena A)
         sb.flags = flags;
         sb.lt_bits = bit_length(max_q);
         if (!nqual || !nsym) atomicMin(A.err, (int32_t)ERR_FORMAT);
+        if (nqual > SMALL_TREE || nsym > SMALL_TREE) atomicOr(A.big_trees, 1u);
     }
 }
 
@@ -407,7 +401,7 @@ void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
 
 void launch_sq_finalize(hipStream_t st, const Arena &A)
 {
-    hipLaunchKernelGGL(k_sq_finalize, dim3(A.n_sb), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_sq_finalize, dim3(A.n_sb), dim3(256), 0, st, A);
 }
 
 void launch_field_finalize(hipStream_t st, const Arena &A)

@@ -29,6 +29,7 @@ constexpr uint32_t MAX_STAT_LEN = 128;      // MAX_FIELD_STAT_LEN, tasks.cpp:25
 constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
 
 // ---- engine limits (inputs beyond them get NGSC_ERR_UNSUPPORTED, never a wrong stream) ------------
+constexpr uint32_t SMALL_TREE = 64;         // symbols of a tree the small Huffman instance builds (kernels_huffman.hip)
 constexpr uint32_t MAX_FIELDS = 64;         // separators per title (one bit each in the field masks, fmask_t)
 typedef uint64_t fmask_t;                   // a bit per title field
 constexpr uint32_t MAX_TEXT_LEN0 = 512;     // record-0 length of a non-constant text field (Hamming mask bits): a whole first title (REC0_TITLE_CAP)
@@ -322,6 +323,9 @@ struct Arena {
     // dtail_b = 4 / 8 / 12 bytes per record instead of 16: chunk dtail_c of record g at dense_x + dtail_c * dstride * 16 + g * dtail_b
     // (a quarter of the copies' bytes at 36 bases).  dtail_c == 0xffffffff: every chunk is 16 bytes
     uint32_t dtail_c, dtail_b;
+    // (round 3) set by k_sq_finalize when some sub-block's quality or base alphabet exceeds SMALL_TREE symbols: the 512-symbol
+    // Huffman instance has quality / base trees to build (else its workgroups leave at once)
+    uint32_t *big_trees;
     // (round 3) the quality code table of every sub-block in the layout the pack kernel keeps in LDS (k_sq_format_qtab):
     // [qrows + 17][57] dwords, qfmt_stride dwords per sub-block
     uint32_t *qfmt;

@@ -45,15 +45,16 @@ for P in PS:
             ok_all = ok_all and same_io
             os.remove(outp + ".io")
     del want, got
+BACK = os.environ.get("BIG_BACK", "/tmp/big_back.fastq")   # (the GPU box's /tmp holds 79 GB: a 50 GB file is decoded to /dev/shm)
 if DECODE:
     del data
     t0 = time.time()
-    r = subprocess.run([exe, "-d", outp, "/tmp/big_back.fastq"], capture_output=True, text=True, env=dict(os.environ, NGSC_VERBOSE="1"))
+    r = subprocess.run([exe, "-d", outp, BACK], capture_output=True, text=True, env=dict(os.environ, NGSC_VERBOSE="1"))
     print(r.stdout.strip(), r.stderr.strip()[-600:], f"[ngsc -d wall {time.time()-t0:.1f} s, rc {r.returncode}]", flush=True)
-    same = r.returncode == 0 and subprocess.run(["cmp", "-s", inp, "/tmp/big_back.fastq"]).returncode == 0
+    same = r.returncode == 0 and subprocess.run(["cmp", "-s", inp, BACK]).returncode == 0
     print("decoded file: " + ("IDENTICAL to the input" if same else "DIFFERENT"), flush=True)
     ok_all = ok_all and same
-    if os.path.exists("/tmp/big_back.fastq"):
-        os.remove("/tmp/big_back.fastq")
+    if os.path.exists(BACK):
+        os.remove(BACK)
 os.remove(inp); os.remove(outp)
 sys.exit(0 if ok_all else 1)
