@@ -1017,7 +1017,11 @@ __device__ __forceinline__ uint32_t qs_record_len(const uint32_t *p32, uint32_t 
     d += 2;
     const uint32_t ksh = 32 - T.K;
     for (uint32_t j = 0; j < L; ++j) {
-        uint32_t len = T.len[((j + 1) << T.K) + (hi >> ksh)];
+        // an entry: the code's length in its low four bits and - where the NEXT position's code also lies inside the K bits - that
+        // one's length in the high four: two symbols per dependent lookup (the lookups, not the arithmetic, are this loop's time)
+        const uint32_t ent = T.len[((j + 1) << T.K) + (hi >> ksh)];
+        uint32_t len = ent & 15u;
+        if (ent >> 4) { len += ent >> 4; ++j; }
         if (!len) {   // a code longer than K bits (or a one-symbol tree, whose codes have no bits): walk the tree
             uint64_t w = ((uint64_t)hi << 32) | lo;
             uint32_t hv = have, dd = d;
@@ -1078,14 +1082,23 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, 
     {
         const uint32_t total = rows << Kl, shq = Kq - Kl;
         const uint16_t *qtab = C.qtab;
+        const bool pairs = !(with_trees & 2u);   // (bit 1 of with_trees: NGSC_DEC_PAIRS=0, single lookups)
         for (uint32_t k = threadIdx.x; k < total; k += QS_THREADS) {
             const uint32_t row = k >> Kl, x = k & ((1u << Kl) - 1u);
-            const uint32_t ln = qtab[((size_t)row << Kq) + (x << shq)] >> 12;
-            s_len[k] = ln <= Kl ? (uint8_t)ln : (uint8_t)0;
+            uint32_t ln = qtab[((size_t)row << Kq) + (x << shq)] >> 12;
+            if (ln > Kl) ln = 0;
+            uint32_t ln2 = 0;
+            if (pairs && ln && ln < Kl && row >= 1 && row + 1 < rows) {   // (row 0 is the position-independent tree: no record position)
+                // the bits behind the first code, zero-padded: the next position's length is what the table says iff it fits them
+                const uint32_t x2 = (x << ln) & ((1u << Kl) - 1u);
+                ln2 = qtab[((size_t)(row + 1) << Kq) + (x2 << shq)] >> 12;
+                if (ln2 > Kl - ln) ln2 = 0;
+            }
+            s_len[k] = (uint8_t)(ln | (ln2 << 4));
         }
     }
     QsLenTabs T = {s_len, nullptr, nullptr, nullptr, Kl, nq};
-    if (with_trees && nq >= 2 && nq <= 128) {
+    if ((with_trees & 1u) && nq >= 2 && nq <= 128) {
         uint8_t *lc = s_len + (((size_t)rows << Kl) + 15 & ~(size_t)15), *rc = lc + (size_t)rows * nq, *root = rc + (size_t)rows * nq;
         for (uint32_t k = threadIdx.x; k < rows * nq; k += QS_THREADS) {
             const uint32_t row = k / nq, i = k % nq;
@@ -1612,10 +1625,11 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
         if (((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes > (120u << 10)) tree_bytes = 0;   // (long reads: no room for the trees)
         const size_t lds_a = ((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes;
+        const bool pairs_off = getenv("NGSC_DEC_PAIRS") && !strcmp(getenv("NGSC_DEC_PAIRS"), "0");   // (per call: the tests switch it)
         const uint32_t phase_tiles[4] = {max_tiles, 16, 256, max_tiles};
         for (int ph = 0; ph < 4; ++ph) {
             hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), lds_a, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
-                               hop, hop_off, lds_a_entries, tree_bytes ? 1u : 0u);
+                               hop, hop_off, lds_a_entries, (tree_bytes ? 1u : 0u) | (pairs_off ? 2u : 0u));
             if (ph == 0) dec_lap(st, t0, "k_dec_qspec_a");
             hipLaunchKernelGGL(k_dec_qspec_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off, scratch, stride, rec_cap, tcap,
                                ph < 3 ? phase_tiles[ph + 1] : 0u);

@@ -64,7 +64,7 @@ def main():
             dtmp = tempfile.mkdtemp(prefix="ngsc_fuzz_drv_")
     t_end = time.time() + a.seconds
     seed = a.first_seed
-    n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = 0
+    n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = n_lossy = 0
     total = 0
     last = time.time()
     while time.time() < t_end and seed < a.first_seed + a.seeds:
@@ -166,8 +166,15 @@ def main():
             try:
                 eng.decompress_file(ng, back)
                 with open(back, "rb") as f:
-                    if f.read() != data:
-                        verdict = "GPU decoder: decoded file differs from the input"
+                    got = f.read()
+                if got != data:
+                    # The format itself loses a title whose numeric field exceeds 32 bits (the value is stored modulo 2^32:
+                    # seed 902976, "...=9999999999" comes back as "...=1410065407" from every decoder): what the container
+                    # holds is what the oracle's decoder makes of it.
+                    if got == orc.decompress(ref):
+                        n_lossy += 1
+                    else:
+                        verdict = "GPU decoder: decoded file differs from the input and from the oracle decoder's output"
             except api.NgscError as e:
                 if e.code != -4:
                     verdict = f"GPU decoder rc {e.code}"
@@ -185,7 +192,8 @@ def main():
                   flush=True)
         seed += 1
     print(f"fuzz: seeds {a.first_seed}..{seed - 1}: {n_ok} equal, {n_rej} rejected by both, {n_bad} mismatches, "
-          f"{n_skip} skipped, {n_crash} reference crashes, {n_limit} engine limits, {total / 1e6:.0f} MB of FASTQ", flush=True)
+          f"{n_skip} skipped, {n_crash} reference crashes, {n_limit} engine limits, {total / 1e6:.0f} MB of FASTQ"
+          + (f"; {n_lossy} containers that do not hold their input (GPU decoder = oracle decoder)" if n_lossy else ""), flush=True)
     if eng is not None:
         eng.close()
     sys.exit(1 if n_bad else 0)
