@@ -77,7 +77,12 @@ __device__ __forceinline__ uint32_t hw_rl(uint32_t v, uint32_t lane) { return (u
 // compiler has no v_writelane builtin and the instruction takes a single SGPR operand on gfx9)
 #define hw_wl(val, idx, old) ((lane == (uint32_t)(idx)) ? (uint32_t)(val) : (uint32_t)(old))
 
-__device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
+// (round 3, last step) The pre-order blob is written in PARALLEL as well: a node's bit offset in the pre-order string is the sum, over
+// the edges from the root down to it, of 1 (the parent's own bit) plus - on a right edge - the bits of the left sibling's
+// subtree; the merge loop keeps every internal node's subtree bits, the leaves add the sum up on the walk that already
+// gives them their codes, and each leaf ORs its "1 | id" field into a zeroed bit string (internal nodes are its 0 bits).
+// The serial form (serial_blob, NGSC_HUFF_BLOB_SERIAL=1) popped 2n - 1 nodes off a register stack one after the other.
+__device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in, bool serial_blob)
 {
     const uint32_t lane = threadIdx.x & 63;
     auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
@@ -101,6 +106,11 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     uint32_t vif = 0, vlc = 0, vrc = 0;           // per internal node k (lane k): frequency, children (node ids)
     uint32_t par_l = 0xffu, par_i = 0xffu;        // parent (creation index) of leaf `lane` (by SYMBOL) / of internal node `lane`; 0xff: none
     uint32_t right_l = 0, right_i = 0;            // ... and whether the node is its parent's right child
+    uint32_t bits_per_id = 0;
+    while ((2u << bits_per_id) <= n) ++bits_per_id;
+    if (n & (n - 1)) ++bits_per_id;
+    const uint32_t leafbits = 1 + bits_per_id;    // a leaf in the blob: a 1 and its id
+    uint32_t vsub = 0, vlsub = 0;                 // per internal node k (lane k): blob bits of its subtree / of its left child's
     uint32_t lq = drop, iq = 0, made = 0;
     for (uint32_t k = 0; k + 1 < present; ++k) {
         uint32_t f2[2], id2[2];
@@ -114,6 +124,11 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
         vif = hw_wl(f2[0] + f2[1], made, vif);
         vlc = hw_wl(id2[0], made, vlc);
         vrc = hw_wl(id2[1], made, vrc);
+        {
+            const uint32_t sb0 = id2[0] < n ? leafbits : hw_rl(vsub, id2[0] - n), sb1 = id2[1] < n ? leafbits : hw_rl(vsub, id2[1] - n);
+            vsub = hw_wl(1 + sb0 + sb1, made, vsub);
+            vlsub = hw_wl(sb0, made, vlsub);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (id2[t] < n) { par_l = hw_wl(made, id2[t], par_l); right_l = hw_wl((uint32_t)t, id2[t], right_l); }
@@ -123,12 +138,13 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     }
     const uint32_t root = n + present - 2;        // (node id; for a single symbol: leaf 0)
     // ---- code of every leaf: up its parent chain (huffman.cpp:73-79 gives a child its parent's code << 1 | right) ----
-    uint32_t code = 0, len = 0;
+    uint32_t code = 0, len = 0, off = 0;          // (off: the leaf's bit offset in the pre-order string)
     {
         uint32_t p = lane < n ? par_l : 0xffu, bit = right_l;
         while (__any(p != 0xffu)) {
             const uint32_t np = (uint32_t)__shfl((int)par_i, (int)(p & 63u)), nb = (uint32_t)__shfl((int)right_i, (int)(p & 63u));
-            if (p != 0xffu) { code |= bit << len; ++len; p = np; bit = nb; }
+            const uint32_t ls = (uint32_t)__shfl((int)vlsub, (int)(p & 63u));
+            if (p != 0xffu) { code |= bit << len; ++len; off += 1u + (bit ? ls : 0u); p = np; bit = nb; }
         }
     }
     uint32_t mx = len, mn = (lane < n && len > 0) ? len : 0xffffffffu;
@@ -140,9 +156,6 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     }
     if (lane < n) { T.code[lane] = code; T.len[lane] = (uint8_t)len; }
     // ---- blob (huffman.cpp:88-118): root id, symbol count, shortest code, the tree in pre-order ----
-    uint32_t bits_per_id = 0;
-    while ((2u << bits_per_id) <= n) ++bits_per_id;
-    if (n & (n - 1)) ++bits_per_id;
     const uint32_t min_len = mn == 0xffffffffu ? n : U(mn);
     uint8_t *blob = T.blob;
     if (lane == 0) {
@@ -151,6 +164,22 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
         blob[8] = (uint8_t)min_len;
     }
     uint32_t pos = 9, nacc = 0;
+    if (!serial_blob && present >= 2) {
+        uint32_t *words = T.ifreq;                // (not used by this form otherwise) 64 words = 2048 bits; a tree of 64 symbols has 511
+        words[lane] = 0;
+        tree_sync();
+        if (lane < n && len > 0) {                // a leaf of the tree (a dropped symbol has no parent)
+            const uint64_t val = (uint64_t)((1u << bits_per_id) | lane) << (64u - (off & 31u) - leafbits);   // (big-endian bit order)
+            atomicOr(&words[off >> 5], (uint32_t)(val >> 32));
+            if ((uint32_t)val) atomicOr(&words[(off >> 5) + 1], (uint32_t)val);
+        }
+        tree_sync();
+        const uint32_t nbytes = (hw_rl(vsub, present - 2) + 7u) >> 3;   // (the root: the last internal node made)
+        for (uint32_t k = lane; k < nbytes; k += 64) blob[9 + k] = (uint8_t)(words[k >> 2] >> (24u - 8u * (k & 3u)));
+        if (lane == 0) { T.blob_len = 9 + nbytes; T.max_len = U(mx); }
+        tree_sync();
+        return;
+    }
     uint64_t acc = 0;
     uint32_t vstack = 0, sp = 0;                  // the stack: lane i holds entry i (at most n entries are pending at a time)
     vstack = hw_wl(root, 0, vstack); sp = 1;
@@ -176,7 +205,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
 template <bool SMALL, class Tree>
-__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t, bool regs)
+__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t, uint32_t regs)
 {
     const int lane = threadIdx.x & 63;
     const SbState &sb = A.sb[s];
@@ -188,7 +217,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nqual;
         const uint32_t *row = A.qhist + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)row[sb.qualities[j]] << 32) | j;
-        if constexpr (SMALL) { if (regs) build_tree_regs(T, n); else build_tree_wave(T, n); } else build_tree_wave(T, n);
+        if constexpr (SMALL) { if (regs & 1u) build_tree_regs(T, n, (regs & 2u) != 0); else build_tree_wave(T, n); } else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.qcodes + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[j] = (T.code[j] << 5) | T.len[j];
@@ -201,7 +230,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nsym;
         const uint32_t *occ = A.dna_occ + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)occ[sb.symbols[j]] << 32) | j;
-        if constexpr (SMALL) { if (regs) build_tree_regs(T, n); else build_tree_wave(T, n); } else build_tree_wave(T, n);
+        if constexpr (SMALL) { if (regs & 1u) build_tree_regs(T, n, (regs & 2u) != 0); else build_tree_wave(T, n); } else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.dcodes + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[sb.symbols[j]] = (T.code[j] << 5) | T.len[j];
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffma
     Tree &T = Ts[threadIdx.x >> 6];
     const uint32_t pairs = nt * A.n_sb;
     for (uint32_t p = blockIdx.x * TPW + (threadIdx.x >> 6); p < pairs; p += gridDim.x * TPW) {
-        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt, regs != 0);
+        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt, regs);
         tree_sync();   // (T is used again)
     }
 }
@@ -289,7 +318,8 @@ static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uin
 {
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
-    const uint32_t regs = getenv("NGSC_HUFF_LDS") ? 0u : 1u;   // (NGSC_HUFF_LDS=1: round 2's LDS form of the small instance)
+    // (NGSC_HUFF_LDS=1: round 2's LDS form of the small instance; NGSC_HUFF_BLOB_SERIAL=1: the register form with its serial blob loop)
+    const uint32_t regs = getenv("NGSC_HUFF_LDS") ? 0u : (getenv("NGSC_HUFF_BLOB_SERIAL") ? 3u : 1u);
     if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt, regs);
     else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt, 0u);
 }

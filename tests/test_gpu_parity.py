@@ -156,7 +156,7 @@ def test_kernel_paths_agree(eng, monkeypatch, sq_path):
 ROUND3_SWITCHES = [("NGSC_TS_QUAD", "0"), ("NGSC_TS_FULL_LDS", "1"), ("NGSC_SQ_STATS_512", "0"), ("NGSC_SQ_NO_TAIL", "1"),
                    ("NGSC_NO_EARLY_ZERO", "1"), ("NGSC_CV_VEC", "1"), ("NGSC_CV_NOCACHE", "1"), ("NGSC_CV_SPLIT", "1"),
                    ("NGSC_SQ_MULTI", "0"), ("NGSC_SQ_MULTI", "2"), ("NGSC_SQ_MULTI", "8"), ("NGSC_OVERLAP", "0"), ("NGSC_OVERLAP", "3"),
-                   ("NGSC_SQ_QFMT", "0"), ("NGSC_HUFF_LDS", "1"), ("NGSC_SQ_RPW_STATS", "256"), ("NGSC_SQ_RPW_PACK", "512")]
+                   ("NGSC_SQ_QFMT", "0"), ("NGSC_HUFF_LDS", "1"), ("NGSC_HUFF_BLOB_SERIAL", "1"), ("NGSC_SQ_RPW_STATS", "256"), ("NGSC_SQ_RPW_PACK", "512")]
 
 
 @pytest.mark.parametrize("switch", ROUND3_SWITCHES, ids=[f"{k}={v}" for k, v in ROUND3_SWITCHES])
@@ -164,7 +164,7 @@ def test_round3_switches_agree(eng, monkeypatch, switch):
     """Every alternative form round 3 left behind a switch - a lane's own title loads instead of the quad-cooperative ones, round 2's
     LDS footprint of the title statistics, 256-thread staged statistics, 16-byte last chunks in the copies, no early clearing,
     the validation pass with 16-byte loads / on its own stream, the planner without its LDS cache, the statistics kernels for long
-    reads with 1 / 2 / 8 lanes per record, the serial and the early-fork schedules, the pack kernel gathering its code table itself, small Huffman trees built in LDS, other workgroup sizes of the statistics and
+    reads with 1 / 2 / 8 lanes per record, the serial and the early-fork schedules, the pack kernel gathering its code table itself, small Huffman trees built in LDS / with their blobs written serially, other workgroup sizes of the statistics and
     pack kernels - reproduces the reference on committed goldens
     and the oracle on generated 36-base, 150-base and mixed-length inputs (two calls each: the second one runs on the first one's
     arena and output hints)."""
