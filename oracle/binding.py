@@ -81,6 +81,8 @@ def lib():
         L.ngsc_o_decode_subblock.argtypes = [u8p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
                                              ctypes.POINTER(ctypes.c_uint32)]
+        L.ngsc_o_lossy_count.restype = ctypes.c_uint64
+        L.ngsc_o_lossy_count.argtypes = [ctypes.c_int]
         _lib = L
     return _lib
 
@@ -91,16 +93,24 @@ def _as_u8(data) -> np.ndarray:
     return np.ascontiguousarray(data, dtype=np.uint8)
 
 
-def compress_file(data, P: int, threads: int = 1):
-    """Returns (ngsc bytes, FileStats)."""
+def compress_file(data, P: int, threads: int = 1, as_reference: bool = False):
+    """Returns (ngsc bytes, FileStats).
+
+    A varying numeric title field whose digits exceed 32 bits is stored modulo 2^32 by the reference (utils.h:117-125): its
+    container does not hold its input.  The HIP engine refuses such input (NGSC_ERR_RANGE), and so does this function
+    (OracleError(-5)) unless ``as_reference`` asks for the reference's own container."""
     a = _as_u8(data)
     out = ctypes.c_void_p()
     n = ctypes.c_uint64()
     st = FileStats()
+    lib().ngsc_o_lossy_count(1)
     rc = lib().ngsc_o_compress_file(a.ctypes.data, a.size, P, threads, ctypes.byref(out), ctypes.byref(n),
                                     ctypes.byref(st))
     if rc:
         raise OracleError(rc)
+    if lib().ngsc_o_lossy_count(1) and not as_reference:
+        _libc.free(out)
+        raise OracleError(-5)
     if n.value < (1 << 31):
         res = ctypes.string_at(out.value, n.value)
     else:   # (string_at takes a C int) multi-GB outputs come back as a numpy array

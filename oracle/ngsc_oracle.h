@@ -104,6 +104,13 @@ int ngsc_o_compress_file(const uint8_t *fastq, uint64_t size, uint32_t P, int th
                          uint64_t *out_len, ngsc_o_filestats *stats);
 
 /*
+ * Diagnostic: varying numeric title values met since the last reset whose digits exceed 32 bits while the wrapped value stays
+ * below 2^31 - the reference (and this restatement) store them modulo 2^32, so the container does not hold its input
+ * (utils.h:117-125).  The HIP engine refuses such input with NGSC_ERR_RANGE; the tests use this count to expect exactly that.
+ */
+uint64_t ngsc_o_lossy_count(int reset);
+
+/*
  * Decoder (ngsc_decode.c), the round-trip leg of the tests: one sub-block's info|title|quality|DNA
  * bytes -> the FASTQ text of its records.  *fastq is malloc()ed; consumed = bytes of sb read (equals
  * the sub-block's SBOL length).  The reference has no decompressor; its unused Fetch* fragments

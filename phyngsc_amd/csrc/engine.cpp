@@ -39,11 +39,28 @@ struct KTime {
 
 }  // namespace
 
+// What the host has to know about a job before it can size the per-record arrays and choose kernels: the planner's counts and
+// the job-wide maxima of the validation pass.  A first call reads them back behind the index kernels (one host sync in the
+// middle of the step).  Later calls of the same shape PREDICT them from the call before - jobs of one file look alike, the bench
+// repeats one job - enqueue the whole step at once, and let k_init_sb compare the prediction with what the index kernels found:
+// on a miss every kernel behind it leaves at once (the error word), and the step runs again the synchronous way.
+struct JobShape {
+    uint32_t valid = 0;
+    // the calls it applies to
+    uint64_t file_size = 0;
+    uint32_t P = 0, n_ranks = 0, part = 0;
+    uint64_t buf_len = 0;
+    // counts (capacities when predicted: the actual numbers may be smaller) ...
+    uint32_t n_rec_total = 0, S = 0, max_rec = 0;
+    uint64_t slots = 0, groups = 0, tiles = 0;
+    // ... and maxima (a predicted maximum must not be exceeded)
+    uint32_t max_title = 0, max_q = 0, max_rec_bytes = 0;
+};
+
 struct ngsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t side_stream = nullptr;          // title kernels run here, beside the sequence/quality kernels
-    hipStream_t aux_stream = nullptr;           // the record validation pass, beside the cut planner and the early clearing
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
     size_t zero_hint = 0;         // bytes of the zero-initialised arena the last call used: cleared while the host waits for the cut list
     uint64_t out_hint = 0;        // output bytes of the last call: that much of the output buffer is cleared beside the index kernels
@@ -55,6 +72,8 @@ struct ngsc_ctx {
     bool cs_retry = false;        // the job is run again on a copy in which colour-space reads are decoded
     uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
+    bool no_spec = getenv("NGSC_NO_SPEC") != nullptr;   // every call reads the job's shape back (the step's first-call form)
+    JobShape shape;               // the last job's counts and maxima: the next call's prediction
     bool big_alphabets = false;   // the last call met a quality / base alphabet of more than 64 symbols (grid of the 512-symbol Huffman instance)
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
@@ -204,14 +223,12 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out)
     c->device = device_id;
     // The side stream carries the latency-bound kernels of the staggered schedule (sub-block finalisation, Huffman waves, headers)
     // beside a throughput kernel on the main stream: with a higher priority its few workgroups are dispatched as soon as a
-    // slot frees up instead of taking turns with tens of thousands of queued ones (NGSC_SIDE_PRIO=0: same priority)
+    // slot frees up instead of taking turns with tens of thousands of queued ones
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const char *pe = getenv("NGSC_SIDE_PRIO");
-    const int side_prio = (pe && !strcmp(pe, "0")) ? prio_lo : prio_hi;
+    const int side_prio = prio_hi;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
         hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, side_prio) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess) {
@@ -234,7 +251,6 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
@@ -335,6 +351,14 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint8_t *buf = (const uint8_t *)d_buf;
     const uint32_t len = (uint32_t)buf_len;
 
+    // Is there a prediction for this call?  (Not while every kernel is being timed, not for the second run of a job - colour
+    // space, text slots, a missed prediction - and not for a rank walked in parts, whose window count follows the buffer.)
+    const bool time_all = c->profiling && c->profile_only.empty();
+    const JobShape &last = c->shape;
+    const bool spec = last.valid && !c->no_spec && !c->cs_retry && !c->slot_retry && !part && !c->debug_sync &&
+                      last.file_size == file_size && last.P == P && last.n_ranks == n_ranks && last.part == 0 &&
+                      buf_len <= last.buf_len + last.buf_len / 64 && last.buf_len <= buf_len + buf_len / 64;
+
     // ---- small device state ----
     const uint64_t region = file_size / P;
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
@@ -365,9 +389,6 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (rc) return rc;
     uint32_t *d_tiles = (uint32_t *)c->tiles.p;
     uint32_t *d_nlmask = (uint32_t *)((uint8_t *)c->tiles.p + ((4 * (size_t)ntiles + 63) & ~(size_t)63));
-    rc = ensure_pinned(c, cs.off);
-    if (rc) return rc;
-    uint8_t *hp = (uint8_t *)c->h_pin;
     const size_t rec_bound = (size_t)len / 5 + 2;   // a record is four newlines and a '+' at the very least
     Carver cr;
     size_t o_te = cr.take(4 * rec_bound), o_se = cr.take(4 * rec_bound), o_ls = cr.take(4 * (rec_bound + 1));
@@ -376,14 +397,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     uint8_t *rb = (uint8_t *)c->recs.p;
     uint32_t *d_te = (uint32_t *)(rb + o_te), *d_se = (uint32_t *)(rb + o_se), *d_ls = (uint32_t *)(rb + o_ls);
 
-    // (round 3) The output bytes of the step are cleared EARLY - while the host waits for the cut list and the GPU has nothing
-    // to do - as far as the previous call's output reached (jobs of one file are alike; the bench repeats one job);
-    // k_zero_output later clears only what lies beyond.
+    // The output bytes of the step are cleared EARLY - beside the index kernels' latency-bound tail - as far as the previous
+    // call's output reached (jobs of one file are alike; the bench repeats one job); k_zero_output later clears only what
+    // lies beyond.
     const char *ov_env = getenv("NGSC_OVERLAP");
-    const bool time_all = c->profiling && c->profile_only.empty();
+    const bool serial = (ov_env && !strcmp(ov_env, "0")) || time_all || c->debug_sync;
     uint64_t out_prefix = 0;
-    if (c->out_hint && !c->debug_sync && !getenv("NGSC_NO_EARLY_ZERO"))
-        out_prefix = std::min<uint64_t>(c->out_hint + (c->out_hint >> 6), out_cap) & ~15ull;
+    if (c->out_hint && !c->debug_sync) out_prefix = std::min<uint64_t>(c->out_hint + (c->out_hint >> 6), out_cap) & ~15ull;
 
     // ---- stage A: line index ----
     {
@@ -393,71 +413,69 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask, buf_off + buf_len == file_size); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
     { KScope k(c, st, "k_nl_write"); launch_nl_write(st, d_nlmask, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_bound); }
-    bool zero_on_side = false;
-    if (out_prefix) {
-        // beside the cut planner / validation kernel (latency-bound: a chain of searches and a light pass over the record table),
-        // on the side stream; in the sync gap behind it the clearing only made the gap longer, and at the step's start it took
-        // bandwidth from the newline count
-        if (c->debug_sync || (c->profiling && c->profile_only.empty())) {
-            KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix);
-        } else {
-            HIPCHK(c, hipEventRecord(c->ev_fork, st));
-            HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-            launch_zero_range(c->side_stream, d_out, out_prefix);
-            HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-            zero_on_side = true;
-        }
+    // beside the cut planner / validation kernel (latency-bound: a chain of searches and a light pass over the record table), on
+    // the side stream: the early clearing of the output and - when the step is enqueued in one go - of the call's zero arena
+    const bool zero_on_side = !serial;
+    void *const prezero_ptr = c->zero.p;
+    const size_t prezero = std::min(c->zero_hint, c->zero.cap);
+    if (zero_on_side) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        if (out_prefix) launch_zero_range(c->side_stream, d_out, out_prefix);
+        if (spec && prezero) launch_zero_range(c->side_stream, c->zero.p, prezero);
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
+    } else if (out_prefix) {
+        KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix);
     }
-    // (round 3) three things that do not depend on each other behind the record table: the cut planner's chain (this stream), the
-    // validation pass over the table (aux stream; as part of the planner's launch every workgroup carried the planner's 24 KB of
-    // LDS) and the early clearing of the output (side stream).  Measured: no gain (469 against 469 GB/s - the planner's chain
-    // and the validation pass already ran side by side inside one launch), so NGSC_CV_SPLIT=1 only keeps the experiment
-    const bool cv_split = zero_on_side && getenv("NGSC_CV_SPLIT") && !strcmp(getenv("NGSC_CV_SPLIT"), "1");
-    if (cv_split) HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));   // (ev_fork: recorded behind k_nl_write above)
     {
         KScope k(c, st, "k_cuts_validate");
         launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
                              max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr, from,
-                             part ? buf_off + buf_len : 0, cv_split ? c->aux_stream : nullptr);
+                             part ? buf_off + buf_len : 0);
     }
-    if (cv_split) {
-        HIPCHK(c, hipEventRecord(c->ev_zero, c->aux_stream));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));
+    if (zero_on_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+
+    // ---- the job's shape: read back (one sync) or predicted ----
+    rc = ensure_pinned(c, 2 * cs.off + 4096);
+    if (rc) return rc;
+    uint8_t *hp = (uint8_t *)c->h_pin;
+    JobShape g;
+    g.file_size = file_size; g.P = P; g.n_ranks = n_ranks; g.part = part ? 1u : 0u; g.buf_len = buf_len;
+    if (spec) {
+        g = last;
+        g.buf_len = buf_len;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(hp, sm, cs.off, hipMemcpyDeviceToHost, st));
+        // while the host waits: the zero-initialised arena of this call, as large as the last call needed it
+        if (prezero) launch_zero_range(st, c->zero.p, prezero);
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
+        g.n_rec_total = *(uint32_t *)(hp + o_total) / 4;
+        if (!g.n_rec_total || (size_t)g.n_rec_total + 2 > rec_bound) return NGSC_ERR_FORMAT;
+        const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
+        const Cut *h_cuts = (const Cut *)(hp + o_cuts);
+        for (uint32_t i = 0; i < n_ranks; ++i) {
+            for (uint32_t k = 0; k < h_plans[i].n_cuts; ++k) {
+                const uint32_t n = h_cuts[(size_t)i * max_cuts + k].n_rec;
+                ++g.S;
+                g.max_rec = std::max(g.max_rec, n);
+                g.slots += n;
+                g.groups += (n + GROUP - 1) / GROUP;
+                g.tiles += (n + 255) / 256;
+            }
+        }
+        if (part) {
+            part->next_pos = h_plans[0].next_pos; part->bytes_read = h_plans[0].bytes_read; part->bsize = h_plans[0].bsize;
+            part->overlap = h_plans[0].overlap; part->done = h_plans[0].done;
+            if (!from.resume) part->overlap_used = h_plans[0].overlap_used;
+            part->resume = 1;
+        }
+        if (!g.S) return part && !part->done ? NGSC_ERR_UNSUPPORTED /* not one window fits the buffer */ : NGSC_ERR_FORMAT;
+        g.max_title = *(uint32_t *)(hp + o_maxtitle);
+        g.max_q = *(uint32_t *)(hp + o_maxq);
+        g.max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
     }
-    if (zero_on_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));   // (joined in front of the cut list copies: behind the sync the side stream is free)
-    // ---- sync 2: cut list ----
-    size_t plan_bytes = cs.off - o_plans;
-    HIPCHK(c, hipMemcpyAsync(hp, sm, o_first, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(hp + o_plans, sm + o_plans, plan_bytes, hipMemcpyDeviceToHost, st));
-    // (round 3) while the host waits: the zero-initialised arena of this call, as large as the last call needed it
-    void *const prezero_ptr = c->zero.p;
-    const size_t prezero = std::min(c->zero_hint, c->zero.cap);
-    if (prezero) launch_zero_range(st, c->zero.p, prezero);
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (*(int32_t *)(hp + o_err)) return *(int32_t *)(hp + o_err);
-    const uint32_t n_rec_total = *(uint32_t *)(hp + o_total) / 4;
-    if (!n_rec_total || (size_t)n_rec_total + 2 > rec_bound) return NGSC_ERR_FORMAT;
-    const RankPlan *h_plans = (const RankPlan *)(hp + o_plans);
-    const Cut *h_cuts = (const Cut *)(hp + o_cuts);
-    std::vector<Cut> cuts;
-    c->res_rank.resize(n_ranks);
-    for (uint32_t i = 0; i < n_ranks; ++i) {
-        ngsc_rank_t &rk = c->res_rank[i];
-        rk.rank = rank_lo + i;
-        rk.n_subblocks = h_plans[i].n_cuts;
-        rk.first_subblock = (uint32_t)cuts.size();
-        rk.overlap_used = h_plans[i].overlap_used;
-        rk.stream_off = rk.stream_bytes = 0;
-        for (uint32_t k = 0; k < h_plans[i].n_cuts; ++k) cuts.push_back(h_cuts[(size_t)i * max_cuts + k]);
-    }
-    const uint32_t S = (uint32_t)cuts.size();
-    if (part) {
-        part->next_pos = h_plans[0].next_pos; part->bytes_read = h_plans[0].bytes_read; part->bsize = h_plans[0].bsize;
-        part->overlap = h_plans[0].overlap; part->done = h_plans[0].done;
-        if (!from.resume) part->overlap_used = h_plans[0].overlap_used;
-        part->resume = 1;
-    }
-    if (!S) return part && !part->done ? NGSC_ERR_UNSUPPORTED /* not one window fits the buffer */ : NGSC_ERR_FORMAT;
+    const uint32_t S = g.S, n_rec_total = g.n_rec_total, max_rec = g.max_rec;
     // per-record arrays
     const size_t rec_cap = (size_t)n_rec_total + 2;
     // Arrays whose per-record values depend on the sub-block (title bits, cached fields, candidate values, payload bit
@@ -465,23 +483,20 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // (phyNGSC.cpp:295-300), so a rank whose last window holds a single record before the overlap also encodes the first
     // record of the next rank, and with rank regions smaller than a record consecutive ranks can even start on the same
     // record.  Slots are dealt out sub-block after sub-block (SbState::slot_bias).
-    size_t slot_cap = 2;
-    for (auto &ct : cuts) slot_cap += ct.n_rec;
-    const size_t grp_cap = (size_t)n_rec_total / GROUP + (size_t)n_ranks * max_cuts + 2;
+    const size_t slot_cap = (size_t)g.slots + 2;
+    const size_t grp_cap = (size_t)g.groups + 2;
     Carver cr2;
     size_t o_slen = cr2.take(4 * rec_cap), o_qoff = cr2.take(4 * slot_cap), o_doff = cr2.take(4 * slot_cap);
     size_t o_goff = cr2.take(4 * grp_cap), o_gflags = cr2.take(sizeof(fmask_t) * grp_cap), o_tbits = cr2.take(4 * slot_cap);
-    const uint32_t max_title = *(uint32_t *)(hp + o_maxtitle);
+    const uint32_t max_title = g.max_title;
     const uint32_t tsep_words = max_title <= 64 ? 1u : 2u;
     size_t o_tsep = cr2.take(8 * tsep_words * rec_cap), o_apos = cr2.take(8 * rec_cap), o_bcnt = cr2.take(8 * rec_cap);
     rc = ensure(c, c->recs2, cr2.off);
     if (rc) return rc;
     uint8_t *rb2 = (uint8_t *)c->recs2.p;
-    const uint32_t max_q = *(uint32_t *)(hp + o_maxq);
-    const uint32_t max_rec_bytes = *(uint32_t *)(hp + o_maxrec);
+    const uint32_t max_q = g.max_q;
+    const uint32_t max_rec_bytes = g.max_rec_bytes;
     const uint32_t qrows = max_q + 1;
-    uint32_t max_rec = 0;
-    for (auto &ct : cuts) max_rec = std::max(max_rec, ct.n_rec);
 
     // ---- per-sub-block arena ----
     // Table slots for the non-constant text fields of all sub-blocks.  FASTQ titles have one or two such fields; a
@@ -494,6 +509,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t z_nhist = cz.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
     size_t z_chist = cz.take(4 * (size_t)n_slots * TEXT_TREES * 256);
     size_t z_sb = cz.take(sizeof(SbState) * (size_t)S);   // (zero but for the four words k_init_sb writes)
+    if (spec && (c->zero.p != prezero_ptr || cz.off > c->zero.cap || cz.off > prezero)) {
+        // (cannot happen: the arena's size follows from the predicted shape, which is the shape of the call that set zero_hint)
+        c->shape.valid = 0;
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipStreamSynchronize(c->side_stream));
+        return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
+    }
     rc = ensure(c, c->zero, cz.off);
     if (rc) return rc;
     Carver cp;
@@ -517,12 +539,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const char *sq_env = getenv("NGSC_SQ_PATH");
     const bool sq_reg = max_rec_bytes <= 2048 && !(sq_env && !strcmp(sq_env, "wave"));
     const uint32_t R = sq_reg ? 256u : 0u;
-    uint32_t n_tiles = 0;
-    std::vector<uint32_t> tile_lo(S);
-    for (uint32_t s = 0; s < S; ++s) { tile_lo[s] = n_tiles; n_tiles += R ? (cuts[s].n_rec + R - 1) / R : 0; }
+    const size_t n_tiles = R ? (size_t)g.tiles : 0;
     size_t p_tilelo = cp.take(4 * (size_t)S);
-    size_t p_wq = cp.take(4 * ((size_t)n_tiles + 8)), p_wd = cp.take(4 * ((size_t)n_tiles + 8));
-    size_t p_ubits = cp.take(4 * ((size_t)n_tiles * 256 + 8));
+    size_t p_wq = cp.take(4 * (n_tiles + 8)), p_wd = cp.take(4 * (n_tiles + 8));
+    size_t p_ubits = cp.take(4 * (n_tiles * 256 + 8));
     size_t p_tw = cp.take(4 * (size_t)NCF_CAP * slot_cap);
     size_t p_tv = cp.take(4 * (size_t)NUM_CAND_CAP * slot_cap);
     size_t p_rec0 = cp.take(sizeof(Rec0Tab) * (size_t)S);
@@ -535,7 +555,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t t_owner = ct.take(4 * (size_t)n_slots);
     rc = ensure(c, c->slots, ct.off);
     if (rc) return rc;
-    if (c->zero.p != prezero_ptr || cz.off > prezero) launch_zero_range(st, c->zero.p, cz.off);
+    if (!spec && (c->zero.p != prezero_ptr || cz.off > prezero)) launch_zero_range(st, c->zero.p, cz.off);
     c->zero_hint = cz.off;
 
     uint8_t *zb = (uint8_t *)c->zero.p, *pb = (uint8_t *)c->persb.p, *tb = (uint8_t *)c->slots.p;
@@ -599,7 +619,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         const char *de = getenv("NGSC_SQ_DENSE");
         uint64_t stride = ((uint64_t)max_q + 15) & ~15ull;
         uint32_t tail_c = 0xffffffffu, tail_b = 16;
-        if (max_q && !getenv("NGSC_SQ_NO_TAIL")) {
+        if (max_q) {
             const uint32_t lc = (max_q - 1) / 16, rem = max_q - 16 * lc;   // last chunk of the longest read and its bytes
             if (rem <= 12) { tail_c = lc; tail_b = (rem + 3) & ~3u; stride = 16ull * lc + tail_b; }
         }
@@ -618,29 +638,29 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     uint32_t *d_qrowoff = (uint32_t *)(pb + p_qrowoff);
 
     // SbState (rec_lo, n_rec, rank, slot_bias; everything else zero), group and tile offsets per sub-block: written on the
-    // device from the cut list that is already there (round 3: k_init_sb instead of a host-built table and three copies in
-    // the gap behind the cut-list sync)
+    // device from the cut list that is already there (k_init_sb), which also holds the job against the shape the arrays
+    // were sized for - the synchronous path's own numbers, or the prediction
     size_t sb_bytes = sizeof(SbState) * (size_t)S;
-    rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + o_first + 4096);
+    rc = ensure_pinned(c, cs.off + sb_bytes + 8 * (size_t)S + cs.off + 4096);
     if (rc) return rc;
     hp = (uint8_t *)c->h_pin;
     SbState *h_sb = (SbState *)hp;
     {
-        uint64_t gacc = 0;
-        for (uint32_t s = 0; s < S; ++s) gacc += (cuts[s].n_rec + GROUP - 1) / GROUP;
-        if (gacc > grp_cap) return NGSC_ERR_NOMEM;
+        KScope k(c, st, "k_init_sb");
+        ShapeCaps caps;
+        caps.n_rec_total = n_rec_total; caps.S = S; caps.max_rec = max_rec; caps.slots = g.slots; caps.groups = g.groups; caps.tiles = g.tiles;
+        caps.max_title = max_title; caps.max_q = max_q; caps.max_rec_bytes = max_rec_bytes; caps.rec_bound = (uint32_t)rec_bound;
+        launch_init_sb(st, A, d_cuts, d_plans, n_ranks, max_cuts, R, caps, d_total, d_maxtitle, d_maxq, d_maxrec);
     }
-    { KScope k(c, st, "k_init_sb"); launch_init_sb(st, A, d_cuts, d_plans, n_ranks, max_cuts, R); }
 
     // ---- stage C: statistics, trees, measure.  The title chain and the sequence/quality chain share nothing
     // until the trees are built and can run on two streams. ----
-    // Two streams.  Default ("staggered", also NGSC_OVERLAP=2): the title chain and the sequence/quality chain are forked
-    // behind the sequence/quality statistics kernel, so that the latency-bound kernels of one chain (sub-block finalisation,
-    // the Huffman waves, later headers and length tables) run beside a throughput kernel of the other instead of alone on the
-    // GPU; the payload pack kernel, the longest of all, runs alone.  3 % on the 1 GB bench job, 10-17 % on 400 MB jobs, which
-    // is the size the file driver works in.  NGSC_OVERLAP=0: everything on the caller's stream - also taken whenever every
-    // kernel is being timed (ngsc_set_profiling without ngsc_profile_only), so that per-kernel durations mean what they say.
-    // NGSC_OVERLAP=1: round 1's form, the title chain beside the sequence/quality chain with a join before the Huffman kernels.
+    // Two streams ("staggered"): the title chain and the sequence/quality chain are forked behind the sequence/quality
+    // statistics kernel, so that the latency-bound kernels of one chain (sub-block finalisation, the Huffman waves, later
+    // headers and length tables) run beside a throughput kernel of the other instead of alone on the GPU; the payload pack
+    // kernel, the longest of all, runs alone.  3 % on the 1 GB bench job, 10-17 % on 400 MB jobs, which is the size the file
+    // driver works in.  NGSC_OVERLAP=0: everything on the caller's stream - also taken whenever every kernel is being timed
+    // (ngsc_set_profiling without ngsc_profile_only), so that per-kernel durations mean what they say.
     // Colour-space sub-blocks (found by the statistics kernels of a first run, which then ends with ERR_COLORSPACE): the job
     // runs on a copy of its input in which they are decoded to bases as the reference decodes them (kernels_cs.hip)
     if (c->cs_retry) {
@@ -652,9 +672,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         A.buf = (const uint8_t *)c->cscopy.p;
         A.cs_mode = 1;
     }
-    const bool overlap = ov_env && !strcmp(ov_env, "1");
-    const bool stagger = (ov_env ? (!strcmp(ov_env, "2") || !strcmp(ov_env, "3")) : !time_all) && sq_reg && !c->debug_sync;
-    hipStream_t st2 = overlap ? c->side_stream : st;
+    const bool stagger = !serial && sq_reg;
     hipStream_t sts = stagger ? c->side_stream : st;   // the sequence/quality chain's stream behind its statistics kernel
     auto fork_s = [&]() -> int {
         if (!stagger) return NGSC_OK;
@@ -668,74 +686,30 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         return NGSC_OK;
     };
-    auto fork = [&]() -> int {
-        if (!overlap) return NGSC_OK;
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));
-        HIPCHK(c, hipStreamWaitEvent(st2, c->ev_fork, 0));
-        return NGSC_OK;
-    };
-    auto join = [&]() -> int {
-        if (!overlap) return NGSC_OK;
-        HIPCHK(c, hipEventRecord(c->ev_join, st2));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-        return NGSC_OK;
-    };
     // titles of at most 128 bytes take the word-parallel kernels, with one or two 64-bit mask words (NGSC_TITLE_PATH=reg forces the byte-serial ones)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
     const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
-    if (stagger) {
-        // NGSC_OVERLAP=3 (experiment): the fork in front of the statistics kernels - the issue-bound title statistics beside
-        // the texture-path-bound sequence/quality statistics
-        const bool early = ov_env && !strcmp(ov_env, "3");
-        if (early) {
-            { KScope k(c, st, "k_rec0_fields"); launch_rec0_fields(st, A); }
-            if ((rc = fork_s())) return rc;
-        } else {
-            // (round 3) record 0's field table - one wave per sub-block, a serial walk over a title: 23 us - is needed by the title
-            // kernels only: on the side stream, beside the sequence/quality statistics instead of in front of them
-            if ((rc = fork_s())) return rc;
-            { KScope k(c, sts, "k_rec0_fields"); launch_rec0_fields(sts, A); }
-            HIPCHK(c, hipEventRecord(c->ev_zero, sts));
-        }
-        hipStream_t sq0 = early ? sts : st;
-        { KScope k(c, sq0, "k_sq_stats_reg"); launch_sq_stats_reg(sq0, A, max_rec, max_rec_bytes, n_rec_total); }
-        if (!early) {
-            if ((rc = fork_s())) return rc;
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
-        }
-        { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
-        { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
-        { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
-        if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
-        else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
-        { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
-        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
-        { KScope k(c, st, "k_huffman_fields"); launch_huffman_fields(st, A); }
-        { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-        { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
-        if ((rc = join_s())) return rc;
-    } else {
-    if ((rc = fork())) return rc;
-    { KScope k(c, st2, "k_rec0_fields"); launch_rec0_fields(st2, A); }
-    if (t_swar) { KScope k(c, st2, "k_title_stats_swar"); launch_title_stats_swar(st2, A, max_rec, max_title); }
-    else { KScope k(c, st2, "k_title_stats_reg"); launch_title_stats_reg(st2, A, max_rec); }
-    { KScope k(c, st2, "k_field_finalize"); launch_field_finalize(st2, A); }
-    { KScope k(c, st2, "k_title_hist"); launch_title_hist(st2, A, max_rec, t_swar); }
+    // record 0's field table - one wave per sub-block, a serial walk over a title: 23 us - is needed by the title kernels
+    // only: on the side stream, beside the sequence/quality statistics instead of in front of them
+    if ((rc = fork_s())) return rc;
+    { KScope k(c, sts, "k_rec0_fields"); launch_rec0_fields(sts, A); }
+    if (stagger) HIPCHK(c, hipEventRecord(c->ev_zero, sts));
     if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec, max_rec_bytes, n_rec_total); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
-    { KScope k(c, st, "k_sq_finalize"); launch_sq_finalize(st, A); }
-    if ((rc = join())) return rc;
-    { KScope k(c, st, "k_huffman_sb"); launch_huffman_sb(st, A); }
+    if ((rc = fork_s())) return rc;
+    if (stagger) HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
+    { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
+    { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
+    if (sq_reg) { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
+    else { KScope k(c, sts, "k_measure_sq"); launch_measure_sq(sts, A, max_rec); }
+    if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
+    else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+    { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
+    { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
+    { KScope k(c, st, "k_huffman_fields"); launch_huffman_fields(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-    if ((rc = fork())) return rc;
-    { KScope k(c, st2, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st2, A, max_rec, t_swar); }
-    if (sq_reg) {
-        { KScope k(c, st, "k_sq_measure_reg"); launch_sq_measure_reg(st, A, max_rec); }
-    } else {
-        { KScope k(c, st, "k_measure_sq"); launch_measure_sq(st, A, max_rec); }
-    }
-    if ((rc = join())) return rc;
-    }
+    { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
+    if ((rc = join_s())) return rc;
     if (R) { KScope k(c, st, "k_layout"); launch_layout(st, A, R, d_qrowoff, out_cap, d_outtot, d_done); }
     else {
         { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
@@ -744,8 +718,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- sizes and layout are on the device now; their copies for the host travel behind the pack kernels (no sync here) ----
     // (staggered: the copies, the headers and the length tables beside the output clearing and the title pack kernel)
     if ((rc = fork_s())) return rc;
+    uint8_t *const h_small = hp + sb_bytes;   // the small state behind the layout kernels (plans and cuts included)
     HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, sts));
-    HIPCHK(c, hipMemcpyAsync(hp + sb_bytes, sm, o_first, hipMemcpyDeviceToHost, sts));
+    HIPCHK(c, hipMemcpyAsync(h_small, sm, cs.off, hipMemcpyDeviceToHost, sts));
     // ---- pack ----
     { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap, out_prefix); }
     if (stagger) {   // the side stream's kernels write into the cleared output
@@ -754,14 +729,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     { KScope k(c, sts, "k_write_headers"); launch_write_headers(sts, A, d_qrowoff); }
     { KScope k(c, sts, "k_pack_lentable"); launch_pack_lentable(sts, A, max_rec); }
-    // (round 3, measured and not kept: NGSC_TPACK_SIDE=1 puts the title pack kernel - latency-bound, 0.11 ms alone - behind the headers
-    // on the side stream, BESIDE the payload pack kernel.  The payload kernel then takes 0.55 ms instead of 0.40: it is bound by
-    // instruction issue and its LDS queue, and what it shares it loses - 452 against 462 GB/s)
-    static const bool tpack_side_env = getenv("NGSC_TPACK_SIDE") != nullptr;
-    const bool tpack_side = stagger && tpack_side_env;
-    if ((rc = fork())) return rc;
-    { hipStream_t tps = tpack_side ? sts : st2; KScope k(c, tps, "k_title_pack_reg"); launch_title_pack_reg(tps, A, max_rec); }
-    if (!tpack_side && (rc = join_s())) return rc;
+    // (measured and not kept: the title pack kernel - latency-bound, 0.11 ms alone - on the side stream BESIDE the payload pack
+    // kernel.  The payload kernel then takes 0.55 ms instead of 0.40: it is bound by instruction issue and its LDS queue, and
+    // what it shares it loses - 452 against 462 GB/s)
+    { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
+    if ((rc = join_s())) return rc;
     if (sq_reg) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
         // length, + 10 % (from the record count: no stream size has to come back to the host first; a tile that needs
@@ -778,19 +750,25 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
-    if (tpack_side && (rc = join_s())) return rc;
-    if ((rc = join())) return rc;
-    // ---- the one sync behind the cut list: error word, sizes, result tables ----
-    uint8_t *hfin = hp + sb_bytes + o_first + 64;
+    // ---- the one sync of a predicted step (the second of a synchronous one): error word, sizes, result tables ----
+    uint8_t *hfin = h_small + cs.off + 64;
     HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
-    const int32_t err3 = *(int32_t *)(hp + sb_bytes + o_err);   // state behind the layout kernels
-    const uint64_t total = *(uint64_t *)(hp + sb_bytes + o_outtot);
+    const int32_t err3 = *(int32_t *)(h_small + o_err);   // state behind the layout kernels
+    const int32_t err4 = *(int32_t *)hfin;
+    if (err3 == ERR_SHAPE || err4 == ERR_SHAPE) {
+        // the prediction did not hold (nothing was written behind k_init_sb): once more, reading the shape back
+        c->shape.valid = 0;
+        if (!spec) return NGSC_ERR_HIP;   // (the synchronous path sizes everything from the job's own numbers)
+        HIPCHK(c, hipStreamSynchronize(c->side_stream));
+        return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
+    }
+    const uint64_t total = *(uint64_t *)(h_small + o_outtot);
     c->res_bytes = total;
     c->out_hint = total;
     if (err3 == NGSC_ERR_UNSUPPORTED && !c->slot_retry) {
-        const uint32_t asked = *(uint32_t *)(hp + sb_bytes + o_slotc);
+        const uint32_t asked = *(uint32_t *)(h_small + o_slotc);
         if (asked > n_slots) {
             // (kernels that start after the error flag is up return early, so the count can fall short: grow at least 2x)
             c->slot_retry = true;
@@ -804,14 +782,55 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             return r;
         }
     }
-    if ((err3 == NGSC_ERR_COLORSPACE || *(int32_t *)hfin == NGSC_ERR_COLORSPACE) && !c->cs_retry) {
+    if ((err3 == NGSC_ERR_COLORSPACE || err4 == NGSC_ERR_COLORSPACE) && !c->cs_retry) {
         c->cs_retry = true;
         const int r = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
         c->cs_retry = false;
         return r;
     }
     if (err3) return err3;
-    if (*(int32_t *)hfin) return *(int32_t *)hfin;
+    if (err4) return err4;
+    // ---- results (the planner's tables came back with the small state) ----
+    const RankPlan *h_plans = (const RankPlan *)(h_small + o_plans);
+    const Cut *h_cuts = (const Cut *)(h_small + o_cuts);
+    std::vector<Cut> cuts;
+    cuts.reserve(S);
+    c->res_rank.resize(n_ranks);
+    JobShape seen = g;   // what this job really looked like: the next call's prediction
+    seen.S = 0; seen.max_rec = 0; seen.slots = seen.groups = seen.tiles = 0;
+    for (uint32_t i = 0; i < n_ranks; ++i) {
+        ngsc_rank_t &rk = c->res_rank[i];
+        rk.rank = rank_lo + i;
+        rk.n_subblocks = h_plans[i].n_cuts;
+        rk.first_subblock = (uint32_t)cuts.size();
+        rk.overlap_used = h_plans[i].overlap_used;
+        rk.stream_off = rk.stream_bytes = 0;
+        for (uint32_t k = 0; k < h_plans[i].n_cuts; ++k) {
+            const Cut &ct = h_cuts[(size_t)i * max_cuts + k];
+            cuts.push_back(ct);
+            ++seen.S;
+            seen.max_rec = std::max(seen.max_rec, ct.n_rec);
+            seen.slots += ct.n_rec;
+            seen.groups += (ct.n_rec + GROUP - 1) / GROUP;
+            seen.tiles += (ct.n_rec + 255) / 256;
+        }
+    }
+    if (cuts.size() != S) return NGSC_ERR_HIP;   // (k_init_sb lets no other count through)
+    seen.n_rec_total = *(uint32_t *)(h_small + o_total) / 4;
+    seen.max_title = *(uint32_t *)(h_small + o_maxtitle);
+    seen.max_q = *(uint32_t *)(h_small + o_maxq);
+    seen.max_rec_bytes = *(uint32_t *)(h_small + o_maxrec);
+    if (!part && !c->cs_retry) {
+        // Capacities with a little head room for the counts (the next job of a file has a few records more or less); the
+        // maxima as they were: a larger title / read / record in the next job is a miss, and so is another sub-block count
+        seen.n_rec_total += seen.n_rec_total / 64 + 256;
+        seen.max_rec = std::min<uint32_t>(MAX_RECORDS, seen.max_rec + seen.max_rec / 64 + 64);
+        seen.slots += seen.slots / 64 + 256;
+        seen.groups += seen.groups / 64 + 64;
+        seen.tiles += seen.tiles / 64 + 64;
+        seen.valid = 1;
+        c->shape = seen;
+    }
     c->res_sb.resize(S);
     c->qbits_x16 = c->dbits_x16 = 0;
     c->big_alphabets = false;

@@ -81,8 +81,8 @@ __device__ __forceinline__ uint32_t hw_rl(uint32_t v, uint32_t lane) { return (u
 // the edges from the root down to it, of 1 (the parent's own bit) plus - on a right edge - the bits of the left sibling's
 // subtree; the merge loop keeps every internal node's subtree bits, the leaves add the sum up on the walk that already
 // gives them their codes, and each leaf ORs its "1 | id" field into a zeroed bit string (internal nodes are its 0 bits).
-// The serial form (serial_blob, NGSC_HUFF_BLOB_SERIAL=1) popped 2n - 1 nodes off a register stack one after the other.
-__device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in, bool serial_blob)
+// (A tree of a single symbol has no internal node: its blob is the one leaf.)
+__device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
 {
     const uint32_t lane = threadIdx.x & 63;
     auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
@@ -163,8 +163,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in, bool serial_blob
         blob[4] = (uint8_t)(n >> 24); blob[5] = (uint8_t)(n >> 16); blob[6] = (uint8_t)(n >> 8); blob[7] = (uint8_t)n;
         blob[8] = (uint8_t)min_len;
     }
-    uint32_t pos = 9, nacc = 0;
-    if (!serial_blob && present >= 2) {
+    if (present >= 2) {
         uint32_t *words = T.ifreq;                // (not used by this form otherwise) 64 words = 2048 bits; a tree of 64 symbols has 511
         words[lane] = 0;
         tree_sync();
@@ -180,32 +179,18 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in, bool serial_blob
         tree_sync();
         return;
     }
-    uint64_t acc = 0;
-    uint32_t vstack = 0, sp = 0;                  // the stack: lane i holds entry i (at most n entries are pending at a time)
-    vstack = hw_wl(root, 0, vstack); sp = 1;
-    while (sp) {
-        const uint32_t node = hw_rl(vstack, --sp);
-        uint32_t v, nb;
-        if (node < n) { v = (1u << bits_per_id) | node; nb = 1 + bits_per_id; }
-        else {
-            v = 0; nb = 1;
-            vstack = hw_wl(hw_rl(vrc, node - n), sp, vstack); ++sp;
-            vstack = hw_wl(hw_rl(vlc, node - n), sp, vstack); ++sp;
-        }
-        acc = (acc << nb) | v;
-        nacc += nb;
-        while (nacc >= 8) { if (lane == 0) blob[pos] = (uint8_t)(acc >> (nacc - 8)); ++pos; nacc -= 8; }
-        acc &= (1ull << nacc) - 1ull;
+    // one symbol: the root is leaf 0, "1 | id" and padding
+    {
+        const uint32_t v = (1u << bits_per_id) | root, nb = 1 + bits_per_id;   // nb <= 7 for n <= 64
+        if (lane == 0) { blob[9] = (uint8_t)(v << (8 - nb)); T.blob_len = 10; T.max_len = U(mx); }
     }
-    if (nacc) { if (lane == 0) blob[pos] = (uint8_t)(acc << (8 - nacc)); ++pos; }
-    if (lane == 0) { T.blob_len = pos; T.max_len = U(mx); }
     tree_sync();
 }
 
 // grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
 template <bool SMALL, class Tree>
-__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t, uint32_t regs)
+__device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t)
 {
     const int lane = threadIdx.x & 63;
     const SbState &sb = A.sb[s];
@@ -217,7 +202,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nqual;
         const uint32_t *row = A.qhist + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)row[sb.qualities[j]] << 32) | j;
-        if constexpr (SMALL) { if (regs & 1u) build_tree_regs(T, n, (regs & 2u) != 0); else build_tree_wave(T, n); } else build_tree_wave(T, n);
+        if constexpr (SMALL) build_tree_regs(T, n); else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.qcodes + ((size_t)s * A.qrows + t) * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[j] = (T.code[j] << 5) | T.len[j];
@@ -230,7 +215,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t n = sb.nsym;
         const uint32_t *occ = A.dna_occ + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)occ[sb.symbols[j]] << 32) | j;
-        if constexpr (SMALL) { if (regs & 1u) build_tree_regs(T, n, (regs & 2u) != 0); else build_tree_wave(T, n); } else build_tree_wave(T, n);
+        if constexpr (SMALL) build_tree_regs(T, n); else build_tree_wave(T, n);
         if (T.max_len > MAX_CODE_LEN) { if (lane == 0) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED); return; }
         uint32_t *dst = A.dcodes + (size_t)s * 256;
         for (uint32_t j = lane; j < n; j += 64) dst[sb.symbols[j]] = (T.code[j] << 5) | T.len[j];
@@ -268,7 +253,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
 // runs beside this kernel.
 constexpr uint32_t SMALL_TREES_PER_WG = 4;
 template <bool SMALL>
-__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t regs)
+__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt)
 {
     if (*A.err) return;
     // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
@@ -280,7 +265,7 @@ __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffma
     Tree &T = Ts[threadIdx.x >> 6];
     const uint32_t pairs = nt * A.n_sb;
     for (uint32_t p = blockIdx.x * TPW + (threadIdx.x >> 6); p < pairs; p += gridDim.x * TPW) {
-        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt, regs);
+        huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt);
         tree_sync();   // (T is used again)
     }
 }
@@ -318,10 +303,8 @@ static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uin
 {
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
-    // (NGSC_HUFF_LDS=1: round 2's LDS form of the small instance; NGSC_HUFF_BLOB_SERIAL=1: the register form with its serial blob loop)
-    const uint32_t regs = getenv("NGSC_HUFF_LDS") ? 0u : (getenv("NGSC_HUFF_BLOB_SERIAL") ? 3u : 1u);
-    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt, regs);
-    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt, 0u);
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt);
+    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt);
 }
 
 void launch_huffman_sb(hipStream_t st, const Arena &A)

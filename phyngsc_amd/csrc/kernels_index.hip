@@ -224,7 +224,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_write(const uint32_t *nl_ma
 // The reference assumes both and runs into undefined behaviour otherwise; we report ERR_FORMAT.
 __device__ __forceinline__ void validate_records(const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec,
                                                  uint32_t first, uint32_t stride, uint32_t *max_q, uint32_t *max_rec,
-                                                 uint32_t *max_title, int32_t *err, bool vec)
+                                                 uint32_t *max_title, int32_t *err)
 {
     uint32_t mq = 0, mr = 0, mt = 0;
     bool bad = false;
@@ -236,19 +236,7 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
         mr = RB > mr ? RB : mr;
         mt = TL > mt ? TL : mt;
     };
-    // four consecutive records per thread and trip, their table entries with 16-byte loads (round 3: 0.068 -> ms)
-    const uint32_t n4 = vec ? n_rec & ~3u : 0u;
-    if (!vec) for (uint32_t r = first; r < n_rec; r += stride) one(te[r], se[r], ls[r], ls[r + 1]);
-    for (uint32_t r = 4 * first; r < n4; r += 4 * stride) {
-        const uint4 t4 = *reinterpret_cast<const uint4 *>(te + r), s4 = *reinterpret_cast<const uint4 *>(se + r);
-        const uint4 l4 = *reinterpret_cast<const uint4 *>(ls + r);
-        const uint32_t l5 = ls[r + 4];
-        one(t4.x, s4.x, l4.x, l4.y);
-        one(t4.y, s4.y, l4.y, l4.z);
-        one(t4.z, s4.z, l4.z, l4.w);
-        one(t4.w, s4.w, l4.w, l5);
-    }
-    if (vec && first == 0) for (uint32_t r = n4; r < n_rec; ++r) one(te[r], se[r], ls[r], ls[r + 1]);
+    for (uint32_t r = first; r < n_rec; r += stride) one(te[r], se[r], ls[r], ls[r + 1]);
     if (__any(bad)) { if ((threadIdx.x & 63) == 0) atomicMin(err, (int32_t)ERR_FORMAT); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -452,7 +440,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
                                                        const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                                                        uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
                                                        uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, PlanResume from,
-                                                       uint64_t buf_end_abs, uint32_t flags)
+                                                       uint64_t buf_end_abs)
 {
     const uint32_t n_rec_total = *total_lines / 4;
     // tail_buf: the job buffer when it ends where the file ends.  Two real newlines behind the last complete record (the
@@ -473,7 +461,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
             const uint64_t D = bs > ov ? bs - ov : 0;
             const uint64_t n_ls = (uint64_t)n_rec_total + 1;
             const uint32_t last_ls = ls[n_rec_total];
-            if (bs == WINDOW && D && x0 >= buf_off && n_rec_total > 256 && !(flags & 2u)) {
+            if (bs == WINDOW && D && x0 >= buf_off && n_rec_total > 256) {
                 const uint64_t w = ((uint64_t)g.region + D - 1) / D + 1;
                 nwin = w < PL_WIN ? (uint32_t)w : PL_WIN;
             }
@@ -515,19 +503,7 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
         return;
     }
     const uint32_t vb = blockIdx.x - n_ranks, nvb = gridDim.x - n_ranks;
-    validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err, (flags & 1u) != 0);
-}
-
-// The validation pass alone (round 3): without the planner's 24 KB of LDS in every workgroup, on a stream of its own beside the
-// planner's chain.
-__global__ __launch_bounds__(256) void k_validate_records(const uint32_t *te, const uint32_t *se, const uint32_t *ls, const uint32_t *total_lines,
-                                                          uint32_t *max_q, uint32_t *max_rec, uint32_t *max_title, int32_t *err,
-                                                          const uint8_t *tail_buf, uint32_t flags)
-{
-    const uint32_t n_rec_total = *total_lines / 4;
-    if (tail_buf && blockIdx.x == 0 && threadIdx.x == 0 && (*total_lines & 3u) == 3u && tail_buf[ls[n_rec_total]] != '\n')
-        atomicMin(err, (int32_t)ERR_FORMAT);   // (see k_cuts_validate)
-    validate_records(te, se, ls, n_rec_total, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, max_q, max_rec, max_title, err, (flags & 1u) != 0);
+    validate_records(te, se, ls, n_rec_total, vb * blockDim.x + threadIdx.x, nvb * blockDim.x, max_q, max_rec, max_title, err);
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------
@@ -565,25 +541,15 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
                           uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
-                          uint64_t buf_end_abs, hipStream_t validate_stream)
+                          uint64_t buf_end_abs)
 {
     // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
     // wave per 64 records
     uint32_t vblocks = (n_rec + 2047) / 2048;
     if (vblocks < 1) vblocks = 1;
     if (vblocks > 16384) vblocks = 16384;
-    // (experiments: NGSC_CV_VEC=1 four records per thread with 16-byte loads - measured SLOWER, see DESIGN.md;
-    // NGSC_CV_NOCACHE=1 the planner without its LDS cache of looked-ahead windows)
-    const uint32_t flags = (getenv("NGSC_CV_VEC") ? 1u : 0u) | (getenv("NGSC_CV_NOCACHE") ? 2u : 0u);
-    if (validate_stream) {   // the planner's chain here, the validation pass on its own stream (the caller joins it)
-        hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                           ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs, flags);
-        hipLaunchKernelGGL(k_validate_records, dim3(vblocks), dim3(256), 0, validate_stream, te, se, ls, total_lines, max_q, max_rec, max_title, err,
-                           tail_buf, flags);
-        return;
-    }
     hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs, flags);
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs);
 }
 
 }  // namespace ngsc

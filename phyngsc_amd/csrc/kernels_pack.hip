@@ -435,9 +435,49 @@ __global__ __launch_bounds__(256) void k_zero_range(uint4 *out, uint64_t n16)
 // SbState of every sub-block (rec_lo, n_rec, rank, slot_bias; the rest is zero already), its first title group and its first tile, from
 // the cut list the planner left on the device (engine.cpp built these on the host and copied them over until round 3).
 // One workgroup; a thread takes a rank: totals of its cuts, workgroup scan, then its cuts again.
-__global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R)
+// It also holds the job against the shape its arrays and grids were sized for (caps): the step may have been enqueued from a
+// PREDICTION of the planner's counts and the job's maxima (engine.cpp: JobShape) - another number of sub-blocks, more records,
+// slots, groups or tiles than there is room for, or a longer title / read / record than the kernels were chosen for raise
+// ERR_SHAPE, every kernel behind this one leaves at once, and the host runs the step again with the job's own numbers.
+__global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
+                                                 ShapeCaps caps, const uint32_t *total_lines, const uint32_t *max_title, const uint32_t *max_q,
+                                                 const uint32_t *max_rec_bytes)
 {
+    if (*A.err) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint32_t s_bad;
+    if (tid == 0) {
+        const uint32_t n_rec_total = *total_lines / 4;
+        s_bad = (n_rec_total > caps.n_rec_total || (uint64_t)n_rec_total + 2 > caps.rec_bound || *max_title > caps.max_title || *max_q > caps.max_q ||
+                 *max_rec_bytes > caps.max_rec_bytes) ? 1u : 0u;
+    }
+    __syncthreads();
+    {   // the planner's counts, before anything is written
+        uint32_t s_cnt = 0, mr = 0;
+        uint64_t sl = 0, gr = 0, tl = 0;
+        for (uint32_t i = tid; i < n_ranks; i += 256) {
+            const uint32_t nc = plans[i].n_cuts < max_cuts ? plans[i].n_cuts : max_cuts;
+            s_cnt += nc;
+            for (uint32_t k = 0; k < nc; ++k) {
+                const uint32_t n = cuts[(size_t)i * max_cuts + k].n_rec;
+                mr = n > mr ? n : mr;
+                sl += n;
+                gr += (n + GROUP - 1) / GROUP;
+                tl += R ? (n + R - 1) / R : 0;
+            }
+        }
+        __shared__ uint32_t s_S;
+        __shared__ unsigned long long s_sl, s_gr, s_tl;
+        if (tid == 0) { s_S = 0; s_sl = s_gr = s_tl = 0; }
+        __syncthreads();
+        if (s_cnt) atomicAdd(&s_S, s_cnt);
+        if (sl) { atomicAdd(&s_sl, (unsigned long long)sl); atomicAdd(&s_gr, (unsigned long long)gr); atomicAdd(&s_tl, (unsigned long long)tl); }
+        if (mr > caps.max_rec) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        if (tid == 0 && (s_S != caps.S || s_sl > caps.slots || s_gr > caps.groups || (R && s_tl > caps.tiles))) s_bad = 1u;
+        __syncthreads();
+        if (s_bad) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
+    }
     // (the SbState array lies in the arena the engine clears for every call: only the non-zero words are written here)
     __shared__ uint32_t s_w[4][4];
     uint32_t base[4] = {0, 0, 0, 0};   // sub-blocks, record slots, title groups, tiles of the ranks in front (workgroup-uniform)
@@ -510,9 +550,10 @@ void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes)   // bytes: 
     hipLaunchKernelGGL(k_zero_range, dim3(grid), dim3(256), 0, st, reinterpret_cast<uint4 *>(d_out), n16);
 }
 
-void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R)
+void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
+                    const ShapeCaps &caps, const uint32_t *total_lines, const uint32_t *max_title, const uint32_t *max_q, const uint32_t *max_rec_bytes)
 {
-    hipLaunchKernelGGL(k_init_sb, dim3(1), dim3(256), 0, st, A, cuts, plans, n_ranks, max_cuts, R);
+    hipLaunchKernelGGL(k_init_sb, dim3(1), dim3(256), 0, st, A, cuts, plans, n_ranks, max_cuts, R, caps, total_lines, max_title, max_q, max_rec_bytes);
 }
 
 static uint32_t lds_entries_for(uint32_t qrows)

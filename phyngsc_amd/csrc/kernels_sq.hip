@@ -780,33 +780,11 @@ constexpr uint32_t SQ_NCOL0 = SR_HCOLS + 1;      // first of the eight transferr
 constexpr uint32_t SQ_QS = SR_HCOLS + 1 + 8;
 constexpr uint32_t SQ_QPAD = 0x51515151u;        // 33 + 48 in every byte
 constexpr uint32_t SQ_QROWS_EXTRA = 17;          // pad bytes of the last chunk, and the (q - 33) & 63 reach of the general path
-// (row_lo: the table holds the rows row_lo .. row_lo + lds_rows - 1 of the sub-block's table - the pack kernel walks long
-// reads window by window with a table of one window's rows, see k_sq_pack_reg)
-template <class T>
-__device__ __forceinline__ void sq_fill_qtab(const Arena &A, uint32_t s, const SbState &sb, T *s_qtab, uint32_t lds_rows, uint32_t row_lo = 0)
-{
-    const uint32_t nq = sb.nqual;
-    const uint32_t *qg = A.qcodes + (size_t)s * A.qrows * 256;
-    for (uint32_t k = threadIdx.x; k < (lds_rows + SQ_QROWS_EXTRA) * SQ_QS; k += SR_THREADS) s_qtab[k] = 0;
-    __syncthreads();
-    const uint32_t have = A.qrows > row_lo ? (A.qrows - row_lo < lds_rows ? A.qrows - row_lo : lds_rows) : 0;
-    for (uint32_t k = threadIdx.x; k < have * nq; k += SR_THREADS) {
-        const uint32_t row = k / nq, ci = k % nq;
-        const uint32_t qv = sb.qualities[ci];
-        // (208..215: a transferred N.  The raw bytes 82..89, which would land on those columns, have none: the measure kernel
-        // reads the N columns whatever else the alphabet holds)
-        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : (qv - 33u < SR_HCOLS ? qv - 33u : ~0u);
-        if (col < SQ_QS) {
-            const uint32_t e = qg[(size_t)(row_lo + row) * 256 + ci];
-            s_qtab[row * SQ_QS + col] = sizeof(T) == 1 ? (T)(e & 31u) : (T)e;
-        }
-    }
-}
-
-// (round 3) The same table from its ready-made copy in global memory (Arena::qfmt, k_sq_format_qtab): rows row_lo .. of the
+// The tables come from their ready-made copies in global memory (Arena::qfmt, k_sq_format_qtab): rows row_lo .. of the
 // sub-block's table as they lie there - a straight 8-byte copy instead of a clearing pass, a barrier and one division per
-// entry, which the windowed pack kernel paid once per window and tile (five times per tile of 150-base reads).  The rows behind
-// lds_rows hold the table's next rows instead of zeros: nothing reads their values (see SQ_QROWS_EXTRA).
+// entry per workgroup (and, in the windowed pack kernel, per window and tile: five times per tile of 150-base reads).  The rows
+// behind lds_rows hold the table's next rows instead of zeros: nothing reads their values (see SQ_QROWS_EXTRA).  The pack kernel
+// walks long reads window by window with a table of one window's rows (row_lo), see k_sq_pack_reg.
 // (the byte tables lie behind the dword tables: 16-byte multiples per sub-block, the pad bytes never written nor used)
 __device__ __host__ __forceinline__ uint32_t sq_qfmt8_stride(uint32_t qrows) { return ((qrows + SQ_QROWS_EXTRA) * SQ_QS + 15u) & ~15u; }
 __device__ __forceinline__ uint8_t *sq_qfmt8(const Arena &A, uint32_t s)
@@ -845,7 +823,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_format_qtab(Arena A)
     __syncthreads();
     if (threadIdx.x < sb.nqual) {
         const uint32_t qv = sb.qualities[threadIdx.x];
-        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : (qv - 33u < SR_HCOLS ? qv - 33u : ~0u);   // (as sq_fill_qtab)
+        // (208..215: a transferred N.  The raw bytes 82..89, which would land on those columns, have none: the measure kernel
+        // reads the N columns whatever else the alphabet holds)
+        const uint32_t col = (qv >= 208u && qv < 216u) ? SQ_NCOL0 + (qv - 208u) : (qv - 33u < SR_HCOLS ? qv - 33u : ~0u);
         if (col < SQ_QS) s_inv[col] = (uint16_t)(threadIdx.x + 1);
     }
     __syncthreads();
@@ -884,9 +864,8 @@ __device__ __forceinline__ uint32_t sq_qentry_slow(const SqTabs &T, uint32_t row
 
 // ---- measure: payload bits per record and per 256-record tile ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw, uint32_t fmt)
+__global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t lds_rows, uint32_t tpw)
 {
-    // fmt != 0: the length table comes from its ready-made copy (sq_copy_qtab8)
     if (*A.err) return;
     extern __shared__ __align__(16) uint8_t s_qlen[];   // [lds_rows][64] code lengths
     __shared__ uint32_t s_dcode[256];
@@ -905,8 +884,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
     s_qcode[tid] = sb.qua_code[tid];
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
     if (tid < 2) s_tot[tid] = 0;
-    if (fmt) sq_copy_qtab8(A, s, s_qlen, lds_rows);
-    else sq_fill_qtab(A, s, sb, s_qlen, lds_rows);
+    sq_copy_qtab8(A, s, s_qlen, lds_rows);
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const bool plain = (sb.flags & F_DNA_PLAIN) != 0;
@@ -953,6 +931,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 for (uint32_t k = 0; k < 4; ++k) {
                     uint32_t qm = qw[k];
                     if (tails) {
+                        if (k && !__any(nv > 4 * k)) continue;   // a dword no lane of the wave needs (36 bases: 16 + 16 + 4)
                         const uint32_t vm = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
                         qm = (qw[k] & vm) | (SQ_QPAD & ~vm);
                     }
@@ -1105,9 +1084,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 
 // ---- pack ----
 template <bool BURST>
-__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win, uint32_t fmt)
+__global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
 {
-    // fmt != 0: the table comes from its ready-made copy (sq_copy_qtab)
     // win != 0 (long reads): the table holds one WINDOW of win positions (rows r0 .. r0 + win, lds_rows = win + 1), refilled
     // window after window for every tile - a [301][49] table plus staging left room for two workgroups per CU, a window
     // of 48 rows leaves room for four, and the lean path no longer needs the whole table to fit.
@@ -1130,10 +1108,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     s_dcode[tid] = A.dcodes[(size_t)s * 256 + tid];
     s_qcode[tid] = sb.qua_code[tid];
     s_amb[tid] = (uint8_t)amb_code((uint8_t)tid);
-    if (!win) {
-        if (fmt) sq_copy_qtab(A, s, s_qtab, lds_rows, 0);
-        else sq_fill_qtab(A, s, sb, s_qtab, lds_rows);
-    }
+    if (!win) sq_copy_qtab(A, s, s_qtab, lds_rows, 0);
     __syncthreads();
     SqTabs T = {A.qcodes + (size_t)s * A.qrows * 256, s_qcode, s_amb, s_dcode, lds_rows};
     const uint32_t n_win = win ? (sb.max_q + win - 1) / win : 1u, win_chunks = win ? win / 16 : ~0u;   // (uniform over the workgroup)
@@ -1200,8 +1175,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         const uint32_t r0 = w * win;
         if (win) {   // (whole workgroup: n_win comes from the sub-block's longest read)
             __syncthreads();
-            if (fmt) sq_copy_qtab(A, s, s_qtab, lds_rows, r0);
-            else sq_fill_qtab(A, s, sb, s_qtab, lds_rows, r0);
+            sq_copy_qtab(A, s, s_qtab, lds_rows, r0);
             __syncthreads();
         }
         for (uint32_t grp = w * (win_chunks / NBX); (!win || grp < (w + 1) * (win_chunks / NBX)) && __any(16 * NBX * grp < L); ++grp) {
@@ -1235,12 +1209,15 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     // ---- lean path: alphabet inside the table (sq_lean_alphabet) and no high bit in this chunk's bytes ----
                     if (lean_wg && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
                         const bool tails = __any(nv != 16);
-                        uint32_t vmk[4] = {~0u, ~0u, ~0u, ~0u}, idx[4], dacc = 0;
+                        // dwords that some lane of the wave still needs (36 bases = 16 + 16 + 4: the last chunk is one dword)
+                        const bool wany[4] = {true, !tails || __any(nv > 4), !tails || __any(nv > 8), !tails || __any(nv > 12)};
+                        uint32_t vmk[4] = {~0u, ~0u, ~0u, ~0u}, idx[4] = {0, 0, 0, 0}, dacc = 0;
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
                             uint32_t w = sw[k];
                             if (tails) {
                                 vmk[k] = t_lowbytes32((int32_t)nv - 4 * (int32_t)k);
+                                if (!wany[k]) continue;   // (idx = 0, 'A': no lane has a byte here)
                                 w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
                             }
                             idx[k] = sr_idx(w);
@@ -1255,6 +1232,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                             uint32_t d5 = 0;
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
+                                if (!wany[k]) continue;
                                 const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
                                 d5 |= __builtin_amdgcn_perm(0x4E000000u, 0x47544341u, (w >> 1) & 0x07070707u) ^ w;
                             }
@@ -1264,6 +1242,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                         if (__any(dacc != 0) && !n_only) {
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
+                                if (!wany[k]) continue;
                                 const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
                                 const uint32_t a01 = t_nonzero01(sr_not_acgt(w, idx[k]));
                                 ambm |= t_movemask(a01) << (4 * k);
@@ -1277,6 +1256,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                         uint32_t e[16];
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
+                            if (!wany[k]) { e[4 * k] = e[4 * k + 1] = e[4 * k + 2] = e[4 * k + 3] = 0; continue; }
                             uint32_t qm = masked ? ((qw[k] & keep[k]) | (SQ_QPAD & ~keep[k])) : qw[k];
                             if (n_only) {   // q -> q + 49 where a transferred record holds an N: column 49 + (q - 33)
                                 const uint32_t w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
@@ -1302,7 +1282,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                         }
 #pragma unroll
                         for (uint32_t k = 0; k < 4; ++k) {
-                            if (tails && !__any(nv > 4 * k)) continue;
+                            if (!wany[k]) continue;
                             const uint32_t e0 = e[4 * k], e1 = e[4 * k + 1], e2 = e[4 * k + 2], e3 = e[4 * k + 3];
                             const uint32_t l1 = e1 & 31u, l2 = e2 & 31u, l3 = e3 & 31u;
                             const uint32_t tl = (e0 & 31u) + l1 + l2 + l3;
@@ -1318,7 +1298,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                                 uint32_t x = 0;
 #pragma unroll
                                 for (uint32_t k = 0; k < 4; ++k)
-                                    x = (x << 8) | ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24);
+                                    if (wany[k]) x |= ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24) << (24 - 8 * k);
                                 wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
                             }
                         } else if (short_codes) {
@@ -1490,10 +1470,10 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 // Records per workgroup: enough to amortise the table fill / histogram flush (1024), but never so many that the job
 // has fewer than ~8 workgroups per CU - long reads mean few records per byte, and a 1024-record workgroup of
 // 150-bp reads left the 256 CUs with four workgroups each.  (NGSC_SQ_RECORDS_PER_WG overrides.)
-static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024, const char *own_env = nullptr, uint32_t min_wgs = 2048)
+static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t most = 1024, uint32_t min_wgs = 2048)
 {
-    // (developer knobs: NGSC_SQ_RECORDS_PER_WG for the three kernels together, NGSC_SQ_RPW_STATS / _MEASURE / _PACK for one)
-    const char *e = own_env && getenv(own_env) ? getenv(own_env) : getenv("NGSC_SQ_RECORDS_PER_WG");
+    // (NGSC_SQ_RECORDS_PER_WG: the tests make small inputs walk several tiles per workgroup with it)
+    const char *e = getenv("NGSC_SQ_RECORDS_PER_WG");
     const uint32_t forced = e ? (uint32_t)atoi(e) : 0;
     if (forced) return forced < SR_THREADS ? SR_THREADS : forced / SR_THREADS * SR_THREADS;
     const uint64_t records = (uint64_t)max_rec * A.n_sb;   // upper estimate of the job's records
@@ -1506,22 +1486,18 @@ static uint32_t sr_records_per_wg(const Arena &A, uint32_t max_rec, uint32_t mos
 
 // NB chunks fetched back to back (BURST) - measured per 400 MB: 150-base reads statistics 0.41 -> 0.25 ms and measure
 // 0.39 -> 0.27 ms, 36..300-base reads 0.34 -> 0.31 and 0.33 -> 0.31 ms, 36-base reads unchanged; the pack kernel gets
-// slower with it and keeps one chunk per trip.  Used when the longest read exceeds 64 bases; NGSC_SQ_BURST=0|1 forces.
+// slower with it and keeps one chunk per trip.  Used when the longest read exceeds 64 bases.
 static bool sr_burst(const Arena &A)
 {
-    static const int forced = getenv("NGSC_SQ_BURST") ? atoi(getenv("NGSC_SQ_BURST")) : -1;
-    if (forced >= 0) return forced != 0;
     return A.qrows - 1 > 16 * NB;   // reads that one trip of NB chunks does not cover anyway
 }
 
-// The staged form (see k_sq_stats_reg): NGSC_SQ_STAGED=0|1 forces; by default for jobs whose 64-record spans fit 10 KB of LDS
+// The staged form (see k_sq_stats_reg): for jobs whose 64-record spans fit 10 KB of LDS
 // per wave (records of up to ~160 bytes: reads of up to ~50 bases), where three workgroups still share a CU.
 static bool sr_staged(const Arena &A, uint32_t max_rec_bytes, uint32_t &span_cap)
 {
     span_cap = (64u * max_rec_bytes + 48u + 1023u) & ~1023u;
-    static const int forced = getenv("NGSC_SQ_STAGED") ? atoi(getenv("NGSC_SQ_STAGED")) : -1;
-    if (sr_burst(A) || !max_rec_bytes || span_cap > (24u << 10)) return false;
-    if (forced >= 0) return forced != 0;
+    if (sr_burst(A) || !max_rec_bytes) return false;
     return span_cap <= (10u << 10);
 }
 
@@ -1530,7 +1506,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     uint32_t rows = A.qrows;
     const uint32_t max_rows = (60u << 10) / (SR_HSTRIDE * 4);
     if (rows > max_rows) rows = max_rows;
-    uint32_t rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS");
+    uint32_t rpw = sr_records_per_wg(A, max_rec, 1024);
     dim3 grid((max_rec + rpw - 1) / rpw, A.n_sb);
     uint32_t span_cap = 0;
     const bool staged = sr_staged(A, max_rec_bytes, span_cap);
@@ -1540,25 +1516,22 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     size_t lds = ((size_t)rows * SR_HSTRIDE + 64) * 4;
     if (staged) lds = ((lds + 15) & ~(size_t)15) + (size_t)(SR_THREADS / 64) * span_cap;
     else if (lds < (24u << 10)) lds = 24u << 10;
-    // (round 3) long reads whose whole table fits the packed LDS histogram: four lanes per record on staged spans
-    // (NGSC_SQ_MULTI=0: the burst form; =2 / 4 / 8: that many lanes per record)
+    // (round 3) long reads whose whole table fits the packed LDS histogram: four lanes per record on staged spans.
     // Only where the reads are about equally long (the job's average record is at least 3/4 of its longest): a record's lanes
     // walk ceil(chunks / 4) trips whatever the other records of the wave need, and on 36..150-base reads the form lost 25 %
-    // (0.39 -> 0.53 ms per 400 MB) where it gains 8 % on 150-base reads (0.324 -> 0.298)
+    // (0.39 -> 0.53 ms per 400 MB) where it gains 8 % on 150-base reads (0.324 -> 0.298; two and eight lanes per record: slower)
     const bool even = (uint64_t)A.buf_len / (n_rec_total ? n_rec_total : 1u) * 4 >= (uint64_t)max_rec_bytes * 3;
-    const int forced_any = getenv("NGSC_SQ_MULTI") ? atoi(getenv("NGSC_SQ_MULTI")) : -1;   // (read per call: the tests switch it)
-    if (!staged && sr_burst(A) && max_rec_bytes && (even || forced_any > 0)) {
-        const int forced = forced_any;
-        const uint32_t lpr = forced > 0 ? (uint32_t)forced : 4u;
+    if (!staged && sr_burst(A) && max_rec_bytes && even) {
+        constexpr uint32_t lpr = 4;
         const uint32_t mcap = ((64u / lpr) * max_rec_bytes + 48u + 1023u) & ~1023u;
         const uint32_t nslots = 8 * ((A.qrows + 14) / 16);
         const size_t mlds = ((((size_t)nslots * SR_HSTRIDE + 64) * 4 + 15) & ~(size_t)15) + (size_t)(SR_THREADS / 64) * mcap;
-        if (forced != 0 && (lpr == 2 || lpr == 4 || lpr == 8) && mlds <= (64u << 10)) {
+        if (mlds <= (64u << 10)) {
             // records per workgroup: batches of SR_THREADS / lpr
             const uint32_t rpb = SR_THREADS / lpr;
             uint32_t mrpw = rpw < rpb ? rpb : rpw / rpb * rpb;
             dim3 mgrid((max_rec + mrpw - 1) / mrpw, A.n_sb);
-            auto mk = lpr == 2 ? k_sq_stats_multi<2> : (lpr == 4 ? k_sq_stats_multi<4> : k_sq_stats_multi<8>);
+            auto mk = k_sq_stats_multi<lpr>;
             if (mlds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mk), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
             hipLaunchKernelGGL(mk, mgrid, dim3(SR_THREADS), mlds, st, A, A.qrows, mrpw, mcap);
             return;
@@ -1569,12 +1542,12 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
     // 256 / 512 / 1024 / 2048 records per workgroup 0.620 / 0.566 / 0.537 / 0.635 ms - the rule above chose 256)
     if (!staged && lds >= (40u << 10)) {
         const uint32_t resident = 256u * (uint32_t)((160u << 10) / lds);
-        rpw = sr_records_per_wg(A, max_rec, 1024, "NGSC_SQ_RPW_STATS", resident + resident / 2);
+        rpw = sr_records_per_wg(A, max_rec, 1024, resident + resident / 2);
         grid = dim3((max_rec + rpw - 1) / rpw, A.n_sb);
     }
     // 512 threads per workgroup for the staged form: eight spans beside one histogram, 80 KB, two workgroups = four waves per SIMD
-    // instead of three (44 KB x 3): +1 % on the step (496-500 against 482-492 GB/s).  NGSC_SQ_STATS_512=0: 256 threads
-    if (staged && !(getenv("NGSC_SQ_STATS_512") && !strcmp(getenv("NGSC_SQ_STATS_512"), "0"))) {
+    // instead of three (44 KB x 3): +1 % on the step (496-500 against 482-492 GB/s)
+    if (staged) {
         const size_t lds5 = ((((size_t)rows * SR_HSTRIDE + 64) * 4 + 15) & ~(size_t)15) + (size_t)8 * span_cap;
         const uint32_t rpw5 = rpw < 512 ? 512 : rpw / 512 * 512;
         dim3 grid5((max_rec + rpw5 - 1) / rpw5, A.n_sb);
@@ -1583,7 +1556,7 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
         hipLaunchKernelGGL(k5, grid5, dim3(512), lds5, st, A, rows, rpw5, span_cap);
         return;
     }
-    auto kern = staged ? k_sq_stats_reg<false, true> : (sr_burst(A) ? k_sq_stats_reg<true, false> : k_sq_stats_reg<false, false>);
+    auto kern = sr_burst(A) ? k_sq_stats_reg<true, false> : k_sq_stats_reg<false, false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, rpw, span_cap);
 }
@@ -1591,8 +1564,6 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
 // Arena::qfmt: per sub-block a dword table (a multiple of 4 dwords) and, behind all of those, a byte table (16-byte multiples)
 size_t sq_qfmt_words(uint32_t qrows) { return (((size_t)qrows + SQ_QROWS_EXTRA) * SQ_QS + 3) & ~(size_t)3; }
 size_t sq_qfmt_bytes(uint32_t qrows, uint32_t n_sb) { return (size_t)n_sb * (4 * sq_qfmt_words(qrows) + sq_qfmt8_stride(qrows)); }
-// the tables in their LDS layouts, once per sub-block (NGSC_SQ_QFMT=0: every workgroup gathers them from the code table itself)
-static bool sq_qfmt_on() { return !(getenv("NGSC_SQ_QFMT") && !strcmp(getenv("NGSC_SQ_QFMT"), "0")); }   // (read per call: the tests switch it)
 
 static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budget)
 {
@@ -1603,24 +1574,22 @@ static uint32_t sr_rows_for(uint32_t qrows, uint32_t entry_bytes, uint32_t budge
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
 {
     const uint32_t rows = sr_rows_for(A.qrows, 1, 32u << 10);
-    const uint32_t tpw = sr_records_per_wg(A, max_rec, 2048, "NGSC_SQ_RPW_MEASURE") / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec, 2048) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     auto kern = sr_burst(A) ? k_sq_measure_reg<true> : k_sq_measure_reg<false>;
-    const bool fmt = sq_qfmt_on();
-    if (fmt) {   // (here: behind the Huffman kernel, ahead of both readers)
+    {   // the tables in their LDS layouts, once per sub-block (here: behind the Huffman kernel, ahead of both readers)
         const uint32_t words = (uint32_t)(A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
         hipLaunchKernelGGL(k_sq_format_qtab, dim3((words + 4 * SR_THREADS - 1) / (4 * SR_THREADS), A.n_sb), dim3(SR_THREADS), 0, st, A);
     }
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw, fmt ? 1u : 0u);
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw);
 }
 
-// Long reads: a table of one window of positions (NGSC_SQ_WINDOW rows, a multiple of 16; 0 = never) once the whole table
-// would be well beyond a window (reads of 65 bases and more at the default of 48).
+// Long reads: a table of one window of 32 positions once the whole table would be well beyond a window (reads of 49 bases
+// and more; 32: 0.524 -> 0.453 ms per 400 MB of 36..300-base reads against 48, with the staging above)
 static uint32_t sr_pack_window(const Arena &A)
 {
-    const char *e = getenv("NGSC_SQ_WINDOW");
-    const uint32_t win = e ? (uint32_t)atoi(e) / 16 * 16 : 32;   // (32: 0.524 -> 0.453 ms per 400 MB of 36..300-base reads against 48, with the staging above)
-    return win && A.qrows > win + 1 + 16 ? win : 0;
+    const uint32_t win = 32;
+    return A.qrows > win + 1 + 16 ? win : 0;
 }
 
 void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t sw_q, uint32_t sw_d)
@@ -1629,7 +1598,7 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     const uint32_t rows = win ? win + 1 : sr_rows_for(A.qrows, 4, 48u << 10);
     if (sw_q > 8192) sw_q = 8192;
     if (sw_d > 6144) sw_d = 6144;
-    const uint32_t tpw = sr_records_per_wg(A, max_rec, 4096, "NGSC_SQ_RPW_PACK") / SR_THREADS;
+    const uint32_t tpw = sr_records_per_wg(A, max_rec, 4096) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     const size_t lds = ((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + sw_q + sw_d) * 4;
     // one chunk per trip: with NB chunks fetched back to back this kernel is 8-10 % slower on every configuration (it
@@ -1638,8 +1607,8 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     // mixed reads - 0.340 against 0.334 ms, 0.530 / 0.530 - and cost 16 % at 36 bases)
     auto kern = k_sq_pack_reg<false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
-    const bool fmt = sq_qfmt_on();   // (the tables: written by launch_sq_measure_reg's first kernel)
-    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win, fmt ? 1u : 0u);
+    // (the tables: written by launch_sq_measure_reg's first kernel)
+    hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win);
 }
 
 }  // namespace ngsc

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
     const uint32_t ls = A.ls[g], te = A.te[g];
 
     // parser state in integer registers; st bit0: non-digit seen, bit1: leading zero,
-    // bit3: differs from record 0
+    // bit2: the value exceeds 32 bits, bit3: differs from record 0
     uint32_t f = 0, k = 0, v = 0, stf = 0;
     fmask_t nummask = 0;
     uint32_t f0len = nf0 ? s_r0.len[0] : 0, f0start = nf0 ? s_r0.start[0] : 0;
@@ -242,7 +242,11 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
         const uint32_t c0 = s_r0.title[f0start + (inr ? k : 0)];
         const uint32_t nd = inr & (c != c0 ? 1u : 0u);
         stf |= (body & (dig ^ 1u)) | ((body & ld0) << 1) | (nd << 3);
-        v = (body & dig) ? v * 10 + d : v;                             // wraps like utils::to_num (utils.h:117-125)
+        if (body & dig) {                                              // wraps like utils::to_num (utils.h:117-125); bit 2: it has wrapped
+            const uint64_t t10 = (uint64_t)v * 10 + d;
+            stf |= (uint32_t)(t10 >> 32) ? 4u : 0u;
+            v = (uint32_t)t10;
+        }
         if (__any(nd)) {
             if (nd && owned && k < MAX_TEXT_LEN0) t_lds_or(&s_stat[f * FSTAT_WORDS + 10 + (k >> 5)], 1u << (k & 31));
         }
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
                                        a7 = st[7];
                         const uint32_t bv = bias((int32_t)v);
                         const bool n0 = len > a0, n1 = ~len > a1, n2 = !same && !a2, n3 = len != len0 && !a3,
-                                   n4 = !isn && !a4, n5 = isn && (v >> 31) && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
+                                   n4 = !isn && !a4, n5 = isn && ((v >> 31) || (stf & 4)) && !a5, n6 = isn && bv > a6, n7 = isn && ~bv > a7;
                         if (n0 | n1 | n2 | n3 | n4 | n5 | n6 | n7) {
                             if (n0) atomicMax(st + 0, len);
                             if (n1) atomicMax(st + 1, ~len);
@@ -937,12 +941,15 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A, uint32
             if (__any(isn && len > 8)) {
                 if (isn && len > 8) {   // nine digits and more: digit by digit, wrapping like utils::to_num (utils.h:117-125)
                     v = 0;
+                    bool big = false;
                     for (uint32_t j = 0; j < len; ++j) {
                         const uint32_t p = pos + j;
                         const uint32_t d = ((s_w[p >> 2][tid] >> (8 * (p & 3))) & 0xffu) - '0';
-                        v = v * 10 + d;
+                        const uint64_t t10 = (uint64_t)v * 10 + d;
+                        big = big || (uint32_t)(t10 >> 32) != 0;
+                        v = (uint32_t)t10;
                     }
-                    ovf = (v >> 31) != 0;   // what the reference ends up with as a negative int32
+                    ovf = big || (v >> 31) != 0;   // beyond INT32_MAX (parse_num): a negative int32 for the reference, or a value it stores modulo 2^32
                 }
             }
             if (kk < NUM_CAND_CAP && owned) A.tv[(size_t)kk * A.tw_stride + g + slot_bias] = v;   // k_title_measure_reg<true> and k_title_hist read it back
@@ -1032,9 +1039,8 @@ void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec, u
     if (z > 16 * W) z = 16 * W;
     if (z < 1) z = 1;
     uint32_t nfc = max_title < MAX_FIELDS ? (max_title < 1 ? 1u : max_title) : MAX_FIELDS;
-    if (getenv("NGSC_TS_FULL_LDS")) { z = 16 * W; nfc = MAX_FIELDS; }   // (round 2's footprint, for the comparison)
     const size_t lds = ((size_t)((nfc * 18 + 3) & ~3u) + (size_t)(z + 1) * TT_THREADS) * 4;
-    const uint32_t quad = getenv("NGSC_TS_QUAD") && !strcmp(getenv("NGSC_TS_QUAD"), "0") ? 0u : 1u;
+    const uint32_t quad = 1u;
     if (W == 2) hipLaunchKernelGGL(k_title_stats_swar<2>, grid, dim3(TT_THREADS), lds, st, A, z, nfc | (quad << 16));
     else hipLaunchKernelGGL(k_title_stats_swar<1>, grid, dim3(TT_THREADS), lds, st, A, z, nfc | (quad << 16));
 }

@@ -60,7 +60,8 @@ enum : int {
     ERR_ARG = -7,
     ERR_UNSUPPORTED = -8,  // engine limit exceeded (MAX_FIELDS, MAX_TEXT_LEN0, MAX_CODE_LEN, text slots)
     ERR_HIP = -9,
-    ERR_CAPACITY = -10     // output buffer too small
+    ERR_CAPACITY = -10,    // output buffer too small
+    ERR_SHAPE = -100       // inside the engine: the job is not of the shape its arrays were sized for (engine.cpp: JobShape) - run it again
 };
 
 enum : uint32_t { KIND_CONST = 0, KIND_NUM = 1, KIND_TEXT = 2 };
@@ -108,21 +109,26 @@ NGSC_HD uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x)
 NGSC_HD uint32_t bias(int32_t v) { return (uint32_t)v ^ 0x80000000u; }
 NGSC_HD int32_t unbias(uint32_t u) { return (int32_t)(u ^ 0x80000000u); }
 
-// utils::is_num + utils::to_num (utils.h:107-125).  v wraps like uint32; ovf is set when the true
-// value exceeds INT32_MAX (the reference then compares wrapped int32 values: unsupported).
+// utils::is_num + utils::to_num (utils.h:107-125).  v wraps like uint32 (what the reference goes on with); ovf is set when
+// the TRUE value exceeds INT32_MAX: the reference then either holds a negative int32 (wrapped value >= 2^31: it loops over a
+// negative count) or carries on with the value modulo 2^32 and writes a container that does not hold its input.  A varying
+// numeric field with such a value is refused (finalize_field: ERR_RANGE); a constant one is stored as text and never parsed.
 NGSC_HD bool parse_num(const uint8_t *b, uint32_t s, uint32_t e, uint32_t &v, bool &ovf)
 {
     uint32_t len = e - s;
     if (len == 0) return false;
     uint32_t acc = 0;   // wraps like utils::to_num (utils.h:117-125)
+    bool big = false;
     for (uint32_t i = s; i < e; ++i) {
         uint32_t d = (uint32_t)b[i] - '0';
         if (d > 9) return false;
-        acc = acc * 10 + d;
+        const uint64_t t = (uint64_t)acc * 10 + d;
+        big = big || (t >> 32) != 0;
+        acc = (uint32_t)t;
     }
     if (len > 1 && b[s] == '0') return false;
     v = acc;
-    ovf = (acc >> 31) != 0;   // the reference holds the value in an int32: negative from here on
+    ovf = big || (acc >> 31) != 0;
     return true;
 }
 
@@ -171,6 +177,13 @@ struct RankPlan {
     uint32_t done;         // the rank is finished
 };
 
+// The shape a step's arrays and grids were sized for (engine.cpp: JobShape): k_init_sb holds the job against it.
+struct ShapeCaps {
+    uint32_t n_rec_total, S, max_rec, rec_bound;
+    uint64_t slots, groups, tiles;
+    uint32_t max_title, max_q, max_rec_bytes;
+};
+
 // A rank taken up in the middle (all zero / null: from its first record).
 struct PlanResume {
     uint64_t next_pos, bytes_read, bsize;
@@ -185,7 +198,7 @@ struct FieldStat {
     uint32_t not_const;     // some record differs from record 0
     uint32_t not_len_const;
     uint32_t not_num;
-    uint32_t ovf;           // some numeric value >= 2^31
+    uint32_t ovf;           // some numeric value > INT32_MAX (parse_num)
     uint32_t max_v, inv_min_v;  // biased int32
     uint32_t max_d, inv_min_d;  // biased int32 (deltas between consecutive records)
     uint32_t not_ham[16];   // bit p set: some record differs from record 0 at position p (< 512 = REC0_TITLE_CAP)

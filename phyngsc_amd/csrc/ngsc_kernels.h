@@ -19,7 +19,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
                           uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
-                          uint64_t buf_end_abs, hipStream_t validate_stream = nullptr);
+                          uint64_t buf_end_abs);
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes, uint32_t n_rec_total);
@@ -51,7 +51,8 @@ void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, ui
 void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done);   // scan_tile + sizes + offsets
 void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap, uint64_t cleared = 0);   // cleared: leading bytes that are zero already
 void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes);
-void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R);
+void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
+                    const ShapeCaps &caps, const uint32_t *total_lines, const uint32_t *max_title, const uint32_t *max_q, const uint32_t *max_rec_bytes);
 void launch_write_headers(hipStream_t st, const Arena &A, const uint32_t *qrow_off);
 void launch_pack_lentable(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_pack_sq(hipStream_t st, const Arena &A, uint32_t max_rec);

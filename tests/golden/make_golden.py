@@ -227,6 +227,25 @@ def small_cases():
     add("title_text_first_300", "".join(rec(f"@L{i % 3} {long_text(i)} {i}", rand_seq(rng5, 40), rand_qual(rng5, 40)) for i in range(420)), [2])
     add("title_fields_80", "".join(rec(f"@F{i}:" + ":".join(str((i * (k + 1) + k) % (3 + k % 7)) if k % 5 else "c" for k in range(79)),
                                        rand_seq(rng5, 36), rand_qual(rng5, 36)) for i in range(900)), [2, 3])
+    # round 4: what only the randomised runs had caught (7241c91): a quality alphabet reaching past 'Q' - the raw bytes 82..89 would
+    # land on the table columns of a transferred N's quality - together with N bases that are transferred (quality '!'..'(') and N /
+    # IUPAC bases that keep their place (any other quality), at 36 bases (one tile, short last chunk) and 100 bases (windowed tables)
+    rng6 = random.Random(20261008)
+
+    def wide_q_with_n(n, L):
+        out = []
+        for i in range(n):
+            seq = list(rand_seq(rng6, L))
+            qual = [chr(rng6.choice([73, 73, 73, 80, 81, 82, 83, 85, 88, 89, 90, 95, 104, 126]) if rng6.random() < 0.8 else rng6.randint(41, 126)) for _ in range(L)]
+            kind = i % 4            # 0: no N, 1: transferred N, 2: N that keeps its place, 3: both kinds of record mixed with IUPAC
+            for _ in range(0 if kind == 0 else rng6.choice([1, 1, 2, 5])):
+                p = rng6.randrange(L)
+                seq[p] = "N" if kind != 3 else rng6.choice("NNRYK")
+                qual[p] = chr(rng6.randint(33, 40)) if kind == 1 or (kind == 3 and rng6.random() < 0.5) else chr(rng6.choice([82, 85, 89, 41, 73]))
+            out.append(rec(f"@w.{i + 1}", "".join(seq), "".join(qual)))
+        return "".join(out)
+    add("qual_past_Q_with_N_36", wide_q_with_n(2400, 36), [2, 3])
+    add("qual_past_Q_with_N_100", wide_q_with_n(1000, 100), [2])
     return cases
 
 
@@ -310,9 +329,15 @@ def main():
                     man["ranks"][str(P)] = ngsc_format.manifest(f.read())
             with open(os.path.join(HERE, f"manifest_{name}.json"), "w") as f:
                 json.dump(man, f, indent=1, sort_keys=True)
-    if not only or "small" in only:
-        with open(os.path.join(HERE, "index.json"), "w") as f:
-            json.dump(index["small"], f, indent=1, sort_keys=True)
+    if index["small"]:
+        idx_path = os.path.join(HERE, "index.json")
+        merged = {}
+        if only and "small" not in only and os.path.exists(idx_path):   # a partial run keeps the other cases' entries
+            with open(idx_path) as f:
+                merged = json.load(f)
+        merged.update(index["small"])
+        with open(idx_path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

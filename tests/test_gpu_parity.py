@@ -127,7 +127,7 @@ def test_no_dense_copies_against_oracle(eng, monkeypatch, name, cfg, size, P):
 
 
 PATH_CASES = ["err_2000rec.p4", "n_mixed.p3", "n_keep.p2", "title_text.p4", "title_numeric.p3", "title_long.p2",
-              "varlen.p5", "qual_wide.p2", "dna_1sym.p2"]
+              "varlen.p5", "qual_wide.p2", "dna_1sym.p2", "qual_past_Q_with_N_36.p3", "qual_past_Q_with_N_100.p2"]
 
 
 @pytest.mark.parametrize("sq_path", ["reg", "dense", "wave"])
@@ -153,21 +153,16 @@ def test_kernel_paths_agree(eng, monkeypatch, sq_path):
         assert ok, f"{name} (sq_path={sq_path}): {msg}"
 
 
-ROUND3_SWITCHES = [("NGSC_TS_QUAD", "0"), ("NGSC_TS_FULL_LDS", "1"), ("NGSC_SQ_STATS_512", "0"), ("NGSC_SQ_NO_TAIL", "1"),
-                   ("NGSC_NO_EARLY_ZERO", "1"), ("NGSC_CV_VEC", "1"), ("NGSC_CV_NOCACHE", "1"), ("NGSC_CV_SPLIT", "1"),
-                   ("NGSC_SQ_MULTI", "0"), ("NGSC_SQ_MULTI", "2"), ("NGSC_SQ_MULTI", "8"), ("NGSC_OVERLAP", "0"), ("NGSC_OVERLAP", "3"),
-                   ("NGSC_SQ_QFMT", "0"), ("NGSC_HUFF_LDS", "1"), ("NGSC_HUFF_BLOB_SERIAL", "1"), ("NGSC_SQ_RPW_STATS", "256"), ("NGSC_SQ_RPW_PACK", "512")]
+SCHEDULE_SWITCHES = [("NGSC_OVERLAP", "0"), ("NGSC_NO_SPEC", "1"), ("NGSC_SQ_RECORDS_PER_WG", "256"), ("NGSC_SQ_RECORDS_PER_WG", "512")]
 
 
-@pytest.mark.parametrize("switch", ROUND3_SWITCHES, ids=[f"{k}={v}" for k, v in ROUND3_SWITCHES])
-def test_round3_switches_agree(eng, monkeypatch, switch):
-    """Every alternative form round 3 left behind a switch - a lane's own title loads instead of the quad-cooperative ones, round 2's
-    LDS footprint of the title statistics, 256-thread staged statistics, 16-byte last chunks in the copies, no early clearing,
-    the validation pass with 16-byte loads / on its own stream, the planner without its LDS cache, the statistics kernels for long
-    reads with 1 / 2 / 8 lanes per record, the serial and the early-fork schedules, the pack kernel gathering its code table itself, small Huffman trees built in LDS / with their blobs written serially, other workgroup sizes of the statistics and
-    pack kernels - reproduces the reference on committed goldens
-    and the oracle on generated 36-base, 150-base and mixed-length inputs (two calls each: the second one runs on the first one's
-    arena and output hints)."""
+@pytest.mark.parametrize("switch", SCHEDULE_SWITCHES, ids=[f"{k}={v}" for k, v in SCHEDULE_SWITCHES])
+def test_schedule_switches_agree(eng, monkeypatch, switch):
+    """The forms of a step that are not a kernel choice by input: the serial schedule (what a per-kernel timing pass runs), every call
+    reading the job's shape back (NGSC_NO_SPEC=1: the first call's form; later calls predict it and enqueue the step in one go), and
+    other records-per-workgroup numbers of the sequence/quality kernels (small inputs otherwise never walk several tiles per workgroup)
+    - each reproduces the reference on committed goldens and the oracle on generated 36-base, 150-base and mixed-length inputs (three
+    calls each on one context: the later ones run on the first one's shape, arena and output hints)."""
     monkeypatch.setenv(*switch)
     for name in PATH_CASES:
         stem, P = name.rsplit(".p", 1)
@@ -181,7 +176,7 @@ def test_round3_switches_agree(eng, monkeypatch, switch):
     for cfg, size, P in ((fastq_gen.CFG2, 24_000_000, 4), (fastq_gen.CFG3, 30_000_000, 3), (fastq_gen.CFG5_300, 20_000_000, 5)):
         data = fastq_gen.generate(cfg, target_bytes=size)
         want, _ = orc.compress_file(data, P, threads=8)
-        for _ in range(2):
+        for _ in range(3):
             _, out = _gpu(eng, data, P)
             assert out == want, (switch, cfg)
 
@@ -782,19 +777,30 @@ def test_record_shared_by_two_ranks(eng):
     assert shared, "no rank split of this input shares a record: the test input lost its point"
 
 
-def test_numeric_title_values_wrap_like_the_reference(eng):
+def test_numeric_title_values_beyond_32_bits_are_refused(eng):
     """utils::to_num is uint32 arithmetic (utils.h:117-125): 8888888888 becomes 298954296, 21474836480 becomes 0, and the
-    reference goes on with those (the stream is lossy there, but defined - checked against the reference binary).  Only a
-    value that ends up >= 2^31, a negative int32 for the reference, is refused."""
+    reference goes on with those - its container holds the values modulo 2^32, not its input (checked against the reference
+    binary; the oracle restates that and counts such values).  The engine refuses a VARYING numeric field with digits beyond
+    int32 (NGSC_ERR_RANGE): whether the wrapped value lands below 2^31 or not, it never writes a container that loses data.
+    A constant field of that size is stored once as text and is fine."""
     import random
     rnd = random.Random(4)
-    vals = [b"8888888888", b"888888", b"21474836480", b"12", b"88888888888888"]
-    data = b"".join(b"@r.%d x %s y\n%s\n+\n%s\n" % (i, vals[i % len(vals)], bytes(rnd.choice(b"ACGT") for _ in range(36)),
-                                                     bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(3000))
-    _, out = _gpu(eng, data, 2)
-    want, _ = orc.compress_file(data, 2)
+    def make(vals):
+        return b"".join(b"@r.%d x %s y 99999999999\n%s\n+\n%s\n" % (i, vals[i % len(vals)], bytes(rnd.choice(b"ACGT") for _ in range(36)),
+                                                                    bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(3000))
+    fine = make([b"888888", b"12", b"2147483647"])
+    _, out = _gpu(eng, fine, 2)
+    want, _ = orc.compress_file(fine, 2)
     assert out == want
-    bad = data.replace(b"21474836480", b"3000000000")
+    for vals in ([b"8888888888", b"888888", b"12"], [b"21474836480", b"12"], [b"88888888888888", b"7"], [b"9999999999", b"1"]):
+        lossy = make(vals)
+        ref_like, _ = orc.compress_file(lossy, 2, as_reference=True)     # what the reference writes ...
+        assert orc.decompress(ref_like) != lossy                          # ... does not hold its input
+        with pytest.raises(orc.OracleError) as ei:
+            orc.compress_file(lossy, 2)
+        assert ei.value.rc == -5
+        _expect_error(eng, lossy, 2, -5)
+    bad = make([b"3000000000", b"12"])      # wraps to nothing: a negative int32 for the reference, which then loops
     with pytest.raises(orc.OracleError):
-        orc.compress_file(bad, 2)
+        orc.compress_file(bad, 2, as_reference=True)
     _expect_error(eng, bad, 2, -5)

@@ -64,7 +64,7 @@ def main():
             dtmp = tempfile.mkdtemp(prefix="ngsc_fuzz_drv_")
     t_end = time.time() + a.seconds
     seed = a.first_seed
-    n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = n_lossy = 0
+    n_ok = n_rej = n_bad = n_skip = n_crash = n_limit = 0
     total = 0
     last = time.time()
     while time.time() < t_end and seed < a.first_seed + a.seeds:
@@ -78,7 +78,9 @@ def main():
         _ln = data.split(b"\n")          # (quality lines may start with '@': count lines, do not look for "\n@")
         max_rec = max((sum(len(x) + 1 for x in _ln[k:k + 4]) for k in range(0, len(_ln) - 3, 4)), default=0)
         try:
-            ref, _ = orc.compress_file(data, d["P"], threads=8)
+            # (against the reference binary: the reference's own container also where it does not hold its input - numeric title
+            # values beyond 32 bits, stored modulo 2^32; against the engine such input is refused by both sides, rc -5)
+            ref, _ = orc.compress_file(data, d["P"], threads=8, as_reference=bool(a.reference))
             o_rc = 0
         except orc.OracleError as e:
             ref, o_rc = None, e.rc
@@ -168,13 +170,7 @@ def main():
                 with open(back, "rb") as f:
                     got = f.read()
                 if got != data:
-                    # The format itself loses a title whose numeric field exceeds 32 bits (the value is stored modulo 2^32:
-                    # seed 902976, "...=9999999999" comes back as "...=1410065407" from every decoder): what the container
-                    # holds is what the oracle's decoder makes of it.
-                    if got == orc.decompress(ref):
-                        n_lossy += 1
-                    else:
-                        verdict = "GPU decoder: decoded file differs from the input and from the oracle decoder's output"
+                    verdict = "GPU decoder: decoded file differs from the input"
             except api.NgscError as e:
                 if e.code != -4:
                     verdict = f"GPU decoder rc {e.code}"
@@ -192,8 +188,7 @@ def main():
                   flush=True)
         seed += 1
     print(f"fuzz: seeds {a.first_seed}..{seed - 1}: {n_ok} equal, {n_rej} rejected by both, {n_bad} mismatches, "
-          f"{n_skip} skipped, {n_crash} reference crashes, {n_limit} engine limits, {total / 1e6:.0f} MB of FASTQ"
-          + (f"; {n_lossy} containers that do not hold their input (GPU decoder = oracle decoder)" if n_lossy else ""), flush=True)
+          f"{n_skip} skipped, {n_crash} reference crashes, {n_limit} engine limits, {total / 1e6:.0f} MB of FASTQ", flush=True)
     if eng is not None:
         eng.close()
     sys.exit(1 if n_bad else 0)
