@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libngsc_hip.so")
+LIB_PATH = os.environ.get("NGSC_LIB_PATH") or os.path.join(_PKG, "libngsc_hip.so")   # (NGSC_LIB_PATH: another build, tools/ab_inproc.py)
 
 EXPORTS = [
     "ngsc_version", "ngsc_strerror", "ngsc_ctx_create", "ngsc_ctx_destroy", "ngsc_last_hip_error",

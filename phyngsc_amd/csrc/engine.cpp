@@ -72,6 +72,8 @@ struct ngsc_ctx {
     bool cs_retry = false;        // the job is run again on a copy in which colour-space reads are decoded
     uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
+    bool wide = false;            // titles of more than MAX_FIELDS separators: the job runs on the wide title kernels (kernels_title_wide.hip);
+                                  // found out by a first run, kept for the context's later jobs while they need it
     bool no_spec = getenv("NGSC_NO_SPEC") != nullptr;   // every call reads the job's shape back (the step's first-call form)
     JobShape shape;               // the last job's counts and maxima: the next call's prediction
     bool big_alphabets = false;   // the last call met a quality / base alphabet of more than 64 symbols (grid of the 512-symbol Huffman instance)
@@ -226,7 +228,8 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out)
     // slot frees up instead of taking turns with tens of thousands of queued ones
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const int side_prio = prio_hi;
+    const int xexp = getenv("NGSC_X") ? atoi(getenv("NGSC_X")) : 0;   // (experiment selector, removed before the round ends)
+    const int side_prio = (xexp & 1) ? prio_lo : prio_hi;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
         hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, side_prio) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -355,7 +358,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // space, text slots, a missed prediction - and not for a rank walked in parts, whose window count follows the buffer.)
     const bool time_all = c->profiling && c->profile_only.empty();
     const JobShape &last = c->shape;
-    const bool spec = last.valid && !c->no_spec && !c->cs_retry && !c->slot_retry && !part && !c->debug_sync &&
+    const bool spec = last.valid && !c->no_spec && !c->cs_retry && !c->slot_retry && !c->wide && !part && !c->debug_sync &&
                       last.file_size == file_size && last.P == P && last.n_ranks == n_ranks && last.part == 0 &&
                       buf_len <= last.buf_len + last.buf_len / 64 && last.buf_len <= buf_len + buf_len / 64;
 
@@ -364,7 +367,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
     Carver cs;
     size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
-    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4), o_done = cs.take(4), o_bigt = cs.take(4);
+    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4), o_done = cs.take(4), o_bigt = cs.take(4), o_wide = cs.take(4);
     size_t o_outtot = cs.take(8);
     size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
     size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
@@ -424,8 +427,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         if (out_prefix) launch_zero_range(c->side_stream, d_out, out_prefix);
         if (spec && prezero) launch_zero_range(c->side_stream, c->zero.p, prezero);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
-    } else if (out_prefix) {
-        KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix);
+    } else {
+        if (out_prefix) { KScope k(c, st, "k_zero_prefix"); launch_zero_range(st, d_out, out_prefix); }
+        if (spec && prezero) launch_zero_range(st, c->zero.p, prezero);
     }
     {
         KScope k(c, st, "k_cuts_validate");
@@ -501,12 +505,14 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- per-sub-block arena ----
     // Table slots for the non-constant text fields of all sub-blocks.  FASTQ titles have one or two such fields; a
     // call that needs more finds out from the slot counter and runs again with what it asked for.
-    const uint32_t n_slots = std::min<uint32_t>(S * MAX_FIELDS, std::max<uint32_t>({64u, 2 * S, c->min_text_slots}));
+    const bool wide = c->wide;
+    const uint32_t fcap = wide ? WIDE_FIELDS : MAX_FIELDS;   // fields per sub-block in the per-field arrays
+    const uint32_t n_slots = std::min<uint32_t>(S * fcap, std::max<uint32_t>({64u, 2 * S, c->min_text_slots}));
     Carver cz;  // zero-initialised every call
-    size_t z_fstat = cz.take(sizeof(FieldStat) * (size_t)S * MAX_FIELDS);
+    size_t z_fstat = cz.take(sizeof(FieldStat) * (size_t)S * fcap);
     size_t z_occ = cz.take(4 * (size_t)S * 256);
     size_t z_qhist = cz.take(4 * (size_t)S * qrows * 256);
-    size_t z_nhist = cz.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
+    size_t z_nhist = cz.take(4 * (size_t)S * fcap * MAX_NUM_HUF);
     size_t z_chist = cz.take(4 * (size_t)n_slots * TEXT_TREES * 256);
     size_t z_sb = cz.take(sizeof(SbState) * (size_t)S);   // (zero but for the four words k_init_sb writes)
     if (spec && (c->zero.p != prezero_ptr || cz.off > c->zero.cap || cz.off > prezero)) {
@@ -519,7 +525,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     rc = ensure(c, c->zero, cz.off);
     if (rc) return rc;
     Carver cp;
-    size_t p_fdesc = cp.take(sizeof(FieldDesc) * (size_t)S * MAX_FIELDS);
+    size_t p_fdesc = cp.take(sizeof(FieldDesc) * (size_t)S * fcap);
     size_t p_grplo = cp.take(4 * (size_t)S);
     size_t p_qcodes = cp.take(4 * (size_t)S * qrows * 256);
     size_t p_qfmt = cp.take(sq_qfmt_bytes(qrows, S));
@@ -529,9 +535,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     size_t p_dcodes = cp.take(4 * (size_t)S * 256);
     size_t p_dblob = cp.take((size_t)S * BLOB_SLOT_256);
     size_t p_dblen = cp.take(4 * (size_t)S);
-    size_t p_ncodes = cp.take(4 * (size_t)S * MAX_FIELDS * MAX_NUM_HUF);
-    size_t p_nblob = cp.take((size_t)S * MAX_FIELDS * BLOB_SLOT_512);
-    size_t p_nblen = cp.take(4 * (size_t)S * MAX_FIELDS);
+    size_t p_ncodes = cp.take(4 * (size_t)S * fcap * MAX_NUM_HUF);
+    size_t p_nblob = cp.take((size_t)S * fcap * BLOB_SLOT_512);
+    size_t p_nblen = cp.take(4 * (size_t)S * fcap);
     // records of up to 2 KB: one lane per record straight from global memory, 256 records per "tile" (kernels_sq.hip);
     // longer records, or NGSC_SQ_PATH=wave: the wave-per-record kernels of kernels_stats.hip / kernels_pack.hip (R = 0).
     // (The LDS-tiled and chunk-per-lane families of rounds 1-2 were slower on every configuration and are gone;
@@ -600,6 +606,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.nblob_len = (uint32_t *)(pb + p_nblen);
     A.slot_counter = d_slotc;
     A.big_trees = (uint32_t *)(sm + o_bigt);
+    A.wide_needed = (uint32_t *)(sm + o_wide);
+    A.fcap = fcap;
     A.slot_owner = (uint32_t *)(tb + t_owner);
     A.n_slots = n_slots;
     A.chist = (uint32_t *)(zb + z_chist);
@@ -686,13 +694,14 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
         return NGSC_OK;
     };
-    // titles of at most 128 bytes take the word-parallel kernels, with one or two 64-bit mask words (NGSC_TITLE_PATH=reg forces the byte-serial ones)
+    // titles of at most 128 bytes take the word-parallel kernels, with one or two 64-bit mask words (NGSC_TITLE_PATH=reg forces the
+    // byte-serial ones); a job with more than MAX_FIELDS separators in some first title the wide kernels (found out by a first run)
     const char *tp_env = getenv("NGSC_TITLE_PATH");
-    const bool t_swar = max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
+    const bool t_swar = !wide && max_title <= 128 && !(tp_env && !strcmp(tp_env, "reg"));
     // record 0's field table - one wave per sub-block, a serial walk over a title: 23 us - is needed by the title kernels
     // only: on the side stream, beside the sequence/quality statistics instead of in front of them
     if ((rc = fork_s())) return rc;
-    { KScope k(c, sts, "k_rec0_fields"); launch_rec0_fields(sts, A); }
+    if (!wide) { KScope k(c, sts, "k_rec0_fields"); launch_rec0_fields(sts, A); }
     if (stagger) HIPCHK(c, hipEventRecord(c->ev_zero, sts));
     if (sq_reg) { KScope k(c, st, "k_sq_stats_reg"); launch_sq_stats_reg(st, A, max_rec, max_rec_bytes, n_rec_total); }
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
@@ -702,13 +711,17 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
     if (sq_reg) { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
     else { KScope k(c, sts, "k_measure_sq"); launch_measure_sq(sts, A, max_rec); }
-    if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
-    else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
-    { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
-    { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
+    if (wide) { KScope k(c, st, "k_title_wide_stats"); launch_title_wide_stats(st, A, max_rec); }
+    else {
+        if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
+        else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
+        { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
+        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
+    }
     { KScope k(c, st, "k_huffman_fields"); launch_huffman_fields(st, A); }
     { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
-    { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
+    if (wide) { KScope k(c, st, "k_title_wide_measure"); launch_title_wide_measure(st, A, max_rec); }
+    else { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if ((rc = join_s())) return rc;
     if (R) { KScope k(c, st, "k_layout"); launch_layout(st, A, R, d_qrowoff, out_cap, d_outtot, d_done); }
     else {
@@ -732,7 +745,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // (measured and not kept: the title pack kernel - latency-bound, 0.11 ms alone - on the side stream BESIDE the payload pack
     // kernel.  The payload kernel then takes 0.55 ms instead of 0.40: it is bound by instruction issue and its LDS queue, and
     // what it shares it loses - 452 against 462 GB/s)
-    { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
+    if (wide) { KScope k(c, st, "k_title_wide_pack"); launch_title_wide_pack(st, A, max_rec); }
+    else { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
     if ((rc = join_s())) return rc;
     if (sq_reg) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
@@ -776,11 +790,17 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             for (uint32_t want = std::max(asked, 2 * n_slots);; want *= 2) {
                 c->min_text_slots = want;
                 r = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
-                if (r != NGSC_ERR_UNSUPPORTED || want >= S * MAX_FIELDS) break;
+                if (r != NGSC_ERR_UNSUPPORTED || want >= S * fcap) break;
             }
             c->slot_retry = false;
             return r;
         }
+    }
+    if (err3 == NGSC_ERR_UNSUPPORTED && *(uint32_t *)(h_small + o_wide) && !wide) {
+        // a first title with more than MAX_FIELDS separators: once more, on the wide title kernels (and so the context's next jobs)
+        c->wide = true;
+        HIPCHK(c, hipStreamSynchronize(c->side_stream));
+        return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
     }
     if ((err3 == NGSC_ERR_COLORSPACE || err4 == NGSC_ERR_COLORSPACE) && !c->cs_retry) {
         c->cs_retry = true;
@@ -832,6 +852,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         c->shape = seen;
     }
     c->res_sb.resize(S);
+    if (wide) {   // (the context goes back to the ordinary title kernels once a job has no such title any more)
+        uint32_t most = 0;
+        for (uint32_t s = 0; s < S; ++s) most = std::max(most, h_sb[s].nf);
+        if (most <= MAX_FIELDS) c->wide = false;
+    }
     c->qbits_x16 = c->dbits_x16 = 0;
     c->big_alphabets = false;
     for (uint32_t s = 0; s < S; ++s) {

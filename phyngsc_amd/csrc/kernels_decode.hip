@@ -26,7 +26,7 @@
 
 namespace ngsc {
 
-constexpr uint32_t DEC_MAX_FIELDS = 64;
+constexpr uint32_t DEC_MAX_FIELDS = 64;      // fields whose tables the head kernel keeps in LDS; a title with more (up to WIDE_FIELDS) has them in the sub-block's scratch pool
 
 // ---- MSB-first bit reader over global memory with a 64-bit window (bit_stream.h:92-147) ----
 // win holds the stream's bits [pos, pos + have) left aligned; pos + have is a multiple of 8 once the window has been
@@ -475,7 +475,7 @@ __device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *
     const uint32_t n = C.n;
     // ---- title header (cf. FetchTitleHeader tasks.cpp:625-735; value-coding trees as the encoder stores them, Q2b) ----
     const uint32_t nf = r.u32();
-    if (r.bad || nf == 0 || nf > DEC_MAX_FIELDS) return r.bad ? ERR_FORMAT : ERR_UNSUPPORTED;
+    if (r.bad || nf == 0 || nf > WIDE_FIELDS) return r.bad ? ERR_FORMAT : ERR_UNSUPPORTED;
     const uint32_t keep_from = num_values_kept_from(nf);
     for (uint32_t f = 0; f < nf && !r.bad; ++f) {
         DField &fd = F[f];
@@ -591,8 +591,9 @@ constexpr uint32_t DEC_TPTR_FIELDS = 4, DEC_TPTR_POS = 32;   // text-field table
 
 __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const VField *VF, uint32_t nvf, uint32_t nvw,
                                                     const DField *F, uint32_t *vtab, uint8_t *tchars, uint64_t tchar_cap, uint32_t *s_in,
-                                                    int32_t *s_prev, uint32_t *s_gv, const uint16_t *const *s_tptr)
+                                                    int32_t *s_prev, uint32_t *s_gv, const uint16_t *const *s_tptr, uint8_t *s_gfl)
 {
+    // s_gfl: the group flags of the varying fields from the 65th on (a byte each; the first 64 live in a register pair)
     const uint32_t lane = threadIdx.x;
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);
     const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
@@ -715,7 +716,9 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
     for (uint32_t g0 = 0; g0 < n && !bad; g0 += GROUP) {
         const uint32_t g1 = g0 + GROUP < n ? g0 + GROUP : n;
         uint64_t gmask = 0;
-        for (uint32_t k = 0; k < nvf; ++k) gmask |= (uint64_t)get(1) << k;
+        for (uint32_t k = 0; k < nvf && k < 64; ++k) gmask |= (uint64_t)get(1) << k;
+        for (uint32_t k = 64; k < nvf; ++k) { const uint32_t b = get(1); if (lane == 0) s_gfl[k] = (uint8_t)b; }
+        if (nvf > 64) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (uint32_t i = g0; i < g1 && !bad; ++i) {
             uint32_t *vrow = vtab + (size_t)i * nvw;
             const bool first = i == g0;
@@ -727,7 +730,7 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
                 const VFc c = ldc(k);
                 int32_t pv = (int32_t)U((uint32_t)s_prev[k]);
                 uint32_t x0 = U(s_gv[2 * k]), x1 = U(s_gv[2 * k + 1]);
-                do_field(k, c, pv, x0, x1, vrow, first, (gmask >> k) & 1);
+                do_field(k, c, pv, x0, x1, vrow, first, k < 64 ? (gmask >> k) & 1 : U(s_gfl[k]) != 0);
                 s_prev[k] = pv; s_gv[2 * k] = x0; s_gv[2 * k + 1] = x1;
             }
         }
@@ -771,10 +774,16 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     const uint32_t s = blockIdx.x;
     if (s >= n_sb) return;
     const uint32_t lane = threadIdx.x;
-    __shared__ DField s_F[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
-    __shared__ VField s_VF[DEC_MAX_FIELDS];
-    __shared__ int32_t s_prev[DEC_MAX_FIELDS];
-    __shared__ uint32_t s_gv[2 * DEC_MAX_FIELDS];
+    __shared__ DField s_F0[DEC_MAX_FIELDS];   // (a lone lane pays a full memory latency for every field it touches in global memory)
+    __shared__ VField s_VF0[DEC_MAX_FIELDS];
+    __shared__ int32_t s_prev0[DEC_MAX_FIELDS];
+    __shared__ uint32_t s_gv0[2 * DEC_MAX_FIELDS];
+    __shared__ uint8_t s_gfl[WIDE_FIELDS];
+    // (a title of more than DEC_MAX_FIELDS fields - up to WIDE_FIELDS, as the encoder takes them - has these four in the scratch pool)
+    __shared__ DField *s_Fp;
+    __shared__ VField *s_VFp;
+    __shared__ int32_t *s_prevp;
+    __shared__ uint32_t *s_gvp;
     __shared__ const uint16_t *s_tptr[DEC_TPTR_FIELDS * DEC_TPTR_POS];
     __shared__ uint32_t s_in[DEC_IN_DW + 4];
     __shared__ DecCtl C;
@@ -830,7 +839,21 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     if (lane == 0) {
         r.seek(C.pos + (uint64_t)n * C.lt_bits);
         r.align();
-        C.err = dec_head(r, D, pool, O, s_F, C, stack);
+        {
+            const uint64_t at = r.pos;
+            const uint32_t nf_peek = r.u32();
+            r.seek(at);
+            s_Fp = s_F0; s_VFp = s_VF0; s_prevp = s_prev0; s_gvp = s_gv0;
+            if (!r.bad && nf_peek > DEC_MAX_FIELDS && nf_peek <= WIDE_FIELDS) {
+                s_Fp = (DField *)pool.take(sizeof(DField) * nf_peek);
+                s_VFp = (VField *)pool.take(sizeof(VField) * nf_peek);
+                s_prevp = (int32_t *)pool.take(4 * nf_peek);
+                s_gvp = (uint32_t *)pool.take(8 * nf_peek);
+            }
+        }
+        DField *const s_F = s_Fp;
+        VField *const s_VF = s_VFp;
+        C.err = (s_Fp && s_VFp && s_prevp && s_gvp) ? dec_head(r, D, pool, O, s_F, C, stack) : (int)ERR_NOMEM;
         if (!C.err) {
             const uint32_t nf = C.nf;
             AField *af = (AField *)pool.take(sizeof(AField) * nf);
@@ -868,8 +891,8 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     {
         const uint64_t vbytes = O.tchar_off;
         const uint64_t room = D.tcap - vbytes - 2 * C.qual_total;   // what is left for the text fields' characters (32 bytes kept for alignment)
-        dec_title_body_wave(r.p, r.nbits, C, s_VF, s_nv[0], s_nv[1], s_F, (uint32_t *)D.titles, D.titles + vbytes, room > 64 ? room - 64 : 0, s_in,
-                            s_prev, s_gv, s_tptr);
+        dec_title_body_wave(r.p, r.nbits, C, s_VFp, s_nv[0], s_nv[1], s_Fp, (uint32_t *)D.titles, D.titles + vbytes, room > 64 ? room - 64 : 0, s_in,
+                            s_prevp, s_gvp, s_tptr, s_gfl);
     }
     if (C.err) { if (lane == 0) O.err = C.err; return; }
     const uint64_t tp3 = wall_clock64();

@@ -187,7 +187,7 @@ __device__ void build_tree_regs(TreeLdsSmall &T, uint32_t n_in)
     tree_sync();
 }
 
-// grid: (qrows + 1 [+ MAX_FIELDS], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
+// grid: (qrows + 1 [+ fields], n_sb); block: 64 threads (one wave).  SMALL: the quality and DNA trees of the
 // sub-blocks whose alphabets fit 64 symbols; the other instance does the rest (numeric title fields, big alphabets).
 template <bool SMALL, class Tree>
 __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_t s, uint32_t t)
@@ -227,10 +227,10 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         if (SMALL) return;   // (never launched for these)
         const uint32_t f = t - A.qrows - 1;
         if (f >= sb.nf) return;
-        const FieldDesc &d = A.fdesc[(size_t)s * MAX_FIELDS + f];
+        const FieldDesc &d = A.fdesc[(size_t)s * A.fcap + f];
         if (d.kind != KIND_NUM || !d.has_huff) return;
         const uint32_t n = d.n_sym;
-        const size_t tix = (size_t)s * MAX_FIELDS + f;
+        const size_t tix = (size_t)s * A.fcap + f;
         const uint32_t *h = A.nhist + tix * MAX_NUM_HUF;
         for (uint32_t j = lane; j < n; j += 64) T.keys[j] = ((uint64_t)h[j] << 32) | j;
         build_tree_wave(T, n);
@@ -307,13 +307,7 @@ static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uin
     else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt);
 }
 
-void launch_huffman_sb(hipStream_t st, const Arena &A)
-{
-    launch_huffman_range(st, A, true, 0, A.qrows + 1);
-    launch_huffman_range(st, A, false, 0, A.qrows + 1 + MAX_FIELDS);
-}
-
-// The same trees in two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
+// Two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
 // sequence/quality statistics only, the numeric title field trees the title statistics only.
 void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected)
 {
@@ -325,7 +319,7 @@ void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected)
 }
 void launch_huffman_fields(hipStream_t st, const Arena &A)
 {
-    launch_huffman_range(st, A, false, A.qrows + 1, MAX_FIELDS);
+    launch_huffman_range(st, A, false, A.qrows + 1, A.fcap);
 }
 
 void launch_huffman_text(hipStream_t st, const Arena &A)

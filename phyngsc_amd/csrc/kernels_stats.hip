@@ -196,18 +196,18 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
     FieldDesc d;
     for (int k = 0; k < 3; ++k) d.pad[k] = 0;
     d.cand = A.rec0[s].kmap[f];
-    int rc = finalize_field(A.fstat[(size_t)s * MAX_FIELDS + f], p, e - p, buf[e], sb.n_rec, f, sb.nf, d);
+    int rc = finalize_field(A.fstat[(size_t)s * A.fcap + f], p, e - p, buf[e], sb.n_rec, f, sb.nf, d);
     if (rc == OK && d.kind == KIND_TEXT) {
         uint32_t slot = atomicAdd(A.slot_counter, 1u);
         if (slot >= A.n_slots) rc = ERR_UNSUPPORTED;
-        else { d.slot = slot; A.slot_owner[slot] = s * MAX_FIELDS + f; }
+        else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
     }
     if (rc) atomicMin(A.err, (int32_t)rc);
     // compact index among the non-constant fields (all lanes with f < nf are still here)
     unsigned long long ncm = __ballot(d.kind != KIND_CONST);
     d.kf = (uint32_t)__popcll(ncm & ((1ull << f) - 1ull));
     if (f == 0) A.sb[s].ncf = (uint32_t)__popcll(ncm);
-    A.fdesc[(size_t)s * MAX_FIELDS + f] = d;
+    A.fdesc[(size_t)s * A.fcap + f] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     if (wg_first >= n) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t *buf = A.buf;
-    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
+    const FieldDesc *fd = A.fdesc + (size_t)s * A.fcap;
 
     __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
     __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
                         if (k != 0xff) {
                             s_val[k][tid] = v;
                         } else if (owned) {  // more than 8 numeric Huffman fields: slow path, previous value re-parsed
-                            uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+                            uint32_t *nh = A.nhist + ((size_t)s * A.fcap + f) * MAX_NUM_HUF;
                             if (!d.delta_coding) {
                                 uint32_t idx = v - (uint32_t)d.min_v;
                                 if (idx < d.n_sym) atomicAdd(&nh[idx], i == 0 ? 2u : 1u);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
         const uint32_t k = s_k[f];
         if (k == 0xff || !((need >> f) & 1)) continue;
         if (fd[f].kind == KIND_NUM) {
-            uint32_t *nh = A.nhist + ((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF;
+            uint32_t *nh = A.nhist + ((size_t)s * A.fcap + f) * MAX_NUM_HUF;
             for (uint32_t x = tid; x < fd[f].n_sym; x += TS_THREADS)
                 if (s_nh[k][x]) atomicAdd(&nh[x], s_nh[k][x]);
         } else {

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
                     T.val0[nf0] = v;
                     T.ovf0[nf0] = o ? 1 : 0;
                     if (ncand < NUM_CAND_CAP) { km = (uint8_t)ncand; T.cand_f[ncand++] = (uint8_t)nf0; }
-                    else { km = 0xfe; A.fstat[(size_t)s * MAX_FIELDS + nf0].no_delta = 1; }
+                    else { km = 0xfe; A.fstat[(size_t)s * A.fcap + nf0].no_delta = 1; }
                 }
                 T.kmap[nf0] = km;
             }
@@ -191,7 +191,10 @@ __global__ __launch_bounds__(64) void k_rec0_fields(Arena A)
         T.nf0 = nf0;
         T.ncand = ncand;
         A.sb[s].nf = nf0;
-        if (nf0 > MAX_FIELDS) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
+        if (nf0 > MAX_FIELDS) {   // more separators than the field masks of these kernels hold: the job runs again on the wide title kernels
+            atomicOr(A.wide_needed, 1u);
+            atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);
+        }
     }
     __syncthreads();
     uint32_t *dst = reinterpret_cast<uint32_t *>(A.rec0 + s);
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_reg(Arena A)
         }
     }
     __syncthreads();
-    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
+    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * A.fcap);
     for (uint32_t kx = tid; kx < nf0 * FSTAT_WORDS; kx += TT_THREADS) {
         uint32_t x = s_stat[kx];
         if (!x) continue;
@@ -342,7 +345,7 @@ __device__ __forceinline__ void title_emit_cached(const uint8_t *rec, const Aren
             } else if (!((gconst >> f) & 1)) {
                 const uint32_t to_store = d.delta_coding ? (wc - C.prev[kf] - (uint32_t)d.min_d) : (wc - (uint32_t)d.min_v);
                 if (d.has_huff) {
-                    const uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                    const uint32_t e = A.ncodes[((size_t)s * A.fcap + f) * MAX_NUM_HUF + to_store];
                     w.put(e >> 5, e & 31);
                 } else {
                     w.put(to_store, d.bits_num);
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_measure_reg(Arena A)
     __shared__ uint32_t s_ntext;   // some non-constant field is a text field
 
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TT_THREADS)
-        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * A.fcap)[k];
     if (tid == 0) s_ntext = 0;
     __syncthreads();
     if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) {
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_pack_reg(Arena A)
 
     for (uint32_t k = tid; k < TP_STAGE_WORDS; k += TT_THREADS) s_stage[k] = 0;
     for (uint32_t k = tid; k < nf * (sizeof(FieldDesc) / 4); k += TT_THREADS)
-        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * MAX_FIELDS)[k];
+        reinterpret_cast<uint32_t *>(s_fd)[k] = reinterpret_cast<const uint32_t *>(A.fdesc + (size_t)s * A.fcap)[k];
     __syncthreads();
     if ((uint32_t)tid < nf && s_fd[tid].kind != KIND_CONST && s_fd[tid].kf < NCF_CAP) s_kf_field[s_fd[tid].kf] = (uint8_t)tid;
     __syncthreads();
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(TT_THREADS) void k_title_stats_swar(Arena A, uint32
         }
     }
     __syncthreads();
-    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * MAX_FIELDS);
+    uint32_t *gst = reinterpret_cast<uint32_t *>(A.fstat + (size_t)s * A.fcap);
     for (uint32_t kx = tid; kx < nf0 * SW; kx += TT_THREADS) {
         uint32_t x = s_stat[kx];
         if (!x) continue;

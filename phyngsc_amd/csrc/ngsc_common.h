@@ -30,8 +30,20 @@ constexpr uint32_t MAX_NUM_HUF = 512;       // MAX_NUM_VAL_HUF, tasks.cpp:27
 
 // ---- engine limits (inputs beyond them get NGSC_ERR_UNSUPPORTED, never a wrong stream) ------------
 constexpr uint32_t SMALL_TREE = 64;         // symbols of a tree the small Huffman instance builds (kernels_huffman.hip)
-constexpr uint32_t MAX_FIELDS = 64;         // separators per title (one bit each in the field masks, fmask_t)
+constexpr uint32_t MAX_FIELDS = 64;         // separators per title the word-parallel / cached title kernels take (one bit each in fmask_t)
 typedef uint64_t fmask_t;                   // a bit per title field
+constexpr uint32_t WIDE_FIELDS = 512;       // ... and what the wide title kernels take (kernels_title_wide.hip): a first title holds at most
+                                            // REC0_TITLE_CAP = 512 bytes, so it cannot have more separators
+// Field masks of the wide path: one bit per field in WIDE_FIELDS / 64 words
+struct WideMask { uint64_t w[WIDE_FIELDS / 64]; };
+NGSC_HD void fm_set(fmask_t &m, uint32_t f, uint32_t bit = 1u) { m |= (fmask_t)(bit & 1u) << f; }
+NGSC_HD uint32_t fm_get(const fmask_t &m, uint32_t f) { return (uint32_t)((m >> f) & 1u); }
+NGSC_HD void fm_or(fmask_t &a, const fmask_t &b) { a |= b; }
+NGSC_HD void fm_clear(fmask_t &m) { m = 0; }
+NGSC_HD void fm_set(WideMask &m, uint32_t f, uint32_t bit = 1u) { m.w[f >> 6] |= (uint64_t)(bit & 1u) << (f & 63u); }
+NGSC_HD uint32_t fm_get(const WideMask &m, uint32_t f) { return (uint32_t)((m.w[f >> 6] >> (f & 63u)) & 1u); }
+NGSC_HD void fm_or(WideMask &a, const WideMask &b) { for (uint32_t k = 0; k < WIDE_FIELDS / 64; ++k) a.w[k] |= b.w[k]; }
+NGSC_HD void fm_clear(WideMask &m) { for (uint32_t k = 0; k < WIDE_FIELDS / 64; ++k) m.w[k] = 0; }
 constexpr uint32_t MAX_TEXT_LEN0 = 512;     // record-0 length of a non-constant text field (Hamming mask bits): a whole first title (REC0_TITLE_CAP)
 constexpr uint32_t MAX_CODE_LEN = 26;       // packed code table entry = code << 5 | len
 constexpr uint32_t NCF_CAP = 8;             // non-constant title fields cached per record by the tiled path
@@ -299,25 +311,28 @@ struct Arena {
     uint32_t *tile_lo;      // per sub-block: first tile index
     int32_t *err;           // job error word (min over error codes)
     // per sub-block arrays (index by sub-block)
+    uint32_t fcap;          // fields per sub-block in fstat / fdesc / nhist / ncodes / nblob: MAX_FIELDS, or WIDE_FIELDS for a job
+                            // with a title of more than MAX_FIELDS separators (which the wide title kernels take)
+    uint32_t *wide_needed;  // set by k_rec0_fields when a first title has more than fcap separators: the job runs again, wide
     SbState *sb;
-    FieldStat *fstat;       // [S][MAX_FIELDS]
-    FieldDesc *fdesc;       // [S][MAX_FIELDS]
+    FieldStat *fstat;       // [S][fcap]
+    FieldDesc *fdesc;       // [S][fcap]
     Rec0Tab *rec0;          // [S]
     uint32_t *dna_occ;      // [S][256]
     uint32_t *qhist;        // [S][qrows][256]  row 0 = totals, row k+1 = position k
-    uint32_t *nhist;        // [S][MAX_FIELDS][512]
+    uint32_t *nhist;        // [S][fcap][512]
     uint32_t *qcodes;       // [S][qrows][256]  entry = code<<5|len, indexed by alphabet index
     uint8_t *qblob;         // [S][qrows][BLOB_SLOT_256]
     uint32_t *qblob_len;    // [S][qrows]
     uint32_t *dcodes;       // [S][256] indexed by raw base byte (plain: len 2)
     uint8_t *dblob;         // [S][BLOB_SLOT_256]
     uint32_t *dblob_len;    // [S]
-    uint32_t *ncodes;       // [S][MAX_FIELDS][512]
-    uint8_t *nblob;         // [S][MAX_FIELDS][BLOB_SLOT_512]
-    uint32_t *nblob_len;    // [S][MAX_FIELDS]
+    uint32_t *ncodes;       // [S][fcap][512]
+    uint8_t *nblob;         // [S][fcap][BLOB_SLOT_512]
+    uint32_t *nblob_len;    // [S][fcap]
     // text-field slot pool
     uint32_t *slot_counter;
-    uint32_t *slot_owner;   // [n_slots] -> sub-block * MAX_FIELDS + field
+    uint32_t *slot_owner;   // [n_slots] -> sub-block * fcap + field
     uint32_t n_slots;
     uint32_t *chist;        // [n_slots][129][256]
     uint32_t *tcodes;       // [n_slots][129][256]
@@ -477,7 +492,7 @@ NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
     const uint8_t *buf = A.buf;
     w.word(sb.nf);
     for (uint32_t f = 0; f < sb.nf; ++f) {
-        const FieldDesc &d = A.fdesc[(size_t)s * MAX_FIELDS + f];
+        const FieldDesc &d = A.fdesc[(size_t)s * A.fcap + f];
         w.byte((uint8_t)d.sep);
         w.byte(d.kind == KIND_CONST);
         if (d.kind == KIND_CONST) {
@@ -492,7 +507,7 @@ NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
             w.word((uint32_t)d.min_d);
             w.word((uint32_t)d.max_d);
             if (d.has_huff) {
-                size_t t = (size_t)s * MAX_FIELDS + f;
+                size_t t = (size_t)s * A.fcap + f;
                 uint32_t bl = A.nblob_len[t];
                 w.align();
                 w.word(bl);
@@ -522,31 +537,35 @@ NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
 // All functions take the byte buffer explicitly (`buf[pos]`, pos = offset inside the job buffer) so that a
 // kernel can hand in an LDS-resident tile (pointer rebased by the tile's first offset).
 
-struct TitleDiffs {
-    fmask_t txt, val, dlt;   // bit f set: field f of this record breaks the group's constancy
+template <class M>
+struct TitleDiffsT {
+    M txt, val, dlt;   // bit f set: field f of this record breaks the group's constancy
 };
+typedef TitleDiffsT<fmask_t> TitleDiffs;
 
 // Record at p_cur (not the group's first record) against the group's first record (p_first) and its
 // predecessor (p_prev): BlockDesc updates of tasks.cpp:63-81 and 127-147, plus the store-time rule that a
 // constant delta only counts when it equals min_delta (tasks.cpp:415).
-NGSC_HD TitleDiffs title_record_diffs(const uint8_t *buf, const FieldDesc *fd, uint32_t nf, uint32_t p_first,
-                                      uint32_t p_prev, uint32_t p_cur)
+template <class M = fmask_t>
+NGSC_HD TitleDiffsT<M> title_record_diffs(const uint8_t *buf, const FieldDesc *fd, uint32_t nf, uint32_t p_first,
+                                          uint32_t p_prev, uint32_t p_cur)
 {
-    TitleDiffs r = {0, 0, 0};
+    TitleDiffsT<M> r;
+    fm_clear(r.txt); fm_clear(r.val); fm_clear(r.dlt);
     uint32_t pf = p_first, pp = p_prev, pc = p_cur;
     for (uint32_t f = 0; f < nf; ++f) {
         uint32_t ef = field_end(buf, pf), ep = field_end(buf, pp), ec = field_end(buf, pc);
         const FieldDesc &d = fd[f];
         if (d.kind == KIND_TEXT) {
-            if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) r.txt |= (fmask_t)1 << f;
+            if (ec - pc != ef - pf || !bytes_equal(buf, pc, pf, ec - pc)) fm_set(r.txt, f);
         } else if (d.kind == KIND_NUM) {
             uint32_t vf = 0, vp = 0, vc = 0;
             bool o;
             parse_num(buf, pf, ef, vf, o);
             parse_num(buf, pp, ep, vp, o);
             parse_num(buf, pc, ec, vc, o);
-            if (vc != vf) r.val |= (fmask_t)1 << f;
-            if ((int32_t)(vc - vp) != d.min_d) r.dlt |= (fmask_t)1 << f;
+            if (vc != vf) fm_set(r.val, f);
+            if ((int32_t)(vc - vp) != d.min_d) fm_set(r.dlt, f);
         }
         pf = ef + 1; pp = ep + 1; pc = ec + 1;
     }
@@ -554,35 +573,37 @@ NGSC_HD TitleDiffs title_record_diffs(const uint8_t *buf, const FieldDesc *fd, u
 }
 
 // Group flag bits from the OR of its records' diffs.  bit f = the flag written for field f (1 = constant).
-NGSC_HD fmask_t title_group_const(const FieldDesc *fd, uint32_t nf, TitleDiffs g, uint32_t group_size)
+template <class M>
+NGSC_HD M title_group_const(const FieldDesc *fd, uint32_t nf, const TitleDiffsT<M> &g, uint32_t group_size)
 {
-    fmask_t gconst = 0;
+    M gconst;
+    fm_clear(gconst);
     for (uint32_t f = 0; f < nf; ++f) {
         const FieldDesc &d = fd[f];
         if (d.kind == KIND_CONST) continue;
         uint32_t flag;
-        if (d.kind == KIND_TEXT) flag = !((g.txt >> f) & 1);
+        if (d.kind == KIND_TEXT) flag = !fm_get(g.txt, f);
         else if (d.delta_coding) {
             // a one-record group keeps block_delta_constant == 0, which must equal min_delta (tasks.cpp:415)
-            flag = group_size == 1 ? (d.min_d == 0) : !((g.dlt >> f) & 1);
-        } else flag = !((g.val >> f) & 1);
-        gconst |= (fmask_t)flag << f;
+            flag = group_size == 1 ? (d.min_d == 0) : !fm_get(g.dlt, f);
+        } else flag = !fm_get(g.val, f);
+        fm_set(gconst, f, flag);
     }
     return gconst;
 }
 
 // The group's flag bits: one per non-constant field, in field order (tasks.cpp:401-425).
-template <class Sink>
-NGSC_HD void title_put_flags(const FieldDesc *fd, uint32_t nf, fmask_t gconst, Sink &w)
+template <class M, class Sink>
+NGSC_HD void title_put_flags(const FieldDesc *fd, uint32_t nf, const M &gconst, Sink &w)
 {
     for (uint32_t f = 0; f < nf; ++f)
-        if (fd[f].kind != KIND_CONST) w.put((uint32_t)((gconst >> f) & 1), 1);
+        if (fd[f].kind != KIND_CONST) w.put(fm_get(gconst, f), 1);
 }
 
 // One record's title bits (tasks.cpp:427-507).  first: it is the group's first record.
-template <class Sink>
+template <class M, class Sink>
 NGSC_HD void title_record_emit(const uint8_t *buf, const Arena &A, uint32_t s, const FieldDesc *fd, uint32_t nf,
-                               bool first, uint32_t p_prev, uint32_t p_cur, fmask_t gconst, Sink &w)
+                               bool first, uint32_t p_prev, uint32_t p_cur, const M &gconst, Sink &w)
 {
     uint32_t pp = p_prev, pc = p_cur;
     for (uint32_t f = 0; f < nf; ++f) {
@@ -594,18 +615,18 @@ NGSC_HD void title_record_emit(const uint8_t *buf, const Arena &A, uint32_t s, c
             parse_num(buf, pc, ec, vc, o);
             if (first) {
                 w.put(vc - (uint32_t)d.min_v, d.bits_val);               // tasks.cpp:457
-            } else if (!((gconst >> f) & 1)) {
+            } else if (!fm_get(gconst, f)) {
                 parse_num(buf, pp, ep, vp, o);
                 uint32_t to_store = d.delta_coding ? (vc - vp - (uint32_t)d.min_d) : (vc - (uint32_t)d.min_v);
                 if (d.has_huff) {
-                    uint32_t e = A.ncodes[((size_t)s * MAX_FIELDS + f) * MAX_NUM_HUF + to_store];
+                    uint32_t e = A.ncodes[((size_t)s * A.fcap + f) * MAX_NUM_HUF + to_store];
                     w.put(e >> 5, e & 31);
                 } else {
                     w.put(to_store, d.bits_num);
                 }
             }
         } else if (d.kind == KIND_TEXT) {
-            if (first || !((gconst >> f) & 1)) {                          // tasks.cpp:487
+            if (first || !fm_get(gconst, f)) {                            // tasks.cpp:487
                 uint32_t len = ec - pc;
                 if (!d.is_len_const) w.put(len - d.min_len, d.bits_len);
                 const uint32_t *tc = A.tcodes + (size_t)d.slot * TEXT_TREES * 256;
@@ -621,20 +642,21 @@ NGSC_HD void title_record_emit(const uint8_t *buf, const Arena &A, uint32_t s, c
     }
 }
 
-// One whole group, sequentially (used by the per-group fallback kernels and by the CPU harness).
-// g0/g1 are record indices inside the job's record table.
-template <class Sink>
+// One whole group, sequentially (the wide title kernels, one thread per group, and the CPU harness).
+// g0/g1 are record indices inside the job's record table.  M: the field mask type (fmask_t: up to MAX_FIELDS fields).
+template <class M = fmask_t, class Sink>
 NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, Sink &w)
 {
     const uint8_t *buf = A.buf;
-    const FieldDesc *fd = A.fdesc + (size_t)s * MAX_FIELDS;
+    const FieldDesc *fd = A.fdesc + (size_t)s * A.fcap;
     const uint32_t nf = A.sb[s].nf;
-    TitleDiffs acc = {0, 0, 0};
+    TitleDiffsT<M> acc;
+    fm_clear(acc.txt); fm_clear(acc.val); fm_clear(acc.dlt);
     for (uint32_t r = g0 + 1; r < g1; ++r) {
-        TitleDiffs d = title_record_diffs(buf, fd, nf, A.ls[g0], A.ls[r - 1], A.ls[r]);
-        acc.txt |= d.txt; acc.val |= d.val; acc.dlt |= d.dlt;
+        TitleDiffsT<M> d = title_record_diffs<M>(buf, fd, nf, A.ls[g0], A.ls[r - 1], A.ls[r]);
+        fm_or(acc.txt, d.txt); fm_or(acc.val, d.val); fm_or(acc.dlt, d.dlt);
     }
-    const fmask_t gconst = title_group_const(fd, nf, acc, g1 - g0);
+    const M gconst = title_group_const(fd, nf, acc, g1 - g0);
     title_put_flags(fd, nf, gconst, w);
     for (uint32_t r = g0; r < g1; ++r)
         title_record_emit(buf, A, s, fd, nf, r == g0, r > g0 ? A.ls[r - 1] : A.ls[r], A.ls[r], gconst, w);

@@ -38,7 +38,6 @@ void launch_field_finalize(hipStream_t st, const Arena &A);
 void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv);
 
 // ---- kernels_huffman.hip ----
-void launch_huffman_sb(hipStream_t st, const Arena &A);
 void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected = false);   // quality / DNA trees (both instances)
 void launch_huffman_fields(hipStream_t st, const Arena &A);
 void launch_huffman_text(hipStream_t st, const Arena &A);
@@ -63,5 +62,10 @@ void launch_title_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_title_stats_swar(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_title);
 void launch_title_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec, bool swar);
 void launch_title_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
+
+// ---- kernels_title_wide.hip (titles of more than MAX_FIELDS separators) ----
+void launch_title_wide_stats(hipStream_t st, const Arena &A, uint32_t max_rec);     // field count, statistics, field decisions, histograms
+void launch_title_wide_measure(hipStream_t st, const Arena &A, uint32_t max_rec);
+void launch_title_wide_pack(hipStream_t st, const Arena &A, uint32_t max_rec);
 
 }  // namespace ngsc

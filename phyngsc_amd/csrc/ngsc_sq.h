@@ -53,13 +53,15 @@ __device__ __forceinline__ uint32_t sr_amb_mask(const uint32_t (&sw)[4], uint32_
 }
 
 // One lane's MSB-first bit writer into LDS staging (or, for a tile whose stream outgrows the staging area,
-// straight into the zeroed output).  Fewer than 32 bits stay pending, so a put of up to 32 bits fits the
-// 64-bit accumulator; complete big-endian words leave with an OR (a lane's first and last word are shared).
+// straight into the zeroed output).  Fewer than 32 bits stay pending, right-aligned in a 32-bit accumulator; a put of
+// up to 32 bits completes at most one big-endian word, which leaves with an OR (a lane's first and last word are shared).
+// All 32-bit operations: the word is a funnel shift of (pending : new bits) - the 64-bit accumulator of rounds 1-3 paid
+// three 64-bit shifts per put, each several times the issue cost of a 32-bit instruction (tools/ubench_valu.hip).
 struct SqWriter {
     uint32_t *words;
     uint64_t widx;
-    uint64_t acc;
-    uint32_t nacc;
+    uint32_t acc;    // the pending bits (the bits above them are zero)
+    uint32_t nacc;   // how many: 0..31
     __device__ __forceinline__ void init(uint32_t *w, uint64_t word0, uint64_t bitpos)
     {
         words = w;
@@ -69,20 +71,23 @@ struct SqWriter {
     }
     __device__ __forceinline__ void put(uint32_t v, uint32_t nb)   // nb <= 32, v < 2^nb
     {
-        acc = (acc << nb) | v;
-        nacc += nb;
-        if (nacc >= 32) {
-            const uint32_t word = (uint32_t)(acc >> (nacc - 32));
+        const uint32_t tot = nacc + nb;
+        if (tot >= 32) {
+            // the string (acc : v) has tot bits; its first 32 are the word, the last r = tot - 32 (of v) stay pending
+            const uint32_t word = __builtin_amdgcn_alignbit(acc, v << ((32u - nb) & 31u), nacc);
             if (word) atomicOr(&words[widx], __builtin_bswap32(word));
             ++widx;
-            nacc -= 32;
-            acc &= (1ull << nacc) - 1ull;
+            nacc = tot - 32;
+            acc = __builtin_amdgcn_ubfe(v, 0u, nacc);
+        } else {
+            acc = (acc << nb) | v;
+            nacc = tot;
         }
     }
     __device__ __forceinline__ void finish()
     {
         if (nacc) {
-            const uint32_t word = (uint32_t)(acc << (32 - nacc));
+            const uint32_t word = acc << (32 - nacc);
             if (word) atomicOr(&words[widx], __builtin_bswap32(word));
             nacc = 0;
         }

@@ -66,11 +66,15 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
     ls[0] = ls0;
     for (uint32_t i = 0; i < n; ++i) ls[i + 1] = 2 * se[i] - te[i] + 3;
     const uint32_t nf = count_fields(buf, ls[0], te[0]);
-    if (nf > MAX_FIELDS) return ERR_UNSUPPORTED;
+    if (nf > WIDE_FIELDS) return ERR_UNSUPPORTED;
+    // (as the engine: the field arrays of a job with more than MAX_FIELDS separators are WIDE_FIELDS wide, and its title groups
+    // are walked with multi-word field masks)
+    const bool wide = nf > MAX_FIELDS;
+    const uint32_t fcap = wide ? WIDE_FIELDS : MAX_FIELDS;
 
     // ---- statistics (what k_title_stats accumulates) ----
-    std::vector<FieldStat> st(MAX_FIELDS);
-    memset(st.data(), 0, sizeof(FieldStat) * MAX_FIELDS);
+    std::vector<FieldStat> st(fcap);
+    memset(st.data(), 0, sizeof(FieldStat) * fcap);
     std::vector<uint32_t> prev(nf, 0);
     std::vector<uint8_t> prevnum(nf, 0);
     for (uint32_t r = 0; r < n; ++r) {
@@ -118,10 +122,10 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
     SbState sb;
     memset(&sb, 0, sizeof sb);
     sb.rec_lo = 0; sb.n_rec = n; sb.nf = nf;
-    std::vector<FieldDesc> fd(MAX_FIELDS);
-    std::vector<uint32_t> nhist((size_t)MAX_FIELDS * MAX_NUM_HUF, 0), ncodes((size_t)MAX_FIELDS * MAX_NUM_HUF, 0);
-    std::vector<uint8_t> nblob((size_t)MAX_FIELDS * BLOB_SLOT_512, 0);
-    std::vector<uint32_t> nblob_len(MAX_FIELDS, 0);
+    std::vector<FieldDesc> fd(fcap);
+    std::vector<uint32_t> nhist((size_t)fcap * MAX_NUM_HUF, 0), ncodes((size_t)fcap * MAX_NUM_HUF, 0);
+    std::vector<uint8_t> nblob((size_t)fcap * BLOB_SLOT_512, 0);
+    std::vector<uint32_t> nblob_len(fcap, 0);
     uint32_t n_slots = 0;
     for (uint32_t f = 0; f < nf; ++f) {
         uint32_t p = ls[0], e = 0;
@@ -182,6 +186,7 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
     A.ncodes = ncodes.data(); A.nblob = nblob.data(); A.nblob_len = nblob_len.data();
     A.tcodes = tcodes.data(); A.tblob = tblob.data(); A.tblob_len = tblob_len.data();
     A.n_sb = 1;
+    A.fcap = fcap;
     // ---- measure, then write (the two passes the kernels make) ----
     BitCounter hc;
     title_header(A, 0, hc);
@@ -189,7 +194,8 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
     std::vector<uint64_t> goff;
     for (uint32_t g0 = 0; g0 < n; g0 += GROUP) {
         BitCounter bc;
-        title_group(A, 0, g0, std::min(g0 + GROUP, n), bc);
+        if (wide) title_group<WideMask>(A, 0, g0, std::min(g0 + GROUP, n), bc);
+        else title_group(A, 0, g0, std::min(g0 + GROUP, n), bc);
         goff.push_back(total);
         total += bc.nbytes();
     }
@@ -200,7 +206,8 @@ int64_t h_title_stream(const uint8_t *buf, uint32_t buf_len, const uint32_t *te,
     uint32_t gi = 0;
     for (uint32_t g0 = 0; g0 < n; g0 += GROUP, ++gi) {
         ByteWriter w(out + goff[gi]);
-        title_group(A, 0, g0, std::min(g0 + GROUP, n), w);
+        if (wide) title_group<WideMask>(A, 0, g0, std::min(g0 + GROUP, n), w);
+        else title_group(A, 0, g0, std::min(g0 + GROUP, n), w);
         uint64_t expect = (gi + 1 < goff.size() ? goff[gi + 1] : total) - goff[gi];
         if (w.nbytes() != expect) return -101;
     }

@@ -51,8 +51,6 @@ def test_huffman_matches_oracle(seed):
 @pytest.mark.parametrize("fastq", FASTQS, ids=[os.path.basename(p)[:-6] for p in FASTQS])
 def test_title_stream_matches_oracle(fastq):
     """Whole file as one sub-block window: harness title stream == oracle title stream."""
-    if os.path.basename(fastq) == "title_fields_80.fastq":
-        pytest.skip("more than 64 title separators: beyond the engine's field masks (the engine returns NGSC_ERR_UNSUPPORTED)")
     data = np.fromfile(fastq, dtype=np.uint8)
     te, se, _ = orc.record_index(data, wsize=data.size, overlap=0)
     sub, inf = orc.subblock(data, wsize=data.size, overlap=0)

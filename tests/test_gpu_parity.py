@@ -49,9 +49,9 @@ def test_native_library_is_loaded():
         assert "libngsc_hip.so" in f.read()
 
 
-# reference outputs the engine still refuses (NGSC_ERR_UNSUPPORTED, never a different stream): titles with more than 64 separators
-BEYOND_ENGINE_LIMITS = ("title_fields_80",)
-SMALL_OK = [p for p in SMALL if not os.path.basename(p).startswith(BEYOND_ENGINE_LIMITS)]
+# (no committed reference output is beyond the engine any more: titles with more than 64 separators - title_fields_80 - run on the
+# wide title kernels since round 4)
+SMALL_OK = SMALL
 
 
 @pytest.mark.parametrize("ngsc_path", SMALL, ids=[os.path.basename(p) for p in SMALL])
@@ -61,11 +61,6 @@ def test_reference_goldens(eng, ngsc_path):
         data = f.read()
     with open(ngsc_path, "rb") as f:
         ref = f.read()
-    if os.path.basename(m.group(1)) in BEYOND_ENGINE_LIMITS:
-        with pytest.raises(api.NgscError) as ei:
-            _gpu(eng, data, int(m.group(2)))
-        assert ei.value.code == -8
-        return
     _, out = _gpu(eng, data, int(m.group(2)))
     ok, msg = nf.equivalent(ref, out)
     assert ok, msg
@@ -378,9 +373,21 @@ def test_colorspace_reads(eng):
     _expect_error(eng, _fq(400, seq="T0123A1230", qual="IIIIIIIIII"), 2, -1)
 
 
-def test_error_more_than_64_title_fields(eng):
-    # engine limit: 64 separators per title; the reference has none
-    _expect_error(eng, _fq(400, title=lambda i: "@" + ":".join(str((i + k) % 10) for k in range(66))), 2, -8)
+def test_titles_of_more_than_64_fields(eng):
+    """The reference has no field limit (phyNGSC.cpp:342-423); a title of more than 64 separators takes the wide title kernels
+    (found out by a first run that ends in the context's retry).  66 fields with varying / group-constant / constant numbers and a
+    text field, 200 single-digit fields, and - on the same context afterwards - an ordinary file again; the way back through the GPU
+    decoder as well.  (tests/golden/small/title_fields_80.* is the reference binary's own output for 80 fields.)"""
+    def title66(i):
+        return "@" + ":".join(("t" if (i // 50) % 2 else "uu") if k == 7 else str((i * (k + 1)) % 10 if k % 3 == 0 else ((i // 32) % 7 if k % 3 == 1 else k % 10))
+                              for k in range(66))
+    for data, P in ((_fq(3000, title=title66), 2),
+                    (_fq(1200, title=lambda i: "@" + "_".join(str((i >> (k % 11)) & 1) for k in range(200))), 3),
+                    (_fq(900, title=lambda i: f"@plain.{i} x"), 2)):
+        _, out = _gpu(eng, data, P)
+        want, _ = orc.compress_file(data, P)
+        assert out == want
+        assert api.decompress_bytes(out, engine=eng) == data
 
 
 def test_error_numeric_overflow(eng):
@@ -788,11 +795,11 @@ def test_numeric_title_values_beyond_32_bits_are_refused(eng):
     def make(vals):
         return b"".join(b"@r.%d x %s y 99999999999\n%s\n+\n%s\n" % (i, vals[i % len(vals)], bytes(rnd.choice(b"ACGT") for _ in range(36)),
                                                                     bytes(rnd.choice(b"5?IJ") for _ in range(36))) for i in range(3000))
-    fine = make([b"888888", b"12", b"2147483647"])
+    fine = make([b"888888", b"12", b"1000000000"])      # (values and delta range within int32)
     _, out = _gpu(eng, fine, 2)
     want, _ = orc.compress_file(fine, 2)
     assert out == want
-    for vals in ([b"8888888888", b"888888", b"12"], [b"21474836480", b"12"], [b"88888888888888", b"7"], [b"9999999999", b"1"]):
+    for vals in ([b"8888888888", b"888888", b"12"], [b"21474836480", b"12"], [b"88888888888888", b"7"], [b"9999999999", b"1410000000"]):
         lossy = make(vals)
         ref_like, _ = orc.compress_file(lossy, 2, as_reference=True)     # what the reference writes ...
         assert orc.decompress(ref_like) != lossy                          # ... does not hold its input

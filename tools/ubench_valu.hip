@@ -18,7 +18,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t a, uint32_t b, 
     else if (OP == 4) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x) : "v"(a));                 \
     else if (OP == 5) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(x));                               \
     else if (OP == 6) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));        \
-    else if (OP == 7) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+    else if (OP == 7) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));         \
+    else if (OP == 8) { uint64_t y = ((uint64_t)x << 32) | x; asm volatile("v_lshlrev_b64 %0, %1, %0" : "+v"(y) : "v"(a)); x = (uint32_t)(y >> 32); } \
+    else if (OP == 9) { uint64_t y = ((uint64_t)x << 32) | x; asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(y) : "v"(a)); x = (uint32_t)y; }         \
+    else if (OP == 10) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(x) : "v"(a));                    \
+    else if (OP == 11) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));            \
+    else if (OP == 12) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
         STEP(x0) STEP(x1) STEP(x2) STEP(x3) STEP(x4) STEP(x5) STEP(x6) STEP(x7)
     }
     out[blockIdx.x * 256 + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
@@ -54,5 +59,10 @@ int main()
     run<4>("v_lshl_or_b32", d);
     run<5>("v_bfe_u32", d);
     run<7>("v_alignbit_b32", d);
+    run<10>("v_lshlrev_b32", d);
+    run<11>("v_bfi_b32", d);
+    run<12>("v_and_or_b32", d);
+    run<8>("v_lshlrev_b64 (+mov)", d);
+    run<9>("v_lshrrev_b64 (+mov)", d);
     return 0;
 }
