@@ -438,8 +438,14 @@ def run_team(args):
     total_out = sum(int(sh.eng._L.ngsc_result_bytes(sh.eng._h)) for sh in shares)
     sh0.eng.set_profiling(False)
     mode = f"one process, team of {n} host threads / contexts" + (" (rehearsal: all on device 0)" if rehearse else "")
+    # the exchange by itself (every step ends in it): the same rows through the bare collective, timed apart from the compression
+    t1 = time.perf_counter()
+    for _ in range(20):
+        team.allgather_u64(rows.reshape(n, -1))
+    coll_ms = (time.perf_counter() - t1) / 20 * 1e3
     extra = {"rccl_ranks": team.rccl_ranks, "collective": team.describe, "collective_per_step": True,
-             "member_ms_last_step": [round(x, 3) for x in ms]}
+             "collective_ms_per_step": round(coll_ms, 4), "member_ms_last_step": [round(x, 3) for x in ms],
+             "member_exchange_ms_last_step": [round(x, 3) for x in team.exchange_ms()]}
     report(sh0, args, n, dt, total_raw, total_out, ktimes_all, dom, mode, extra)
     team.close()
 

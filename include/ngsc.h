@@ -234,8 +234,18 @@ const char *ngsc_team_describe(ngsc_team *team);  /* which collective a step use
  * host time of each member's part. */
 int ngsc_team_compress(ngsc_team *team, const ngsc_shard_t *shards, uint64_t file_size, uint32_t P, uint64_t *rows,
                        uint32_t row_len, double *shard_ms);
+/* Host time each member spent in the exchange of the last ngsc_team_compress (vote + H2D + collective + D2H; it includes waiting
+ * for the slowest member's compression): ms[team size]. */
+void ngsc_team_exchange_ms(ngsc_team *team, double *ms);
 /* The bare collective: member i contributes send[i * count .. ), receives all n * count words; recv: n x (n * count). */
 int ngsc_team_allgather_u64(ngsc_team *team, const uint64_t *send, uint32_t count, uint64_t *recv);
+/* The same from a thread of the caller's that acts as member `member` (ngsc_compress_file_multi's workers: every member calls, in
+ * the same order): send[count] -> recv[n * count].  status: 0, or the member's error - the members vote in host memory in front of
+ * the collective, and if any of them reports an error (or ngsc_team_abort() was called) NOBODY enters it and all return that
+ * code: a member that gave up cannot leave the others waiting in RCCL.  Replaces MPI_Gather / MPI_Gatherv, phyNGSC.cpp:964, 994. */
+int ngsc_team_member_allgather(ngsc_team *team, uint32_t member, int status, const uint64_t *send, uint32_t count, uint64_t *recv);
+/* A member that cannot go on (I/O error, allocation failure): everyone waiting in the team's collective, now or later, returns `code`. */
+void ngsc_team_abort(ngsc_team *team, int code);
 /* Offsets from rows (host): offsets[r * (row_len - 3) + k] = file offset of rank r's k-th block; cbo: WRID of every block
  * in file order (nullable); *end: where the footer goes. */
 int ngsc_rows_to_offsets(const uint64_t *rows, uint32_t P, uint32_t row_len, uint64_t file_size, uint64_t *offsets, uint32_t *cbo,

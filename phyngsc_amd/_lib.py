@@ -20,7 +20,7 @@ EXPORTS = [
     "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
     "ngsc_decompress_file", "ngsc_read_footer", "ngsc_read_header",
     "ngsc_team_create", "ngsc_team_destroy", "ngsc_team_size", "ngsc_team_rccl_ranks", "ngsc_team_describe",
-    "ngsc_team_compress", "ngsc_team_allgather_u64", "ngsc_rows_to_offsets",
+    "ngsc_team_compress", "ngsc_team_allgather_u64", "ngsc_team_member_allgather", "ngsc_team_abort", "ngsc_team_exchange_ms", "ngsc_rows_to_offsets",
 ]
 
 BLOCK_SIZE = 8 << 20
@@ -162,6 +162,9 @@ def lib():
     L.ngsc_team_describe.argtypes = [vp]
     L.ngsc_team_compress.restype = ctypes.c_int
     L.ngsc_team_compress.argtypes = [vp, ctypes.POINTER(Shard), u64, u32, ctypes.POINTER(u64), u32, ctypes.POINTER(ctypes.c_double)]
+    if hasattr(L, "ngsc_team_exchange_ms"):   # (an older build loaded through NGSC_LIB_PATH, tools/ab_inproc.py, may lack it)
+        L.ngsc_team_exchange_ms.restype = None
+        L.ngsc_team_exchange_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     L.ngsc_team_allgather_u64.restype = ctypes.c_int
     L.ngsc_team_allgather_u64.argtypes = [vp, ctypes.POINTER(u64), u32, ctypes.POINTER(u64)]
     L.ngsc_rows_to_offsets.restype = ctypes.c_int

@@ -236,6 +236,12 @@ class Team:
             raise NgscError(rc, "; ".join(self._L.ngsc_last_hip_error(e._h).decode() for e in self.engines))
         return np.frombuffer(rows, dtype=np.uint64).reshape(P, row_len).copy(), list(ms)
 
+    def exchange_ms(self):
+        """Host time of every member in the exchange of the last step (includes waiting for the slowest member's compression)."""
+        ms = (ctypes.c_double * self.n)()
+        self._L.ngsc_team_exchange_ms(self._h, ms)
+        return list(ms)
+
     def allgather_u64(self, send: np.ndarray) -> np.ndarray:
         """The bare collective: send[i] (count words) from member i; returns recv[i] = what member i received (n x count)."""
         send = np.ascontiguousarray(send, dtype=np.uint64)

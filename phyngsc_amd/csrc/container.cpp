@@ -286,8 +286,70 @@ struct Worker {
     ngsc_ctx *ctx = nullptr;
     uint32_t index = 0, n_workers = 1;
     int rc = NGSC_OK;
-    double io_s = 0, t_comp = 0, t_wait_in = 0, t_wait_out = 0, t_d2h = 0, t_write = 0;
+    double io_s = 0, t_comp = 0, t_wait_in = 0, t_wait_out = 0, t_d2h = 0, t_write = 0, t_xchg = 0;
+    // Several GPUs: no shared cursor.  The workers' groups of one ROUND (groups round * n .. round * n + n - 1, one per worker)
+    // meet in the team's collective - an RCCL all-gather of the block-size rows over the GPUs' communicator, the reference's
+    // MPI_Gather / MPI_Gatherv (phyNGSC.cpp:964, 994) - and every worker derives the same offsets from the same rows by a
+    // local prefix sum, writes its own blocks, and keeps the footer's tables (worker 0's copy is the one written).
+    ngsc_team *team = nullptr;
+    uint64_t cursor = 0;
+    std::vector<uint32_t> cbo, lbs, nblocks;
+    std::vector<int32_t> ov;
+    uint32_t n_sub_total = 0;
 };
+
+// words per rank row of the exchange: n_blocks, n_subblocks, overlap_used, block sizes (a rank's stream cannot be larger than
+// what the output buffers of its jobs hold: 1.25 x its region + 64 MiB a job)
+static uint32_t exchange_row_len(uint64_t FS, uint32_t P)
+{
+    const uint64_t region = FS / P + OVERLAP + 65536;
+    const uint64_t jobs = region / (64u << 20) + 2;
+    return 3 + (uint32_t)std::min<uint64_t>(1u << 20, (region + (region >> 2) + jobs * (64ull << 20)) / (NGSC_BLOCK_SIZE - 4096) + 4);
+}
+
+// One round of the exchange from worker w's writer thread.  mine: rpg rows of this worker's group (absent ranks: all zero), rc_in:
+// what the worker has to report.  On success the offsets of this worker's blocks are in my_off[rank slot][block], and the footer
+// tables / cursor have moved past the round's groups.
+static int exchange_round(Worker *w, uint32_t round, uint32_t rpg, uint32_t row_len, uint32_t P, uint32_t n_groups, int rc_in,
+                          const std::vector<uint64_t> &mine, std::vector<std::vector<uint64_t>> &my_off)
+{
+    const uint32_t n = w->n_workers, count = rpg * row_len;
+    std::vector<uint64_t> all((size_t)count * n);
+    const double t0 = now_s();
+    const int rc = ngsc_team_member_allgather(w->team, w->index, rc_in, mine.data(), count, all.data());
+    w->t_xchg += now_s() - t0;
+    if (rc) return rc;
+    my_off.assign(rpg, std::vector<uint64_t>());
+    for (uint32_t v = 0; v < n; ++v) {
+        const uint32_t g = round * n + v;
+        if (g >= n_groups) break;
+        const uint32_t r0 = g * rpg, nr = std::min(rpg, P - r0);
+        const uint64_t *rows = all.data() + (size_t)v * count;
+        uint64_t maxb = 0;
+        for (uint32_t k = 0; k < nr; ++k) {
+            const uint64_t nb = rows[(size_t)k * row_len];
+            if (nb > (uint64_t)row_len - 3) return NGSC_ERR_FORMAT;
+            maxb = std::max(maxb, nb);
+            if (v == w->index) my_off[k].resize(nb);
+        }
+        for (uint64_t b = 0; b < maxb; ++b)
+            for (uint32_t k = 0; k < nr; ++k) {
+                const uint64_t *row = rows + (size_t)k * row_len;
+                if (b >= row[0]) continue;
+                if (v == w->index) my_off[k][b] = w->cursor;
+                w->cursor += row[3 + b];
+                w->cbo.push_back(r0 + k);
+            }
+        for (uint32_t k = 0; k < nr; ++k) {
+            const uint64_t *row = rows + (size_t)k * row_len;
+            w->ov[r0 + k] = (int32_t)(int64_t)row[2];
+            w->lbs[r0 + k] = row[0] ? (uint32_t)row[3 + row[0] - 1] : 0;
+            w->nblocks[r0 + k] = (uint32_t)row[0];
+            w->n_sub_total += (uint32_t)row[1];
+        }
+    }
+    return NGSC_OK;
+}
 
 struct Pipe {
     std::mutex m;
@@ -336,7 +398,8 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                 for (uint64_t p = lo;; p = (p + part_limit - PART_OVERLAP) & ~15ull) {
                     uint64_t e = std::min<uint64_t>(rank_hi, p + part_limit);
                     if (e >= rank_end) e = rank_hi;   // the part that reaches the end of the region finishes the rank
-                    jobs.push_back({g, a, a + 1, p, e, true, first, false, g1 - g0 == 1, e == rank_hi});
+                    jobs.push_back({g, a, a + 1, p, e, true, first, false, g1 - g0 == 1 && !w->team, e == rank_hi});   // (several GPUs: a group's blocks
+                                                                                                               // are placed by the round's exchange, when the group is complete)
                     max_len = std::max(max_len, e - p);
                     first = false;
                     if (e == rank_hi) break;
@@ -358,7 +421,19 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
         }
         jobs.back().last_of_group = true;
     }
-    if (jobs.empty()) return;
+    const uint32_t n_rounds = (n_groups + w->n_workers - 1) / w->n_workers, row_len = w->team ? exchange_row_len(FS, P) : 0;
+    uint32_t rounds_done = 0;   // (by this worker's writer thread)
+    // a worker without a group in some round (the last one, or a file with fewer groups than GPUs) still takes part in the exchange
+    auto idle_rounds = [&](int status) {
+        if (!w->team) return;
+        std::vector<std::vector<uint64_t>> none;
+        const std::vector<uint64_t> zero((size_t)rpg * row_len, 0);
+        for (; rounds_done < n_rounds; ++rounds_done) {
+            const int r = exchange_round(w, rounds_done, rpg, row_len, P, n_groups, status, zero, none);
+            if (r) { if (!w->rc) w->rc = r; break; }
+        }
+    };
+    if (jobs.empty()) { idle_rounds(NGSC_OK); return; }
     const int nbuf = jobs.size() > 1 ? 2 : 1;
     void *d_in[2] = {nullptr, nullptr}, *h_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
     hipStream_t in_stream = nullptr, out_stream = nullptr;
@@ -379,6 +454,7 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
         // no reader or writer thread will ever run: nobody would end the wait below, and the other workers would wait for
         // this worker's groups in begin_group() - tell them, release what was allocated, and return the error
         sink->abort();
+        if (w->team) ngsc_team_abort(w->team, w->rc);
         for (int i = 0; i < 2; ++i) {
             if (d_in[i]) (void)hipFree(d_in[i]);
             if (h_in[i]) (void)hipHostFree(h_in[i]);
@@ -542,7 +618,35 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                             maxb = std::max<uint32_t>(maxb, (uint32_t)rb[k].size());
                             for (auto &b : rb[k]) gbytes += b.size;
                         }
-                        if (rc) break;
+                        if (rc && !w->team) break;
+                        if (w->team) {
+                            // ---- several GPUs: this group's rows into the round's exchange, offsets out of everybody's rows ----
+                            std::vector<uint64_t> mine((size_t)rpg * row_len, 0);
+                            for (size_t k = 0; k < acc.size() && !rc; ++k) {
+                                if (rb[k].size() + 3 > row_len || k >= rpg) { rc = NGSC_ERR_CAPACITY; break; }
+                                uint64_t *row = mine.data() + k * row_len;
+                                row[0] = rb[k].size();
+                                row[1] = acc[k].sb.size();
+                                row[2] = (uint64_t)(int64_t)acc[k].ov;
+                                for (size_t b = 0; b < rb[k].size(); ++b) row[3 + b] = rb[k][b].size;
+                            }
+                            std::vector<std::vector<uint64_t>> my_off;
+                            rc = exchange_round(w, jb.group / w->n_workers, rpg, row_len, P, n_groups, rc, mine, my_off);
+                            if (rc) break;
+                            rounds_done = jb.group / w->n_workers + 1;
+                            std::vector<WriteItem> items;
+                            for (size_t r = 0; r < acc.size(); ++r) {
+                                const uint8_t *stream = single_job_group ? hb + res.ranks[r].stream_off : acc[r].carry.data();
+                                for (size_t b = 0; b < rb[r].size(); ++b)
+                                    items.push_back({my_off[r][b], rb[r][b].header, rb[r][b].header_len, stream + rb[r][b].stream_off, rb[r][b].payload});
+                            }
+                            if (!write_items(sink->fd, items)) { rc = NGSC_ERR_IO; break; }
+                            acc.clear();
+                            w->t_write += now_s() - t0;
+                            { std::lock_guard<std::mutex> lk(pipe.m); pipe.written = (int)j + 1; }
+                            pipe.cv.notify_all();
+                            continue;
+                        }
                         if (!sink->begin_group(jb.group)) { rc = NGSC_ERR_IO; break; }
                         uint64_t off = sink->cursor;
                         sink->cursor += gbytes;
@@ -577,7 +681,11 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
                 { std::lock_guard<std::mutex> lk(pipe.m); pipe.written = (int)j + 1; }
                 pipe.cv.notify_all();
             }
-            if (rc) { pipe.fail(rc); sink->abort(); }
+            bool stopped;
+            { std::lock_guard<std::mutex> lk(pipe.m); stopped = pipe.abort; }
+            if (rc) { pipe.fail(rc); sink->abort(); if (w->team) ngsc_team_abort(w->team, rc); }
+            else if (stopped) { if (w->team) ngsc_team_abort(w->team, pipe.rc ? pipe.rc : (int)NGSC_ERR_IO); }   // (the reader or the compress thread gave up)
+            else idle_rounds(NGSC_OK);
         });
     }
     // ---- the worker thread itself: compress job after job ----
@@ -630,7 +738,7 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
     if (reader.joinable()) reader.join();
     if (writer.joinable()) writer.join();
     if (!w->rc && pipe.rc) w->rc = pipe.rc;
-    if (w->rc) sink->abort();
+    if (w->rc) { sink->abort(); if (w->team) ngsc_team_abort(w->team, w->rc); }
     const double t_free = now_s();
     for (int i = 0; i < 2; ++i) {
         if (d_in[i]) (void)hipFree(d_in[i]);
@@ -642,8 +750,8 @@ static void run_worker(Worker *w, Sink *sink, const char *in_path, uint64_t FS, 
     if (out_stream) (void)hipStreamDestroy(out_stream);
     if (getenv("NGSC_VERBOSE"))
         fprintf(stderr, "[ngsc] device %d: %zu jobs, buffers %.3f s (alloc, before the first job), waits: input %.3f s, output buffer %.3f s; "
-                        "compress %.3f s; beside it: file read %.3f s, D2H %.3f s, plan + write %.3f s; free %.3f s\n", dev, jobs.size(), t_alloc,
-                w->t_wait_in, w->t_wait_out, w->t_comp, w->io_s, w->t_d2h, w->t_write, now_s() - t_free);
+                        "compress %.3f s; beside it: file read %.3f s, D2H %.3f s, plan + write %.3f s (of it in the exchange of block rows: %.3f s); free %.3f s\n", dev, jobs.size(), t_alloc,
+                w->t_wait_in, w->t_wait_out, w->t_comp, w->io_s, w->t_d2h, w->t_write, w->t_xchg, now_s() - t_free);
 }
 
 int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_path, const char *out_path, uint32_t P,
@@ -674,11 +782,21 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     // the groups of the block order are dealt to the contexts in turn: group g to context g % n_ctx
     std::vector<Worker> workers(n_ctx);
     for (uint32_t i = 0; i < n_ctx; ++i) { workers[i].ctx = ctxs[i]; workers[i].index = i; workers[i].n_workers = n_ctx; }
+    ngsc_team *team = nullptr;
     if (n_ctx == 1) run_worker(&workers[0], &sink, in_path, FS, P);
     else {
+        // several GPUs: where a group's blocks land is agreed through the team's collective (RCCL over the GPUs' communicator;
+        // host memory when RCCL is not to be had - two contexts on one device, no library), not through a shared cursor
+        if (int trc = ngsc_team_create(ctxs, n_ctx, &team)) { ::close(sink.fd); return trc; }
+        if (getenv("NGSC_VERBOSE")) fprintf(stderr, "[ngsc] %u contexts, exchange of block rows: %s\n", n_ctx, ngsc_team_describe(team));
+        for (auto &w : workers) { w.team = team; w.ov.assign(P, 0); w.lbs.assign(P, 0); w.nblocks.assign(P, 0); }
         std::vector<std::thread> th;
         for (uint32_t i = 0; i < n_ctx; ++i) th.emplace_back(run_worker, &workers[i], &sink, in_path, FS, P);
         for (auto &t : th) t.join();
+        // (every worker holds the same tables: worker 0's go into the footer)
+        sink.cbo = workers[0].cbo; sink.ov = workers[0].ov; sink.lbs = workers[0].lbs; sink.nblocks = workers[0].nblocks;
+        sink.n_sub_total = workers[0].n_sub_total; sink.cursor = workers[0].cursor;
+        ngsc_team_destroy(team);
     }
     double t2 = now_s();
     int rc = NGSC_OK;

@@ -620,6 +620,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // measure and pack - when they stay within 2.5x the job (address space; only real chunks are touched).  NGSC_SQ_DENSE=0:
     // measure and pack read the file themselves, as in round 1
     A.dense_s = A.dense_q = nullptr;
+    A.dense_s2 = nullptr;
     A.dstride = 0;
     A.dtail_c = 0xffffffffu;
     A.dtail_b = 16;
@@ -631,12 +632,15 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             const uint32_t lc = (max_q - 1) / 16, rem = max_q - 16 * lc;   // last chunk of the longest read and its bytes
             if (rem <= 12) { tail_c = lc; tail_b = (rem + 3) & ~3u; stride = 16ull * lc + tail_b; }
         }
-        const uint64_t per_stream = (stride * (uint64_t)n_rec_total + 15) & ~15ull, need = 2 * per_stream;
-        if (!(de && !strcmp(de, "0")) && sq_reg && stride && need <= (uint64_t)len * 5 / 2) {
+        const uint64_t per_stream = (stride * (uint64_t)n_rec_total + 15) & ~15ull;
+        const uint64_t two_bit = ((uint64_t)((max_q + 15) / 16) * n_rec_total * 4 + 15) & ~15ull;   // a dword per chunk of bases
+        const uint64_t need = 2 * per_stream + two_bit;
+        if (!(de && !strcmp(de, "0")) && sq_reg && stride && need <= (uint64_t)len * 3) {
             rc = ensure(c, c->dense, (size_t)need + 64);
             if (rc) return rc;
             A.dense_s = (uint8_t *)c->dense.p;
             A.dense_q = A.dense_s + per_stream;
+            A.dense_s2 = (uint32_t *)(A.dense_q + per_stream);
             A.dstride = n_rec_total;
             A.dtail_c = tail_c;
             A.dtail_b = tail_b;

@@ -56,12 +56,32 @@ __device__ void build_tree_wave(Tree &T, uint32_t n)
         for (uint32_t j = 0; j < n; ++j) rank += T.keys[j] < k;
         T.sorted[rank] = k;
     }
+    // the passes over all n symbols with the whole wave (ngsc_common.h: huffman_zeros / _clear / _min_len), the merge, the code walk
+    // and the blob - over the symbols that are present - by lane 0
+    uint32_t zeros = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {   // sorted ascending: the zero frequencies are a prefix
+        const uint32_t i = i0 + lane;
+        const unsigned long long m = __ballot(i < n && (T.sorted[i < n ? i : 0] >> 32) == 0);
+        zeros += (uint32_t)__popcll(m);
+        if (m != ~0ull) break;
+    }
+    for (uint32_t i = lane; i < 2 * n - 1; i += 64) { T.code[i] = 0; T.len[i] = 0; }
     tree_sync();
+    int root = 0;
     if (lane == 0) {
         uint32_t mx = 0;
-        T.blob_len = huffman_sequential(T.sorted, n, T.ifreq, T.lc, T.rc, T.code, T.len, T.stack, T.blob, &mx);
+        root = huffman_core(T.sorted, n, zeros, T.ifreq, T.lc, T.rc, T.code, T.len, &mx);
         T.max_len = mx;
     }
+    tree_sync();
+    uint32_t min_len = n;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t l = T.len[i];
+        if (l > 0 && l < min_len) min_len = l;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)min_len, d); min_len = o < min_len ? o : min_len; }
+    if (lane == 0) T.blob_len = huffman_blob(n, root, min_len, T.lc, T.rc, T.stack, T.blob);
     tree_sync();
 }
 

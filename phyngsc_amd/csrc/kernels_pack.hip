@@ -259,6 +259,38 @@ __global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *
 
 // ---------------------------------------------------------------------------------------------------
 // Headers: info (19 B), title header, quality alphabet + trees, DNA alphabet + tree.
+// (round 4) The title header - field after field, a text field with up to 129 tree blobs of ~300 bytes - was ONE thread's
+// byte-by-byte walk (84 us per launch on titles with text fields, longer than the title pack kernel it runs beside).  Its
+// per-field parts are byte aligned (ngsc_common.h: title_header_field): a thread per field measures its part, a scan places
+// it, the thread writes it - and byte runs of 32 bytes and more (constant fields, tree blobs) are only queued, for the whole
+// workgroup to copy afterwards.
+struct HdrCopy { uint32_t dst, len; const uint8_t *src; };
+constexpr uint32_t HDR_JOBS = 640;
+struct DeferWriter {   // ByteWriter whose long byte runs go to the workgroup's copy queue
+    ByteWriter w;
+    uint8_t *base;
+    HdrCopy *jobs;
+    uint32_t *n_jobs;
+    __device__ DeferWriter(uint8_t *dst, uint8_t *b, HdrCopy *q, uint32_t *qn) : w(dst), base(b), jobs(q), n_jobs(qn) {}
+    __device__ void put(uint32_t v, uint32_t nb) { w.put(v, nb); }
+    __device__ void align() { w.align(); }
+    __device__ void byte(uint8_t b) { w.byte(b); }
+    __device__ void word(uint32_t v) { w.word(v); }
+    __device__ void bytes(const uint8_t *d, uint32_t len)
+    {
+        if (len >= 32) {
+            const uint32_t k = atomicAdd(n_jobs, 1u);
+            if (k < HDR_JOBS) {
+                w.align();
+                jobs[k] = HdrCopy{(uint32_t)((w.p + w.n) - base), len, d};
+                w.n += len;
+                return;
+            }
+        }
+        w.bytes(d, len);
+    }
+};
+
 __global__ __launch_bounds__(256) void k_write_headers(Arena A, const uint32_t *qrow_off)
 {
     if (*A.err) return;
@@ -266,20 +298,51 @@ __global__ __launch_bounds__(256) void k_write_headers(Arena A, const uint32_t *
     const SbState &sb = A.sb[s];
     const int tid = threadIdx.x;
     uint8_t *o = A.out + sb.out_off;
+    __shared__ HdrCopy s_jobs[HDR_JOBS];
+    __shared__ uint32_t s_njobs, s_wsum[4];
+    if (tid == 0) s_njobs = 0;
+    __syncthreads();
     if (tid == 0) {
         ByteWriter w(o);  // phyNGSC.cpp:719-731
         w.word(sb.n_rec); w.word(sb.max_q); w.word(sb.max_s);
         w.byte((uint8_t)sb.nsym); w.byte(0 /* QUALITY_PLAIN */); w.byte((uint8_t)sb.nqual);
         w.word(sb.flags);
-    } else if (tid == 64) {
-        ByteWriter w(o + sb.info_len);
-        title_header(A, s, w);
     } else if (tid == 128) {
         ByteWriter w(o + sb.info_len + sb.title_len + sb.qual_len);  // tasks.cpp:519-542
         w.bytes(sb.symbols, sb.nsym);
         if (!(sb.flags & F_DNA_PLAIN)) {
             w.word(A.dblob_len[s]);
             w.bytes(A.dblob + (size_t)s * BLOB_SLOT_256, A.dblob_len[s]);
+        }
+    }
+    // title header (tasks.cpp:302-390): fields tid, tid + 256, ... of the sub-block (more than 256: the wide title path)
+    {
+        uint8_t *th = o + sb.info_len;
+        uint32_t carry = 4;   // (the field count in front)
+        if (tid == 0) { ByteWriter w(th); w.word(sb.nf); }
+        for (uint32_t f0 = 0; f0 < sb.nf; f0 += 256) {
+            const uint32_t f = f0 + tid;
+            uint32_t size = 0;
+            if (f < sb.nf) { BitCounter bc; title_header_field(A, s, f, bc); size = (uint32_t)bc.nbytes(); }
+            uint32_t incl = wave_scan_incl_u32(size);
+            if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+            for (int w = 0; w < 4; ++w) { if (w < (tid >> 6)) before += s_wsum[w]; total += s_wsum[w]; }
+            if (f < sb.nf) {
+                DeferWriter w(th + carry + before + incl - size, o, s_jobs, &s_njobs);
+                title_header_field(A, s, f, w);
+            }
+            carry += total;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    {   // the queued byte runs: a wave each, 64 bytes a step
+        const uint32_t nj = s_njobs < HDR_JOBS ? s_njobs : HDR_JOBS;
+        for (uint32_t k = (uint32_t)tid >> 6; k < nj; k += 4) {
+            const HdrCopy j = s_jobs[k];
+            for (uint32_t x = (uint32_t)tid & 63u; x < j.len; x += 64) o[j.dst + x] = j.src[x];
         }
     }
     // quality header: alphabet, then one tree per row (tasks.cpp:577-605); threads stride over rows

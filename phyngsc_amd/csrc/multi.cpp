@@ -44,10 +44,9 @@ struct RcclApi {
     ncclResult_t (*GetVersion)(int *) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // (optional)
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok() const { return handle != nullptr; }
 };
@@ -73,10 +72,9 @@ RcclApi &rccl()
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
         api.CommCount = (decltype(api.CommCount))sym("ncclCommCount");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
-        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
         if (!all) { api.handle = nullptr; }
+        else api.CommAbort = (decltype(api.CommAbort))dlsym(api.handle, "ncclCommAbort");
     });
     return api;
 }
@@ -91,7 +89,7 @@ struct Member {
     size_t cap_words = 0;                            // capacity of d_send (d_recv: n x)
     std::vector<uint64_t> rows;                      // this member's view of all rows after a step
     int rc = NGSC_OK;
-    double ms = 0;
+    double ms = 0, xchg_ms = 0;   // host time of the member's last step / of the exchange inside it
 };
 
 }  // namespace
@@ -114,6 +112,9 @@ struct ngsc_team {
     std::condition_variable hcv;
     uint32_t arrived = 0;
     uint64_t gen = 0;
+    int vote = NGSC_OK, agreed = NGSC_OK;   // what the members have reported in the barrier being filled / in the last one
+    int aborted = NGSC_OK;                  // a member could not go on (ngsc_team_abort): nobody waits in a barrier any more
+    std::atomic<int> coll_failed{0};        // a member's part of the running collective failed: the others stop waiting for it
 };
 
 namespace {
@@ -151,19 +152,28 @@ void team_run(ngsc_team *t, std::function<void(uint32_t)> fn)
     t->cv_done.wait(lk, [&] { return t->pending == 0; });
 }
 
-// all members have arrived (host-memory barrier between the team's threads)
-void team_barrier(ngsc_team *t)
+// Host-memory barrier between the team's members that is also a vote: every member hands in its status (0 or an error code),
+// all of them leave with the first error handed in - or with the code of ngsc_team_abort(), which also ends the wait of
+// whoever is already inside.  A collective is entered only behind such a vote: no member can be left waiting in RCCL for a
+// peer that has given up.
+int team_vote(ngsc_team *t, int status)
 {
     std::unique_lock<std::mutex> lk(t->hm);
+    if (t->aborted) return t->aborted;
     const uint64_t g = t->gen;
+    if (status && !t->vote) t->vote = status;
     if (++t->arrived == t->m.size()) {
         t->arrived = 0;
+        t->agreed = t->vote;
+        t->vote = NGSC_OK;
         ++t->gen;
+        const int a = t->agreed;
         lk.unlock();
         t->hcv.notify_all();
-        return;
+        return a;
     }
-    t->hcv.wait(lk, [&] { return t->gen != g; });
+    t->hcv.wait(lk, [&] { return t->gen != g || t->aborted; });
+    return t->gen != g ? t->agreed : t->aborted;
 }
 
 int member_buffers(Member &mb, size_t words, uint32_t n)
@@ -182,48 +192,72 @@ int member_buffers(Member &mb, size_t words, uint32_t n)
 }
 
 // The collective, from member i's own thread: send[count] -> recv[n * count] (member order).  RCCL when the team has a
-// communicator, host memory otherwise.
-int member_allgather(ngsc_team *t, uint32_t i, const uint64_t *send, uint32_t count, uint64_t *recv)
+// communicator, host memory otherwise.  status: what the member has to report about its own step (0: fine).  Nobody enters
+// the collective unless every member is fine and has its buffers and its row on its GPU (a vote in host memory first);
+// inside, a member waits for its stream by polling, so that a failure on another member or ngsc_team_abort() ends the
+// wait (the communicator is aborted where the library allows it) instead of leaving it in hipStreamSynchronize for ever.
+int member_allgather(ngsc_team *t, uint32_t i, int status, const uint64_t *send, uint32_t count, uint64_t *recv)
 {
     const uint32_t n = (uint32_t)t->m.size();
     Member &mb = t->m[i];
-    if (t->rccl_ranks == n && n > 0) {
-        RcclApi &R = rccl();
-        if (hipSetDevice(mb.device) != hipSuccess || count > mb.cap_words) return NGSC_ERR_HIP;   // (buffers: team_reserve, before the step)
-        memcpy(mb.h_send, send, 8 * (size_t)count);
-        if (hipMemcpyAsync(mb.d_send, mb.h_send, 8 * (size_t)count, hipMemcpyHostToDevice, mb.stream) != hipSuccess) return NGSC_ERR_HIP;
-        const ncclResult_t nr = R.AllGather(mb.d_send, mb.d_recv, count, ncclUint64, mb.comm, mb.stream);
-        if (nr != ncclSuccess) { fprintf(stderr, "[ngsc] ncclAllGather: %s\n", R.GetErrorString(nr)); return NGSC_ERR_HIP; }
-        if (hipMemcpyAsync(mb.h_recv, mb.d_recv, 8 * (size_t)count * n, hipMemcpyDeviceToHost, mb.stream) != hipSuccess ||
-            hipStreamSynchronize(mb.stream) != hipSuccess)
-            return NGSC_ERR_HIP;
-        memcpy(recv, mb.h_recv, 8 * (size_t)count * n);
-        return NGSC_OK;
+    const bool use_rccl = t->rccl_ranks == n && n > 0;
+    if (const char *e = getenv("NGSC_TEST_FAIL_MEMBER"))   // (test hook: this member fails in front of the collective)
+        if (!status && atoi(e) == (int)i) status = NGSC_ERR_NOMEM;
+    if (use_rccl && !status) {
+        if (hipSetDevice(mb.device) != hipSuccess) status = NGSC_ERR_HIP;
+        else if ((status = member_buffers(mb, count, n)) == NGSC_OK) {
+            memcpy(mb.h_send, send, 8 * (size_t)count);
+            if (hipMemcpyAsync(mb.d_send, mb.h_send, 8 * (size_t)count, hipMemcpyHostToDevice, mb.stream) != hipSuccess ||
+                hipStreamSynchronize(mb.stream) != hipSuccess)
+                status = NGSC_ERR_HIP;
+        }
     }
-    {
+    if (!use_rccl && !status) {
         std::lock_guard<std::mutex> lk(t->hm);
         if (t->host_rows.size() < (size_t)count * n) t->host_rows.resize((size_t)count * n);
     }
-    team_barrier(t);   // (sized before anyone writes)
+    int rc = team_vote(t, status);   // (also: the host rows are sized before anyone writes)
+    if (rc) return rc;
+    if (use_rccl) {
+        RcclApi &R = rccl();
+        t->coll_failed.store(0);
+        rc = team_vote(t, NGSC_OK);  // (every member has reset the flag before anyone can raise it)
+        if (rc) return rc;
+        int mine = NGSC_OK;
+        const ncclResult_t nr = R.AllGather(mb.d_send, mb.d_recv, count, ncclUint64, mb.comm, mb.stream);
+        if (nr != ncclSuccess) { fprintf(stderr, "[ngsc] ncclAllGather: %s\n", R.GetErrorString(nr)); mine = NGSC_ERR_HIP; }
+        else if (hipMemcpyAsync(mb.h_recv, mb.d_recv, 8 * (size_t)count * n, hipMemcpyDeviceToHost, mb.stream) != hipSuccess) mine = NGSC_ERR_HIP;
+        if (mine) t->coll_failed.store(1);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!mine) {
+            const hipError_t q = hipStreamQuery(mb.stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { mine = NGSC_ERR_HIP; t->coll_failed.store(1); break; }
+            bool gone;
+            { std::lock_guard<std::mutex> lk(t->hm); gone = t->aborted != 0; }
+            if (gone || t->coll_failed.load() || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                mine = NGSC_ERR_HIP;
+                t->coll_failed.store(1);
+                if (R.CommAbort && mb.comm) { (void)R.CommAbort(mb.comm); mb.comm = nullptr; t->rccl_ranks = 0; }
+                break;
+            }
+            std::this_thread::yield();
+        }
+        if (!mine) memcpy(recv, mb.h_recv, 8 * (size_t)count * n);
+        return team_vote(t, mine);   // all leave with the same verdict
+    }
     memcpy(t->host_rows.data() + (size_t)i * count, send, 8 * (size_t)count);
-    team_barrier(t);
+    if ((rc = team_vote(t, NGSC_OK))) return rc;
     memcpy(recv, t->host_rows.data(), 8 * (size_t)count * n);
-    team_barrier(t);   // (read before the next step overwrites)
-    return NGSC_OK;
+    return team_vote(t, NGSC_OK);   // (read before the next step overwrites)
 }
 
-// Exchange buffers of every member, from the calling thread and BEFORE the members start: a member that failed to
-// allocate inside the step would leave the others waiting in the collective.
-int team_reserve(ngsc_team *t, size_t count)
-{
-    if (!t->rccl_ranks) return NGSC_OK;
-    for (auto &mb : t->m) {
-        if (hipSetDevice(mb.device) != hipSuccess) return NGSC_ERR_HIP;
-        const int rc = member_buffers(mb, count, (uint32_t)t->m.size());
-        if (rc) return rc;
-    }
-    return NGSC_OK;
-}
+// (the calling thread's device is left as it was found)
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 }  // namespace
 
@@ -234,6 +268,7 @@ int ngsc_team_create(ngsc_ctx **ctxs, uint32_t n_ctx, ngsc_team **out)
     if (!ctxs || !n_ctx || !out) return NGSC_ERR_ARG;
     for (uint32_t i = 0; i < n_ctx; ++i)
         if (!ctxs[i]) return NGSC_ERR_ARG;
+    DeviceGuard keep;
     ngsc_team *t = new ngsc_team();
     t->m.resize(n_ctx);
     std::vector<int> devs(n_ctx);
@@ -287,6 +322,7 @@ void ngsc_team_destroy(ngsc_team *t)
     }
     t->cv_go.notify_all();
     for (auto &th : t->threads) th.join();
+    DeviceGuard keep;
     RcclApi &R = rccl();
     for (auto &mb : t->m) {
         (void)hipSetDevice(mb.device);
@@ -301,13 +337,35 @@ uint32_t ngsc_team_size(ngsc_team *t) { return t ? (uint32_t)t->m.size() : 0; }
 uint32_t ngsc_team_rccl_ranks(ngsc_team *t) { return t ? t->rccl_ranks : 0; }
 const char *ngsc_team_describe(ngsc_team *t) { return t ? t->describe.c_str() : ""; }
 
+int ngsc_team_member_allgather(ngsc_team *t, uint32_t member, int status, const uint64_t *send, uint32_t count, uint64_t *recv)
+{
+    if (!t || member >= t->m.size() || !send || !recv || !count) return NGSC_ERR_ARG;
+    return member_allgather(t, member, status, send, count, recv);
+}
+
+void ngsc_team_exchange_ms(ngsc_team *t, double *ms)
+{
+    if (!t || !ms) return;
+    for (size_t i = 0; i < t->m.size(); ++i) ms[i] = t->m[i].xchg_ms;
+}
+
+void ngsc_team_abort(ngsc_team *t, int code)
+{
+    if (!t) return;
+    {
+        std::lock_guard<std::mutex> lk(t->hm);
+        if (!t->aborted) t->aborted = code ? code : NGSC_ERR_HIP;
+    }
+    t->coll_failed.store(1);
+    t->hcv.notify_all();
+}
+
 int ngsc_team_allgather_u64(ngsc_team *t, const uint64_t *send, uint32_t count, uint64_t *recv)
 {
     if (!t || !send || !recv || !count) return NGSC_ERR_ARG;
     const uint32_t n = (uint32_t)t->m.size();
     std::vector<std::vector<uint64_t>> got(n, std::vector<uint64_t>((size_t)count * n));
-    if (int rc = team_reserve(t, count)) return rc;
-    team_run(t, [&](uint32_t i) { t->m[i].rc = member_allgather(t, i, send + (size_t)i * count, count, got[i].data()); });
+    team_run(t, [&](uint32_t i) { t->m[i].rc = member_allgather(t, i, NGSC_OK, send + (size_t)i * count, count, got[i].data()); });
     for (uint32_t i = 0; i < n; ++i) {
         if (t->m[i].rc) return t->m[i].rc;
         memcpy(recv + (size_t)i * count * n, got[i].data(), 8 * (size_t)count * n);
@@ -325,7 +383,6 @@ int ngsc_team_compress(ngsc_team *t, const ngsc_shard_t *shards, uint64_t file_s
     for (uint32_t i = 0; i < n; ++i)
         if (shards[i].rank_lo != i * per || shards[i].rank_hi != (i + 1) * per) return NGSC_ERR_ARG;   // member i owns ranks [i P/n, (i+1) P/n)
     const uint32_t count = per * row_len;
-    if (int rc = team_reserve(t, count)) return rc;
     team_run(t, [&](uint32_t i) {
         Member &mb = t->m[i];
         const ngsc_shard_t &sh = shards[i];
@@ -359,9 +416,11 @@ int ngsc_team_compress(ngsc_team *t, const ngsc_shard_t *shards, uint64_t file_s
                 for (uint32_t k = 0; k < nb; ++k) row[3 + k] = blocks[k].size;
             }
         }
-        if (mb.rc) mine[0] = ~0ull;   // (the others learn of the failure through the exchange instead of waiting for it)
         mb.rows.resize((size_t)count * n);
-        const int xr = member_allgather(t, i, mine.data(), count, mb.rows.data());
+        // (a member whose step failed says so in the vote in front of the collective: nobody enters it then)
+        const auto tx = std::chrono::steady_clock::now();
+        const int xr = member_allgather(t, i, mb.rc, mine.data(), count, mb.rows.data());
+        mb.xchg_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tx).count();
         if (!mb.rc) mb.rc = xr;
         mb.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
@@ -393,7 +452,7 @@ int ngsc_rows_to_offsets(const uint64_t *rows, uint32_t P, uint32_t row_len, uin
         const uint32_t g1 = (uint32_t)std::min<uint64_t>(P, g0 + rpg);
         uint64_t maxb = 0;
         for (uint32_t r = g0; r < g1; ++r) {
-            if (rows[(size_t)r * row_len] + 3 > row_len) return NGSC_ERR_FORMAT;
+            if (rows[(size_t)r * row_len] > (uint64_t)row_len - 3) return NGSC_ERR_FORMAT;   // (also the all-ones word of a row nobody filled)
             maxb = std::max(maxb, rows[(size_t)r * row_len]);
         }
         for (uint64_t k = 0; k < maxb; ++k)

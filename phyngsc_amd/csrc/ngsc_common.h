@@ -347,6 +347,10 @@ struct Arena {
     // instead of 16 bytes each at addresses a whole record apart.  dstride == 0: off
     uint8_t *dense_s, *dense_q;
     uint32_t dstride;
+    // (round 4) the bases two bits each, a dword per 16-base chunk, chunk-major like the byte copies: chunk c of record g at
+    // dense_s2[c * dstride + g] (kernels_sq.hip: sq_keep_bases).  dense_s then holds only the chunks with something else than
+    // A / C / G / T in them
+    uint32_t *dense_s2;
     // (round 3) the LAST chunk of the job's longest read, when it holds at most 12 bytes (36 bases: 16 + 16 + 4), is kept as
     // dtail_b = 4 / 8 / 12 bytes per record instead of 16: chunk dtail_c of record g at dense_x + dtail_c * dstride * 16 + g * dtail_b
     // (a quarter of the copies' bytes at 36 bases).  dtail_c == 0xffffffff: every chunk is 16 bytes
@@ -484,53 +488,59 @@ NGSC_HD bool text_tree_needed(const FieldDesc &d, uint32_t j)
     return j == MAX_STAT_LEN && d.max_len >= MAX_STAT_LEN;
 }
 
-// Title header (tasks.cpp:302-390) written or measured through Sink.
+// Title header (tasks.cpp:302-390) written or measured through Sink: the field count, then one part per field.  Every part
+// starts and ends on a byte boundary (its own bit runs - a text field's Hamming mask - are closed by the align() calls), so the
+// parts can be measured independently and written at offsets from a prefix sum (kernels_pack.hip: k_write_headers).
+template <class Sink>
+NGSC_HD void title_header_field(const Arena &A, uint32_t s, uint32_t f, Sink &w)
+{
+    const uint8_t *buf = A.buf;
+    const FieldDesc &d = A.fdesc[(size_t)s * A.fcap + f];
+    w.byte((uint8_t)d.sep);
+    w.byte(d.kind == KIND_CONST);
+    if (d.kind == KIND_CONST) {
+        w.word(d.len0);
+        w.bytes(buf + d.start0, d.len0);
+        return;
+    }
+    w.byte(d.kind == KIND_NUM);
+    if (d.kind == KIND_NUM) {
+        w.word((uint32_t)d.min_v);
+        w.word((uint32_t)d.max_v);
+        w.word((uint32_t)d.min_d);
+        w.word((uint32_t)d.max_d);
+        if (d.has_huff) {
+            size_t t = (size_t)s * A.fcap + f;
+            uint32_t bl = A.nblob_len[t];
+            w.align();
+            w.word(bl);
+            w.bytes(A.nblob + t * BLOB_SLOT_512, bl);
+        }
+        return;
+    }
+    w.byte((uint8_t)d.is_len_const);
+    w.word(d.len0);
+    w.word(d.max_len);
+    w.word(d.min_len);
+    w.bytes(buf + d.start0, d.len0);
+    for (uint32_t j = 0; j < d.len0; ++j) w.put(ham_bit(d, j), 1);
+    for (uint32_t j = 0; j <= MAX_STAT_LEN; ++j) {
+        if (!text_tree_needed(d, j)) continue;
+        size_t t = (size_t)d.slot * TEXT_TREES + j;
+        uint32_t bl = A.tblob_len[t];
+        w.align();
+        w.word(bl);
+        w.bytes(A.tblob + t * BLOB_SLOT_256, bl);
+    }
+    w.align();
+}
+
 template <class Sink>
 NGSC_HD void title_header(const Arena &A, uint32_t s, Sink &w)
 {
     const SbState &sb = A.sb[s];
-    const uint8_t *buf = A.buf;
     w.word(sb.nf);
-    for (uint32_t f = 0; f < sb.nf; ++f) {
-        const FieldDesc &d = A.fdesc[(size_t)s * A.fcap + f];
-        w.byte((uint8_t)d.sep);
-        w.byte(d.kind == KIND_CONST);
-        if (d.kind == KIND_CONST) {
-            w.word(d.len0);
-            w.bytes(buf + d.start0, d.len0);
-            continue;
-        }
-        w.byte(d.kind == KIND_NUM);
-        if (d.kind == KIND_NUM) {
-            w.word((uint32_t)d.min_v);
-            w.word((uint32_t)d.max_v);
-            w.word((uint32_t)d.min_d);
-            w.word((uint32_t)d.max_d);
-            if (d.has_huff) {
-                size_t t = (size_t)s * A.fcap + f;
-                uint32_t bl = A.nblob_len[t];
-                w.align();
-                w.word(bl);
-                w.bytes(A.nblob + t * BLOB_SLOT_512, bl);
-            }
-            continue;
-        }
-        w.byte((uint8_t)d.is_len_const);
-        w.word(d.len0);
-        w.word(d.max_len);
-        w.word(d.min_len);
-        w.bytes(buf + d.start0, d.len0);
-        for (uint32_t j = 0; j < d.len0; ++j) w.put(ham_bit(d, j), 1);
-        for (uint32_t j = 0; j <= MAX_STAT_LEN; ++j) {
-            if (!text_tree_needed(d, j)) continue;
-            size_t t = (size_t)d.slot * TEXT_TREES + j;
-            uint32_t bl = A.tblob_len[t];
-            w.align();
-            w.word(bl);
-            w.bytes(A.tblob + t * BLOB_SLOT_256, bl);
-        }
-        w.align();
-    }
+    for (uint32_t f = 0; f < sb.nf; ++f) title_header_field(A, s, f, w);
 }
 
 // ---- 32-record title groups (tasks.cpp:393-509), decomposed per record --------------------------------
@@ -669,16 +679,34 @@ NGSC_HD void title_group(const Arena &A, uint32_t s, uint32_t g0, uint32_t g1, S
 // Inputs: sorted[n] = (freq << 32 | symbol) ascending.  Work arrays: ifreq[n], lc[2n], rc[2n], code[2n], len[2n],
 // stack[2n+2], blob (>= BLOB_SLOT bytes).  Outputs: code/len per node, blob bytes, returns blob length;
 // *max_len_out = longest code.
-NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t *ifreq, uint16_t *lc, uint16_t *rc,
-                                    uint32_t *code, uint8_t *len, uint16_t *stack, uint8_t *blob,
-                                    uint32_t *max_len_out)
+// The passes over all n symbols - counting the zero frequencies, clearing code / len, the shortest code - are split off
+// (huffman_zeros / huffman_clear / huffman_min_len) so that a wave can do them with all its lanes (kernels_huffman.hip: one
+// lane walking 256 or 512 LDS entries three times was most of a text or numeric-field tree's 80 us); what is left for ONE
+// lane is the merge, the top-down code walk and the pre-order blob over the symbols that are PRESENT (huffman_core).
+NGSC_HD uint32_t huffman_zeros(const uint64_t *sorted, uint32_t n)
 {
-    // compact: drop zero-frequency symbols while more than two remain (huffman.cpp:44-50)
     uint32_t zeros = 0;
     while (zeros < n && (sorted[zeros] >> 32) == 0) ++zeros;
+    return zeros;
+}
+NGSC_HD void huffman_clear(uint32_t *code, uint8_t *len, uint32_t n)
+{
+    for (uint32_t i = 0; i < 2 * n - 1; ++i) { code[i] = 0; len[i] = 0; }
+}
+NGSC_HD uint32_t huffman_min_len(const uint8_t *len, uint32_t n)
+{
+    uint32_t min_len = n;
+    for (uint32_t i = 0; i < n; ++i)
+        if (len[i] < min_len && len[i] > 0) min_len = len[i];
+    return min_len;
+}
+// merge + code walk: zeros = huffman_zeros(), code / len cleared.  Returns the root's node id.
+NGSC_HD int huffman_core(const uint64_t *sorted, uint32_t n, uint32_t zeros, uint32_t *ifreq, uint16_t *lc, uint16_t *rc, uint32_t *code,
+                         uint8_t *len, uint32_t *max_len_out)
+{
+    // compact: drop zero-frequency symbols while more than two remain (huffman.cpp:44-50)
     uint32_t drop = n > 2 ? (zeros < n - 2 ? zeros : n - 2) : 0;
     uint32_t present = n - drop;
-    for (uint32_t i = 0; i < 2 * n - 1; ++i) { code[i] = 0; len[i] = 0; }
     // merge (huffman.cpp:57-70) as a two-queue merge; ties go to the smaller node id and a leaf id is
     // always smaller than an internal id, which is the heap's (frequency, symbol) order
     uint32_t lq = drop, iq = 0, made = 0;
@@ -706,13 +734,14 @@ NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t
         if (l > mx) mx = l;
     }
     *max_len_out = mx;
-    // blob (huffman.cpp:88-118): root_id, n_symbols, min_len, pre-order bits
+    return root;
+}
+// blob (huffman.cpp:88-118): root_id, n_symbols, min_len, pre-order bits.  Returns its length.
+NGSC_HD uint32_t huffman_blob(uint32_t n, int root, uint32_t min_len, const uint16_t *lc, const uint16_t *rc, uint16_t *stack, uint8_t *blob)
+{
     uint32_t bits_per_id = 0;
     while ((2u << bits_per_id) <= n) ++bits_per_id;
     if (n & (n - 1)) ++bits_per_id;
-    uint32_t min_len = n;
-    for (uint32_t i = 0; i < n; ++i)
-        if (len[i] < min_len && len[i] > 0) min_len = len[i];
     ByteWriter w(blob);
     w.word((uint32_t)root);
     w.word(n);
@@ -732,6 +761,16 @@ NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t
     }
     w.align();
     return (uint32_t)w.nbytes();
+}
+// everything by one thread (the CPU harness)
+NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t *ifreq, uint16_t *lc, uint16_t *rc,
+                                    uint32_t *code, uint8_t *len, uint16_t *stack, uint8_t *blob,
+                                    uint32_t *max_len_out)
+{
+    const uint32_t zeros = huffman_zeros(sorted, n);
+    huffman_clear(code, len, n);
+    const int root = huffman_core(sorted, n, zeros, ifreq, lc, rc, code, len, max_len_out);
+    return huffman_blob(n, root, huffman_min_len(len, n), lc, rc, stack, blob);
 }
 
 // =====================================================================================================

@@ -487,6 +487,33 @@ def test_file_driver_worker_allocation_failure_is_an_error_not_a_hang(tmp_path, 
     assert (tmp_path / "ok.ngsc").read_bytes() == want
 
 
+@pytest.mark.timeout(300)
+def test_exchange_member_failure_is_an_error_not_a_hang(tmp_path, monkeypatch):
+    """The multi-GPU driver agrees on block offsets through the team's collective (RCCL over the contexts' communicator when
+    they sit on distinct GPUs, host memory otherwise).  A member that fails in front of the collective (forced here:
+    NGSC_TEST_FAIL_MEMBER) votes its error in host memory first, so nobody enters the collective and every worker - and the call
+    - returns the code instead of waiting for the missing rank for ever; the bare collective behaves the same."""
+    data = fastq_gen.generate(fastq_gen.CFG2, target_bytes=12_000_000)
+    inp = tmp_path / "in.fastq"
+    data.tofile(inp)
+    ndev = torch.cuda.device_count()
+    e0, e1 = api.Engine(0), api.Engine(1 % ndev)
+    monkeypatch.setenv("NGSC_TEST_FAIL_MEMBER", "1")
+    with pytest.raises(api.NgscError) as ei:
+        api.compress_file_multi([e0, e1], str(inp), str(tmp_path / "x.ngsc"), 8)
+    assert ei.value.code == -6
+    team = api.Team([e0, e1])
+    with pytest.raises(api.NgscError) as ei:
+        team.allgather_u64(np.array([[1, 2], [3, 4]], dtype=np.uint64))
+    assert ei.value.code == -6
+    monkeypatch.delenv("NGSC_TEST_FAIL_MEMBER")
+    assert team.allgather_u64(np.array([[1, 2], [3, 4]], dtype=np.uint64)).tolist() == [[1, 2, 3, 4], [1, 2, 3, 4]]
+    team.close()
+    api.compress_file_multi([e0, e1], str(inp), str(tmp_path / "ok.ngsc"), 8)
+    want, _ = orc.compress_file(data, 8, threads=8)
+    assert (tmp_path / "ok.ngsc").read_bytes() == want
+
+
 def test_file_driver_parts_groups_and_streamed_writes(tmp_path, monkeypatch):
     """The file driver beyond one group (ngsc.h: NGSC_ORDER_GROUP_BYTES): (a) a rank larger than a job is walked in parts
     (ngsc_compress_rank_part) - inside a multi-rank group its stream is collected, (b) as a group of its own (region above

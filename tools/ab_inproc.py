@@ -100,7 +100,8 @@ def main():
                 continue
             t = sorted(times[i])
             med, mn, nbytes = t[len(t) // 2], t[0], infos[i]["bytes"]
-            same = "" if infos[i]["sha"] == infos[0]["sha"] else "  !! OUTPUT DIFFERS from the first variant's"
+            first = next(x for x in infos if x.get("ready"))
+            same = "" if infos[i]["sha"] == first["sha"] else "  !! OUTPUT DIFFERS from the first variant's"
             kts = infos[i]["kernels"]
             print(f"{name} {nbytes / 1e6:7.1f} MB  {v:>34s}  median {med * 1e3:6.3f} ms = {nbytes / med / 1e9:6.1f} GB/s   min {mn * 1e3:6.3f} ms = {nbytes / mn / 1e9:6.1f} GB/s   "
                   + ", ".join(f"{k}={ms:.3f}" for ms, k in kts[:a.kernels]) + f"  sum={sum(ms for ms, _ in kts):.3f}{same}", flush=True)

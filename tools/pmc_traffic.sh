@@ -2,6 +2,7 @@
 # Developer tool (GPU box): HBM traffic per kernel launch, collected as MI355X_MICROARCH.md prescribes:
 # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (kilobytes; gfx950 reports half of wide coalesced
 # reads, so fetch is doubled = an upper estimate for byte-granular access).  Writes gpurun_out/traffic_<tag>.json.
+#   PMC_SCRIPT=tools/time_configs.py PMC_ARGS=400000000 NGSC_TC_ONLY=cfg3_150bp tools/pmc_traffic.sh cfg3   (other workloads)
 set -e
 tag=${1:-x}
 repo=${GRAFT_REPO_ROOT:-/root/repo}
@@ -9,7 +10,7 @@ out=$repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_${tag}_$c -- \
-        python3 $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs > $out/pmc_${tag}_$c.log 2>&1
+        python3 $repo/${PMC_SCRIPT:-bench.py} ${PMC_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-verify --no-other-configs} > $out/pmc_${tag}_$c.log 2>&1
     python3 $repo/tools/pmc_summary.py $out/pmc_${tag}_$c > $out/pmc_${tag}_$c.json
     find $out/pmc_${tag}_$c -name "*.csv" -size +8M -delete
 done
@@ -21,7 +22,8 @@ def norm(k):   # template arguments off; the word-parallel instance of the title
     return re.sub(r'<[^>]*>', '', k)
 out, tag = sys.argv[1], sys.argv[2]
 f = json.load(open(f"{out}/pmc_{tag}_FETCH_SIZE.json")); w = json.load(open(f"{out}/pmc_{tag}_WRITE_SIZE.json"))
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, bench.py 1 GB cfg2 workload; FETCH_SIZE doubled per "
+import os
+res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, " + (os.environ.get("PMC_SCRIPT", "bench.py 1 GB cfg2 workload") + " " + os.environ.get("NGSC_TC_ONLY", "")).strip() + "; FETCH_SIZE doubled per "
                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads) - an upper estimate for byte-granular access",
        "build": tag, "kernel_source_hash": sys.argv[3]}
 for k in f:
