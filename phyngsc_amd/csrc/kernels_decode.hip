@@ -1105,13 +1105,12 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, 
     {
         const uint32_t total = rows << Kl, shq = Kq - Kl;
         const uint16_t *qtab = C.qtab;
-        const bool pairs = !(with_trees & 2u);   // (bit 1 of with_trees: NGSC_DEC_PAIRS=0, single lookups)
         for (uint32_t k = threadIdx.x; k < total; k += QS_THREADS) {
             const uint32_t row = k >> Kl, x = k & ((1u << Kl) - 1u);
             uint32_t ln = qtab[((size_t)row << Kq) + (x << shq)] >> 12;
             if (ln > Kl) ln = 0;
             uint32_t ln2 = 0;
-            if (pairs && ln && ln < Kl && row >= 1 && row + 1 < rows) {   // (row 0 is the position-independent tree: no record position)
+            if (ln && ln < Kl && row >= 1 && row + 1 < rows) {   // (row 0 is the position-independent tree: no record position)
                 // the bits behind the first code, zero-padded: the next position's length is what the table says iff it fits them
                 const uint32_t x2 = (x << ln) & ((1u << Kl) - 1u);
                 ln2 = qtab[((size_t)(row + 1) << Kq) + (x2 << shq)] >> 12;
@@ -1639,20 +1638,18 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
         // phases: what the first one leaves uncovered is small when few bases were transferred to the quality stream (each
         // moves the stream's end by a few bits), so the next ones are small; the last takes whatever is left
         // kernel A: byte entries (lengths only) - as many look-ahead bits as 60 KB of them allow - and the trees (up to 128
-        // symbols: rows x 128 x 2 + rows bytes at most; NGSC_DEC_LDS_TREES=0: long codes walk the trees in global memory)
+        // symbols: rows x 128 x 2 + rows bytes at most; without room for them long codes walk the trees in global memory)
         uint32_t Ka = DEC_K;
         while (Ka > 5 && ((uint64_t)rows << Ka) > lds_cap) --Ka;
         const uint32_t lds_a_entries = (uint32_t)std::min<uint64_t>(lds_cap, (uint64_t)rows << Ka);
-        const bool lds_trees = !(getenv("NGSC_DEC_LDS_TREES") && !strcmp(getenv("NGSC_DEC_LDS_TREES"), "0"));   // (per call: the tests switch it)
         const uint32_t nq_cap = spec_max_nq < 2 ? 2u : (spec_max_nq > 128 ? 128u : spec_max_nq);
-        size_t tree_bytes = lds_trees ? (size_t)rows * (2 * nq_cap + 1) + 32 : 0;
+        size_t tree_bytes = (size_t)rows * (2 * nq_cap + 1) + 32;
         if (((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes > (120u << 10)) tree_bytes = 0;   // (long reads: no room for the trees)
         const size_t lds_a = ((size_t)lds_a_entries + 15 & ~(size_t)15) + tree_bytes;
-        const bool pairs_off = getenv("NGSC_DEC_PAIRS") && !strcmp(getenv("NGSC_DEC_PAIRS"), "0");   // (per call: the tests switch it)
         const uint32_t phase_tiles[4] = {max_tiles, 16, 256, max_tiles};
         for (int ph = 0; ph < 4; ++ph) {
             hipLaunchKernelGGL(k_dec_qspec_a, dim3(phase_tiles[ph], n_sb), dim3(QS_THREADS), lds_a, st, sub, sb_off, sb_len, (const DecCtl *)ctl,
-                               hop, hop_off, lds_a_entries, (tree_bytes ? 1u : 0u) | (pairs_off ? 2u : 0u));
+                               hop, hop_off, lds_a_entries, tree_bytes ? 1u : 0u);
             if (ph == 0) dec_lap(st, t0, "k_dec_qspec_a");
             hipLaunchKernelGGL(k_dec_qspec_b, dim3(n_sb), dim3(64), 0, st, sb_len, (DecCtl *)ctl, hop, hop_off, scratch, stride, rec_cap, tcap,
                                ph < 3 ? phase_tiles[ph + 1] : 0u);

@@ -48,41 +48,22 @@ __device__ __forceinline__ uint4 load16_guarded_sq(const uint8_t *buf, uint32_t 
         if (a + x < buf_len) w[x >> 2] |= (uint32_t)buf[a + x] << (8 * (x & 3));
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
-// one stream's 16-byte chunk into its chunk-major copy (the short last chunk: Arena::dtail_b bytes)
-__device__ __forceinline__ void sq_chunk_keep1(const Arena &A, uint8_t *dense, uint32_t g, uint32_t off, const uint4 &V)
+__device__ __forceinline__ void sq_chunk_keep(const Arena &A, uint32_t g, uint32_t off, const uint4 &S, const uint4 &Q)
 {
-    const uint32_t c = off >> 4;
-    if (c == A.dtail_c) {
-        uint8_t *p = dense + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
-        if (A.dtail_b == 4) *reinterpret_cast<uint32_t *>(p) = V.x;
-        else if (A.dtail_b == 8) *reinterpret_cast<uint2 *>(p) = make_uint2(V.x, V.y);
-        else *reinterpret_cast<U3a *>(p) = U3a{V.x, V.y, V.z};
-        return;
+    if (A.dstride) {
+        const uint32_t c = off >> 4;
+        if (c == A.dtail_c) {
+            uint8_t *ps = A.dense_s + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
+            uint8_t *pq = A.dense_q + (size_t)c * A.dstride * 16 + (size_t)g * A.dtail_b;
+            if (A.dtail_b == 4) { *reinterpret_cast<uint32_t *>(ps) = S.x; *reinterpret_cast<uint32_t *>(pq) = Q.x; }
+            else if (A.dtail_b == 8) { *reinterpret_cast<uint2 *>(ps) = make_uint2(S.x, S.y); *reinterpret_cast<uint2 *>(pq) = make_uint2(Q.x, Q.y); }
+            else { *reinterpret_cast<U3a *>(ps) = U3a{S.x, S.y, S.z}; *reinterpret_cast<U3a *>(pq) = U3a{Q.x, Q.y, Q.z}; }
+            return;
+        }
+        // (plain stores: with the non-temporal hint the kernel is no faster and the readers lose what the caches kept)
+        *reinterpret_cast<uint4 *>(A.dense_s + ((size_t)c * A.dstride + g) * 16) = S;
+        *reinterpret_cast<uint4 *>(A.dense_q + ((size_t)c * A.dstride + g) * 16) = Q;
     }
-    // (plain stores: with the non-temporal hint the kernel is no faster and the readers lose what the caches kept)
-    *reinterpret_cast<uint4 *>(dense + ((size_t)c * A.dstride + g) * 16) = V;
-}
-// (round 4) The BASES of a chunk are kept as two bits each - (c >> 1) & 3: A, C, T, G = 0, 1, 2, 3; base j of the chunk at bits
-// 31 - 2j, 30 - 2j, the order the two-bit DNA stream wants them in - one dword per chunk in a chunk-major array of its own
-// (Arena::dense_s2): a quarter of the bytes the statistics kernel writes for them and the pack kernel reads.  The byte form
-// goes to dense_s only for the chunks that hold something else than A / C / G / T (k_sq_stats_reg knows; the readers know from
-// the record's list of such positions, Arena::apos, or - more than four of them - take every chunk of the record as bytes).
-// idx: the chunk's dwords as (c >> 1) & 3 per byte (bytes behind the read: anything)
-__device__ __forceinline__ uint32_t sq_pack2(const uint32_t (&idx)[4])
-{
-    return (((idx[0] * 0x40100401u) >> 24) << 24) | (((idx[1] * 0x40100401u) >> 24) << 16) | (((idx[2] * 0x40100401u) >> 24) << 8) |
-           ((idx[3] * 0x40100401u) >> 24);
-}
-// ... and back: dword k of the chunk as (c >> 1) & 3 per byte
-__device__ __forceinline__ uint32_t sq_unpack2(uint32_t w2, uint32_t k)
-{
-    return ((((w2 >> (24 - 8 * k)) & 0xffu) * 0x40100401u) >> 6) & 0x03030303u;
-}
-__device__ __forceinline__ void sq_keep_bases(const Arena &A, uint32_t g, uint32_t ch, const uint32_t (&idx)[4], bool other, const uint4 &S)
-{
-    if (!A.dstride) return;
-    A.dense_s2[(size_t)ch * A.dstride + g] = sq_pack2(idx);
-    if (other) sq_chunk_keep1(A, A.dense_s, g, 16 * ch, S);
 }
 
 // STAGED (short records, round 3): the 64 records of a wave are one contiguous span of the file (~8 KB at 36 bases).  The wave
@@ -207,13 +188,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                         Qb[k] = load16_unaligned(A.buf, q0 + off, A.buf_len);
                     }
                 }
-                // (the quality copies for measure / pack: behind all four loads, so that the loads stay in flight together)
-                if (A.dstride) {
+                // (the copies for measure / pack: behind all four loads, so that the loads stay in flight together)
 #pragma unroll
-                    for (uint32_t k = 0; k < NBX; ++k) {
-                        const uint32_t off = 16 * NBX * grp + 16 * k;
-                        if (L > off) sq_chunk_keep1(A, A.dense_q, g, off, Qb[k]);
-                    }
+                for (uint32_t k = 0; k < NBX; ++k) {
+                    const uint32_t off = 16 * NBX * grp + 16 * k;
+                    if (L > off) sq_chunk_keep(A, g, off, Sb[k], Qb[k]);
                 }
             } else {
                 Sb[0] = Sn; Qb[0] = Qn;
@@ -222,7 +201,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                     Sn = ld16(s0 + 16 * grp + 16);
                     Qn = ld16(q0 + 16 * grp + 16);
                 }
-                if (A.dstride && L > 16 * grp) sq_chunk_keep1(A, A.dense_q, g, 16 * grp, Qb[0]);   // (the chunk that has arrived, not the one in flight)
+                if (L > 16 * grp) sq_chunk_keep(A, g, 16 * grp, Sb[0], Qb[0]);   // (the chunk that has arrived, not the one in flight)
             }
 #pragma unroll
             for (uint32_t kb = 0; kb < NBX; ++kb) {
@@ -261,7 +240,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                         c1 += __builtin_popcount(p1);
                         c01 += __builtin_popcount(p0 & p1);
                     }
-                    if (nv) sq_keep_bases(A, g, ch, idx, dacc != 0, S);   // the bases' copy: two bits each (+ the bytes where there is more to say)
                     const bool rows_ok = 16 * ch + 17 <= lds_rows;
                     const bool odd = dacc != 0 || qbad != 0 || (nv != 0 && nv != 16);
                     const unsigned long long live = __ballot(nv != 0);
@@ -408,7 +386,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                     const uint4 S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
                     const uint4 Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
                     const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
-                    if (A.dstride) sq_chunk_keep1(A, A.dense_s, g, 16 * ch, S);   // (such a record's chunks are all read as bytes)
                     const uint32_t ambm = sr_amb_mask(sw, nv);
 #pragma unroll
                     for (uint32_t u = 0; u < 16; ++u) {
@@ -569,7 +546,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             if (nv) {
                 S = ld16(s0 + 16 * ch);
                 Q = ld16(q0 + 16 * ch);
-                if (A.dstride) sq_chunk_keep1(A, A.dense_q, g, 16 * ch, Q);
+                sq_chunk_keep(A, g, 16 * ch, S, Q);
             }
             const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
             if (nv != 0 && L <= 16 * ch + 16) {   // the end of the read: "\n+\n" follows
@@ -598,7 +575,6 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 c1 += __builtin_popcount(p1);
                 c01 += __builtin_popcount(p0 & p1);
             }
-            if (nv) sq_keep_bases(A, g, ch, idx, dacc != 0, S);
             const uint32_t rb = 8 * ch * SR_HSTRIDE * 4 - 33 * 4;   // (per lane: the lanes of a wave are at different positions)
             if (!__any(nv != 0 && (nv != 16 || dacc != 0 || qbad != 0))) {
                 // every lane that still has bytes: sixteen plain qualities, only A/C/G/T
@@ -732,7 +708,6 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                     const uint4 S = load16_unaligned(A.buf, s0 + 16 * ch, A.buf_len);
                     const uint4 Q = load16_unaligned(A.buf, q0 + 16 * ch, A.buf_len);
                     const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
-                    if (A.dstride) sq_chunk_keep1(A, A.dense_s, g, 16 * ch, S);   // (such a record's chunks are all read as bytes)
                     const uint32_t ambm = sr_amb_mask(sw, nv);
 #pragma unroll
                     for (uint32_t u = 0; u < 16; ++u) {
@@ -1179,27 +1154,6 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         const uint32_t L = valid ? se - te - 1 : 0;
         const uint32_t s0 = te + 1, q0 = se + 3;
         const bool xfer = valid ? (sl_n >> 31) : false;
-        // the chunks of this record whose bases are in dense_s as BYTES (they hold something else than A / C / G / T); the others
-        // are two bits a base in dense_s2 (sq_keep_bases).  Up to 64 chunks: the records of this path have at most 1021 bases
-        uint64_t ambc = 0;
-        if (A.dstride) {
-            const uint32_t nall = valid ? (sl_n >> 28) & 7u : 0u;
-            if (nall > 4) ambc = ~0ull;
-            if (__any(nall >= 1 && nall <= 4)) {
-                if (nall >= 1 && nall <= 4) {
-                    const AmbPos ap = A.apos[g];
-                    ambc = 1ull << ((ap.x & 0xffffu) >> 4);
-                    if (nall > 1) ambc |= 1ull << ((ap.x >> 16) >> 4);
-                    if (nall > 2) ambc |= 1ull << ((ap.y & 0xffffu) >> 4);
-                    if (nall > 3) ambc |= 1ull << ((ap.y >> 16) >> 4);
-                }
-            }
-        }
-        // a chunk of bases as it is fetched ahead: the dword of its two-bit form in .x (dense copies), or its 16 bytes (the file)
-        auto load_s = [&](uint32_t off) __attribute__((always_inline)) -> uint4 {
-            if (A.dstride) return make_uint4(A.dense_s2[(size_t)(off >> 4) * A.dstride + g], 0u, 0u, 0u);
-            return load16_unaligned(A.buf, s0 + off, A.buf_len);
-        };
         const uint32_t ub = ub_n;
         if (tile + 1 < tile_last) {
             if (i + SR_THREADS < n) { te_n = A.te[g + SR_THREADS]; se_n = A.se[g + SR_THREADS]; sl_n = A.slen[g + SR_THREADS]; }
@@ -1214,7 +1168,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         constexpr uint32_t NBX = BURST ? NB : 1u;   // chunks per trip, see k_sq_stats_reg
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
         if (!BURST && L) {
-            Sn = load_s(0);
+            Sn = sq_chunk_load(A, A.dense_s, g, 0, s0);
             Qn = sq_chunk_load(A, A.dense_q, g, 0, q0);
         }
         for (uint32_t w = 0; w < n_win; ++w) {
@@ -1232,7 +1186,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint32_t off = 16 * NBX * grp + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Sb[k] = load_s(off);
+                        Sb[k] = sq_chunk_load(A, A.dense_s, g, off, s0);
                         Qb[k] = sq_chunk_load(A, A.dense_q, g, off, q0);
                     }
                 }
@@ -1240,7 +1194,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * grp + 16) {
-                    Sn = load_s(16 * grp + 16);
+                    Sn = sq_chunk_load(A, A.dense_s, g, 16 * grp + 16, s0);
                     Qn = sq_chunk_load(A, A.dense_q, g, 16 * grp + 16, q0);
                 }
             }
@@ -1249,27 +1203,11 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 if (kb == 0 || __any(16 * (NBX * grp + kb) < L)) {
                     const uint32_t ch = NBX * grp + kb;
                     const uint32_t lrow0 = 16 * ch + 1 - r0;   // row of the chunk's first position inside the table
-                    uint4 S = Sb[kb];
-                    const uint4 Q = Qb[kb];
+                    const uint4 S = Sb[kb], Q = Qb[kb];
                     const uint32_t nv = L > 16 * ch ? (L - 16 * ch < 16 ? L - 16 * ch : 16) : 0;
-                    // two_bit: the wave's chunks of bases are all A / C / G / T and come as two bits a base (s2; base j at bits 31 - 2j,
-                    // 30 - 2j); else some lane's chunk holds more: that lane fetches its bytes, the others spell theirs out
-                    const uint32_t s2 = S.x;
-                    const uint32_t qany = Q.x | Q.y | Q.z | Q.w;
-                    const bool lean_now = lean_wg && !__any((qany & 0x80808080u) != 0 && nv != 0);
-                    bool two_bit = false;
-                    if (A.dstride) {
-                        const bool other = nv != 0 && ((ambc >> ch) & 1ull) != 0;
-                        two_bit = lean_now && (plain || short_codes) && !__any(other);   // (the lean path's word-wise DNA forms)
-                        if (!two_bit) {
-                            if (other) S = sq_chunk_load(A, A.dense_s, g, 16 * ch, s0);
-                            else S = make_uint4(__builtin_amdgcn_perm(0u, 0x47544341u, sq_unpack2(s2, 0)), __builtin_amdgcn_perm(0u, 0x47544341u, sq_unpack2(s2, 1)),
-                                                __builtin_amdgcn_perm(0u, 0x47544341u, sq_unpack2(s2, 2)), __builtin_amdgcn_perm(0u, 0x47544341u, sq_unpack2(s2, 3)));
-                        }
-                    }
                     const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
                     // ---- lean path: alphabet inside the table (sq_lean_alphabet) and no high bit in this chunk's bytes ----
-                    if (lean_now) {
+                    if (lean_wg && !__any(((qw[0] | qw[1] | qw[2] | qw[3]) & 0x80808080u) != 0 && nv != 0)) {
                         const bool tails = __any(nv != 16);
                         // dwords that some lane of the wave still needs (36 bases = 16 + 16 + 4: the last chunk is one dword)
                         const bool wany[4] = {true, !tails || __any(nv > 4), !tails || __any(nv > 8), !tails || __any(nv > 12)};
@@ -1282,7 +1220,6 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                                 if (!wany[k]) continue;   // (idx = 0, 'A': no lane has a byte here)
                                 w = (sw[k] & vmk[k]) | (0x41414141u & ~vmk[k]);
                             }
-                            if (two_bit) { if (!plain) idx[k] = sq_unpack2(s2, k); continue; }   // (nothing but A / C / G / T: dacc stays 0)
                             idx[k] = sr_idx(w);
                             dacc |= sr_not_acgt(w, idx[k]);
                         }
@@ -1359,18 +1296,9 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                         if (plain && !__any(dacc != 0)) {
                             if (nv) {
                                 uint32_t x = 0;
-                                if (two_bit) {
-                                    // the 16 two-bit fields at once: field value j -> code of the j-th of A, C, T, G (two-bit codes: ctab's bytes)
-                                    // (A, C, G, T all present - codes 0, 1, 2, 3 in byte order, i.e. 0, 1, 3, 2 in field order - is one XOR)
-                                    const uint32_t lo = s2 & 0x55555555u, hi = (s2 >> 1) & 0x55555555u;
-                                    if (ctab == 0x02030100u) x = s2 ^ hi;
-                                    else x = (lo & ~hi) * ((ctab >> 8) & 3u) + (hi & ~lo) * ((ctab >> 16) & 3u) + (lo & hi) * ((ctab >> 24) & 3u) +
-                                             (~(lo | hi) & 0x55555555u) * (ctab & 3u);
-                                } else {
 #pragma unroll
-                                    for (uint32_t k = 0; k < 4; ++k)
-                                        if (wany[k]) x |= ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24) << (24 - 8 * k);
-                                }
+                                for (uint32_t k = 0; k < 4; ++k)
+                                    if (wany[k]) x |= ((__builtin_amdgcn_perm(0u, ctab, idx[k]) * 0x40100401u) >> 24) << (24 - 8 * k);
                                 wd_.put(nv == 16 ? x : (x >> (32 - 2 * nv)), 2 * nv);
                             }
                         } else if (short_codes) {
@@ -1379,7 +1307,7 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
                             for (uint32_t k = 0; k < 4; ++k) {
                                 if (!__any(nv > 4 * k)) continue;
-                                const uint32_t i7 = two_bit ? idx[k] : ((((sw[k] & vmk[k]) | (0x41414141u & ~vmk[k])) >> 1) & 0x07070707u);
+                                const uint32_t i7 = ((((sw[k] & vmk[k]) | (0x41414141u & ~vmk[k])) >> 1) & 0x07070707u);
                                 uint32_t l4 = __builtin_amdgcn_perm(lhi, ltab, i7) & vmk[k], c4 = __builtin_amdgcn_perm(chi, ctab, i7) & vmk[k];
                                 if (__any((ambm >> (4 * k)) & 15u)) {
 #pragma unroll
@@ -1649,11 +1577,14 @@ void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec)
     const uint32_t tpw = sr_records_per_wg(A, max_rec, 2048) / SR_THREADS;
     dim3 grid(((max_rec + SR_THREADS - 1) / SR_THREADS + tpw - 1) / tpw, A.n_sb);
     auto kern = sr_burst(A) ? k_sq_measure_reg<true> : k_sq_measure_reg<false>;
-    {   // the tables in their LDS layouts, once per sub-block (here: behind the Huffman kernel, ahead of both readers)
-        const uint32_t words = (uint32_t)(A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
-        hipLaunchKernelGGL(k_sq_format_qtab, dim3((words + 4 * SR_THREADS - 1) / (4 * SR_THREADS), A.n_sb), dim3(SR_THREADS), 0, st, A);
-    }
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), (((size_t)(rows + SQ_QROWS_EXTRA) * SQ_QS + 15) & ~(size_t)15), st, A, rows, tpw);
+}
+
+// the quality code tables in their LDS layouts, once per sub-block: behind the Huffman kernel, ahead of both readers (measure, pack)
+void launch_sq_format_qtab(hipStream_t st, const Arena &A)
+{
+    const uint32_t words = (uint32_t)(A.qrows + SQ_QROWS_EXTRA) * SQ_QS;
+    hipLaunchKernelGGL(k_sq_format_qtab, dim3((words + 4 * SR_THREADS - 1) / (4 * SR_THREADS), A.n_sb), dim3(SR_THREADS), 0, st, A);
 }
 
 // Long reads: a table of one window of 32 positions once the whole table would be well beyond a window (reads of 49 bases

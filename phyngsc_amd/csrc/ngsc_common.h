@@ -347,10 +347,6 @@ struct Arena {
     // instead of 16 bytes each at addresses a whole record apart.  dstride == 0: off
     uint8_t *dense_s, *dense_q;
     uint32_t dstride;
-    // (round 4) the bases two bits each, a dword per 16-base chunk, chunk-major like the byte copies: chunk c of record g at
-    // dense_s2[c * dstride + g] (kernels_sq.hip: sq_keep_bases).  dense_s then holds only the chunks with something else than
-    // A / C / G / T in them
-    uint32_t *dense_s2;
     // (round 3) the LAST chunk of the job's longest read, when it holds at most 12 bytes (36 bases: 16 + 16 + 4), is kept as
     // dtail_b = 4 / 8 / 12 bytes per record instead of 16: chunk dtail_c of record g at dense_x + dtail_c * dstride * 16 + g * dtail_b
     // (a quarter of the copies' bytes at 36 bases).  dtail_c == 0xffffffff: every chunk is 16 bytes

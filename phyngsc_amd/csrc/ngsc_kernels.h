@@ -23,6 +23,7 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
 
 // ---- kernels_sq.hip ----
 void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32_t max_rec_bytes, uint32_t n_rec_total);
+void launch_sq_format_qtab(hipStream_t st, const Arena &A);   // the quality code tables as measure and pack keep them in LDS
 void launch_sq_measure_reg(hipStream_t st, const Arena &A, uint32_t max_rec);
 size_t sq_qfmt_words(uint32_t qrows);   // dwords per sub-block of Arena::qfmt (a multiple of 4)
 size_t sq_qfmt_bytes(uint32_t qrows, uint32_t n_sb);   // the whole of Arena::qfmt: dword tables, then byte tables

@@ -727,12 +727,11 @@ def test_decompress_file_shared_records_and_cli(eng, tmp_path):
     assert subprocess.run([exe, "-d", str(mid), str(back)], capture_output=True).returncode == 4
 
 
-@pytest.mark.parametrize("switch", [("NGSC_DEC_DNA_PAR", "0"), ("NGSC_DEC_LDS_TREES", "0"), ("NGSC_DEC_SPEC", "0"), ("NGSC_DEC_PAIRS", "0")],
-                         ids=["serial_bases", "trees_in_global_memory", "serial_qualities", "one_symbol_per_lookup"])
+@pytest.mark.parametrize("switch", [("NGSC_DEC_DNA_PAR", "0"), ("NGSC_DEC_SPEC", "0")], ids=["serial_bases", "serial_qualities"])
 def test_gpu_decoder_switches_agree(eng, monkeypatch, switch):
-    """The decoder's round-3 forms against their predecessors: Huffman-coded bases decoded by one wave instead of in parallel,
-    long quality codes walked in global memory instead of LDS, the quality stream decoded serially, the speculative kernel with one symbol per table lookup - each must give the input
-    back (150-base reads with N bases: Huffman-coded bases, equally long reads; mixed lengths: no speculation anyway)."""
+    """The decoder's serial forms - what a stream the parallel kernels give up on falls back to - in place of the parallel ones:
+    Huffman-coded bases decoded by one wave, the quality stream decoded serially.  Each must give the input back (150-base reads
+    with N bases: Huffman-coded bases, equally long reads; mixed lengths: no speculation anyway)."""
     monkeypatch.setenv(*switch)
     for cfg, size, P in ((fastq_gen.CFG3, 30_000_000, 3), (fastq_gen.CFG5_300, 12_000_000, 2), (fastq_gen.CFG2, 20_000_000, 2)):
         data = fastq_gen.generate(cfg, target_bytes=size)
