@@ -61,8 +61,6 @@ struct ngsc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t side_stream = nullptr;          // the latency-bound kernels of the staggered schedule (high priority)
-    hipStream_t low_stream = nullptr;           // ... and the throughput kernel of the side chain (payload measure): ordinary priority
-    hipEvent_t ev_low = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
     size_t zero_hint = 0;         // bytes of the zero-initialised arena the last call used: cleared while the host waits for the cut list
     uint64_t out_hint = 0;        // output bytes of the last call: that much of the output buffer is cleared beside the index kernels
@@ -74,7 +72,6 @@ struct ngsc_ctx {
     bool cs_retry = false;        // the job is run again on a copy in which colour-space reads are decoded
     uint32_t qbits_x16 = 0, dbits_x16 = 0;   // payload bits per base (x 16) of the densest sub-block of the last call: staging hint
     bool slot_retry = false;
-    int xexp = 0;
     bool wide = false;            // titles of more than MAX_FIELDS separators: the job runs on the wide title kernels (kernels_title_wide.hip);
                                   // found out by a first run, kept for the context's later jobs while they need it
     bool no_spec = getenv("NGSC_NO_SPEC") != nullptr;   // every call reads the job's shape back (the step's first-call form)
@@ -231,12 +228,9 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out)
     // slot frees up instead of taking turns with tens of thousands of queued ones
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    c->xexp = getenv("NGSC_X") ? atoi(getenv("NGSC_X")) : 0;   // (experiment selector, removed before the round ends)
-    const int side_prio = (c->xexp & 1) ? prio_lo : prio_hi;
+    const int side_prio = prio_hi;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
         hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, side_prio) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->low_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_low, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess) {
@@ -259,8 +253,6 @@ void ngsc_ctx_destroy(ngsc_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-    if (c->low_stream) (void)hipStreamDestroy(c->low_stream);
-    if (c->ev_low) (void)hipEventDestroy(c->ev_low);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
@@ -716,22 +708,12 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (stagger) HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
     { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
     { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
-    // (round 4) the payload measure kernel is the side chain's one THROUGHPUT kernel: at the side stream's high priority its
-    // workgroups were dispatched ahead of the title chain's small kernels on the main stream (title histogram 77 us instead of
-    // 18, in a step's trace), which are the critical path - it runs on a stream of ordinary priority (NGSC_X & 2: as before)
-    const bool measure_low = stagger && !(c->xexp & 2);
-    hipStream_t stm = measure_low ? c->low_stream : sts;
+    // (round 4, measured and not kept: the payload measure kernel - the side chain's one throughput kernel - on a stream of ordinary
+    // priority, so that the title chain's small kernels are not dispatched behind it: no change on 36-base reads, 3 % slower on
+    // 150-base reads, profiles/r04_ab_measure_stream_priority.txt; the side stream at low priority altogether: 1-2 % slower)
     if (sq_reg) {
         { KScope k(c, sts, "k_sq_format_qtab"); launch_sq_format_qtab(sts, A); }
-        if (measure_low) {
-            HIPCHK(c, hipEventRecord(c->ev_low, sts));
-            HIPCHK(c, hipStreamWaitEvent(stm, c->ev_low, 0));
-        }
-        { KScope k(c, stm, "k_sq_measure_reg"); launch_sq_measure_reg(stm, A, max_rec); }
-        if (measure_low) {
-            HIPCHK(c, hipEventRecord(c->ev_low, stm));
-            HIPCHK(c, hipStreamWaitEvent(sts, c->ev_low, 0));   // (the side stream's join below then covers it)
-        }
+        { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
     }
     else { KScope k(c, sts, "k_measure_sq"); launch_measure_sq(sts, A, max_rec); }
     if (wide) { KScope k(c, st, "k_title_wide_stats"); launch_title_wide_stats(st, A, max_rec); }
