@@ -42,10 +42,11 @@ enum {
     NGSC_ERR_FIELDS = -2,      /* title separator count differs inside a sub-block (reference: warning, then UB) */
     NGSC_ERR_TOOMANY = -3,     /* > 100000 records in one sub-block (reference: warning + overflow) */
     NGSC_ERR_COLORSPACE = -4,  /* decoder only: a colour-space (SOLiD) sub-block, which the format stores lossily (phyNGSC.cpp:531); the compressor handles such reads */
-    NGSC_ERR_RANGE = -5,       /* numeric title field >= 2^31 (reference: int32 wrap) */
+    NGSC_ERR_RANGE = -5,       /* a varying numeric title field with a value beyond INT32_MAX (reference: negative int32 and an endless loop, or
+                                * - digits beyond 32 bits - the value stored modulo 2^32), or a delta range >= 2^31 */
     NGSC_ERR_NOMEM = -6,
     NGSC_ERR_ARG = -7,
-    NGSC_ERR_UNSUPPORTED = -8, /* engine limit: > 64 title fields, text field > 256 B, code > 26 bits */
+    NGSC_ERR_UNSUPPORTED = -8, /* engine limit: a first title or a non-constant text field's first value > 512 B, a Huffman code > 26 bits */
     NGSC_ERR_HIP = -9,         /* HIP runtime / device failure (ngsc_last_hip_error()) */
     NGSC_ERR_CAPACITY = -10,   /* output buffer too small: ngsc_result_bytes() tells the size needed */
     NGSC_ERR_IO = -11
@@ -100,6 +101,9 @@ int ngsc_ctx_create(int device_id, ngsc_ctx **out);
 void ngsc_ctx_destroy(ngsc_ctx *ctx);
 const char *ngsc_last_hip_error(ngsc_ctx *ctx);
 int ngsc_ctx_device(ngsc_ctx *ctx); /* the HIP device the context was created on */
+/* Gives the decoder's working memory back to the device (per-sub-block scratch and the speculative decoder's hop table stay with the
+ * context between ngsc_decompress_* calls: several GB after a large file).  The compressor does this by itself when it finds no room. */
+int ngsc_ctx_trim(ngsc_ctx *ctx);
 
 /* Per-kernel device timing (hipEvent pairs around every launch). Off by default. */
 int ngsc_set_profiling(ngsc_ctx *ctx, int enable);

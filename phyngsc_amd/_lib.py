@@ -17,7 +17,7 @@ EXPORTS = [
     "ngsc_set_profiling", "ngsc_reset_kernel_times", "ngsc_get_kernel_times", "ngsc_compress_device",
     "ngsc_result_bytes", "ngsc_result_num_subblocks", "ngsc_result_num_ranks", "ngsc_result_subblocks",
     "ngsc_result_ranks", "ngsc_plan_blocks", "ngsc_make_header", "ngsc_make_footer", "ngsc_compress_file",
-    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
+    "ngsc_compress_file_multi", "ngsc_ctx_device", "ngsc_ctx_trim", "ngsc_profile_only", "ngsc_compress_rank_part", "ngsc_decompress_device",
     "ngsc_decompress_file", "ngsc_read_footer", "ngsc_read_header",
     "ngsc_team_create", "ngsc_team_destroy", "ngsc_team_size", "ngsc_team_rccl_ranks", "ngsc_team_describe",
     "ngsc_team_compress", "ngsc_team_allgather_u64", "ngsc_team_member_allgather", "ngsc_team_abort", "ngsc_team_exchange_ms", "ngsc_rows_to_offsets",

@@ -816,6 +816,7 @@ int ngsc_compress_file_multi(ngsc_ctx **ctxs, uint32_t n_ctx, const char *in_pat
     double io = 0;
     for (auto &w : workers) io = std::max(io, w.io_s);
     if (seconds_out) { seconds_out[0] = (t1 - t0) + io; seconds_out[1] = (t2 - t1) - io; seconds_out[2] = t3 - t2; }
+    if (rc || !okw) (void)::unlink(out_path);   // (no half-written, preallocated file left behind)
     if (rc) return rc;
     return okw ? NGSC_OK : NGSC_ERR_IO;
 }

@@ -62,7 +62,11 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
     {   // ... and what the device has room for: at most half of its free memory goes into the per-sub-block scratch
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b) {
-            const uint64_t fit = (uint64_t)free_b / 2 / stride;
+            // (the hop table of the speculative quality decoder - 16 bytes per compressed byte of a batch - is budgeted with the scratch)
+            uint64_t all_len = 0;
+            for (uint32_t k = 0; k < n_sb; ++k) all_len += sb_len[k];
+            const uint64_t per_sb = stride + (spec ? 16 * (all_len / n_sb + 1) : 0);
+            const uint64_t fit = (uint64_t)free_b / 2 / per_sb;
             batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch, fit));
         }
     }
@@ -352,6 +356,7 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
         fprintf(stderr, "[ngsc -d] no room for %llu bytes of output in %s\n", (unsigned long long)F.FS, out_path);
         close(fd);
         close(ofd);
+        (void)unlink(out_path);
         return NGSC_ERR_IO;
     }
     // batches: at most 512 sub-blocks (two decoder waves per CU) or 2 GiB of compressed bytes
@@ -573,6 +578,9 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     if (!rc && ftruncate(ofd, (off_t)F.FS) != 0) rc = NGSC_ERR_IO;
     close(fd);
     if (close(ofd) != 0 && !rc) rc = NGSC_ERR_IO;
+    // a failed job leaves no file behind: the size came from the (untrusted) footer and the space was reserved up front - a
+    // zero-filled file of that size would look like a result
+    if (rc) (void)unlink(out_path);
     if (seconds_out) { seconds_out[0] = t_read; seconds_out[1] = t_dev; seconds_out[2] = t_down + t_write; }
     if (getenv("NGSC_VERBOSE"))
         fprintf(stderr, "[ngsc -d] %u ranks, %u blocks, %zu sub-blocks in %zu batches: read + upload %.3f s, decode %.3f s, download %.3f s, write %.3f s "

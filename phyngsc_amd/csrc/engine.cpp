@@ -109,7 +109,21 @@ static int ensure(ngsc_ctx *c, DevBuf &b, size_t bytes)
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 8 + 4096;
-    HIPCHK(c, hipMalloc(&b.p, want));
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        // the decoder's working memory stays with the context between calls (several GB after a large file): a compress job
+        // that finds no room gives it back and tries once more
+        (void)hipGetLastError();
+        b.p = nullptr;
+        bool freed = false;
+        for (DevBuf &d : c->dec)
+            if (d.p) { (void)hipFree(d.p); d.p = nullptr; d.cap = 0; freed = true; }
+        if (!freed || hipMalloc(&b.p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            b.p = nullptr;
+            c->hip_err = "hipMalloc: out of device memory";
+            return NGSC_ERR_NOMEM;
+        }
+    }
     b.cap = want;
     return NGSC_OK;
 }
@@ -278,6 +292,15 @@ void *ngsc_ctx_scratch(ngsc_ctx *c, uint32_t slot, size_t bytes)
 }
 
 int ngsc_ctx_device(ngsc_ctx *c) { return c ? c->device : -1; }
+
+int ngsc_ctx_trim(ngsc_ctx *c)
+{
+    if (!c) return NGSC_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return NGSC_ERR_HIP;
+    for (DevBuf &d : c->dec)
+        if (d.p) { (void)hipFree(d.p); d.p = nullptr; d.cap = 0; }
+    return NGSC_OK;
+}
 
 int ngsc_set_profiling(ngsc_ctx *c, int enable)
 {
@@ -772,6 +795,14 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- the one sync of a predicted step (the second of a synchronous one): error word, sizes, result tables ----
     uint8_t *hfin = h_small + cs.off + 64;
     HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));
+    {   // the step's one wait: polled for its first millisecond-scale stretch (a blocking wait wakes up 10-20 us after the copy
+        // has landed - one percent of a step), then handed to the runtime
+        const auto t_poll = std::chrono::steady_clock::now();
+        hipError_t q;
+        while ((q = hipStreamQuery(st)) == hipErrorNotReady)
+            if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
+        if (q != hipSuccess && q != hipErrorNotReady) HIPCHK(c, q);
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipGetLastError());
     const int32_t err3 = *(int32_t *)(h_small + o_err);   // state behind the layout kernels

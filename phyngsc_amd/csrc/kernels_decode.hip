@@ -316,29 +316,31 @@ struct DecCtl {   // state of one sub-block's decode: lane 0 -> wave inside a ke
 template <bool PER_POS>
 __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const uint16_t *tab, uint32_t K, const DTree *trees,
                                                  const uint32_t *lens, uint32_t n, uint8_t *dst, uint32_t *kept, const uint8_t *map, uint32_t *s_in,
-                                                 uint8_t *s_out, uint32_t nrows)
+                                                 uint8_t *s_out, uint32_t nrows, const uint8_t *t_lc = nullptr, const uint8_t *t_rc = nullptr,
+                                                 const uint8_t *t_root = nullptr, uint32_t t_nq = 0)
 {
+    // t_lc / t_rc / t_root (LDS, optional): the rows' trees as byte child tables [row][t_nq] (alphabets of up to 128 symbols) - a code
+    // longer than the table's K bits is then walked inside the chain, out of LDS, instead of ending the trip for a walk in global memory
     const uint32_t lane = threadIdx.x;
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);   // (sub-blocks start 16-byte aligned and are padded to 16)
     const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
-    // lane 0's decoder state
-    uint64_t win = 0;
+    // the decoder's state: a window of four dwords of the bit string (w0 first), sh bits of w0 already consumed
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, sh = 0;
     // (values that come from memory go through readfirstlane: that is what tells the compiler they are wave-uniform)
     auto U = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
     const uint32_t pos_lo = U((uint32_t)C.pos), pos_hi = U((uint32_t)(C.pos >> 32));
     const uint64_t pos0 = ((uint64_t)pos_hi << 32) | pos_lo;
-    uint32_t have = 0, wi = (uint32_t)(pos0 >> 5), i = 0, j = 0, L = 0, kc = 0, bad = 0, Lnext = 0;
+    uint32_t wi = (uint32_t)(pos0 >> 5), i = 0, j = 0, L = 0, kc = 0, bad = 0, Lnext = 0;
     uint64_t kbase = 0;
     const uint32_t skip0 = (uint32_t)(pos0 & 31);   // the stream starts inside dword wi
     n = U(n); K = U(K);
     bool opened = false;
-    // roles of the lanes in the four-symbol lookup: symbol index inside the group (lane_d) and bit offset in the window (lane_s)
-    const uint32_t lane_d = lane == 0 ? 0u : (lane <= 16 ? 1u : (lane <= 39 ? 2u : 3u));
-    const uint32_t lane_s = lane == 0 ? 0u : (lane <= 16 ? lane : (lane <= 39 ? lane - 15u : lane - 37u));
-    // Every lane runs the decoder, on the same data: nothing in the loop depends on the lane, so its values are wave-uniform,
-    // the compiler keeps them in scalar registers and branches without exec-mask bookkeeping (a loop under `if (lane == 0)`
-    // was ~190 instructions per symbol, most of them mask handling); stores of identical values to one address are harmless.
+    // Every lane runs the decoder, on the same data: nothing in the loop depends on the lane but the table lookups below, so its
+    // values are wave-uniform, the compiler keeps them in scalar registers and branches without exec-mask bookkeeping (a loop
+    // under `if (lane == 0)` was ~190 instructions per symbol, most of them mask handling); stores of identical values to one
+    // address are harmless.
     if (n) { L = U(lens[0]); Lnext = n > 1 ? U(lens[1]) : 0; }
+    constexpr uint32_t TS = 12;   // symbols per trip at most
     for (;;) {
         const uint32_t base = wi;
         for (uint32_t t = lane; t < DEC_IN_DW + 4; t += 64) s_in[t] = base + t < ndw ? __builtin_bswap32(p32[base + t]) : 0u;
@@ -346,14 +348,18 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
         uint32_t ko = 0;
         {
             const uint32_t limit = base + DEC_IN_DW;
-            if (!opened) {   // first dword: drop the bits in front of the stream
-                win = (uint64_t)U(s_in[0]) << 32 << skip0;
-                have = 32 - skip0;
-                ++wi;
-                win |= (uint64_t)U(s_in[1]) << (32 - have); have += 32; ++wi;   // (the loop keeps more than 32 bits in the window)
+            if (!opened) {   // the first dwords; the bits in front of the stream count as consumed
+                w0 = U(s_in[0]); w1 = U(s_in[1]); w2 = U(s_in[2]); w3 = U(s_in[3]);
+                sh = skip0;
+                wi += 4;
                 opened = true;
             }
-            while (i < n && wi < limit && ko + 4 <= DEC_OUT && !bad) {
+            // nb bits leave the window (whole dwords come in from the staged bit string)
+            auto consume = [&](uint32_t nb) __attribute__((always_inline)) {
+                sh += nb;
+                while (sh >= 32) { w0 = w1; w1 = w2; w2 = w3; w3 = U(s_in[wi - base]); ++wi; sh -= 32; }
+            };
+            while (i < n && wi < limit && ko + TS <= DEC_OUT && !bad) {
                 if (j == L) {   // next record (also the empty ones)
                     if (kept) kept[i] = kc;
                     kc = 0; j = 0; ++i;
@@ -361,66 +367,76 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
                     Lnext = i + 1 < n ? U(lens[i + 1]) : 0;
                     continue;
                 }
-                // Up to four symbols per table access.  The lanes look up, in ONE LDS instruction, every entry the next four
-                // symbols can need: lane 0 the entry of this symbol at bit 0 of the window, lanes 1-16 the entries of the next
-                // symbol for every bit it can start at, lanes 17-39 and 40-63 the same for the two after it (lane_d / lane_s
-                // below).  The chain is then resolved with scalar reads of the right lanes: each entry's code length names the
-                // lane that holds its successor.  (A lone lane waits a full LDS latency per symbol.)
-                const uint32_t nxv = s_in[wi - base];                                   // next window dword, in flight with the table read
-                const uint32_t bitsv = (uint32_t)((win << lane_s) >> (64 - K));
-                const uint32_t rowv = PER_POS ? (j + 1 + lane_d < nrows ? j + 1 + lane_d : nrows - 1) : 0;   // (lanes past the read's end are not used)
-                const uint32_t ev = tab[((size_t)rowv << K) + bitsv];
-                const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)ev, 0) & 0xffffu;
-                uint32_t used = 0, cnt = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
-                if (e0) {
-                    used = e0 >> 12; o0 = e0 & 0xffu; cnt = 1;
-                    if (j + 1 < L && used >= 1 && used <= 16) {
-                        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)used) & 0xffffu;
-                        const uint32_t u1 = used + (e1 >> 12);
-                        if (e1 && u1 <= have) {
-                            used = u1; o1 = e1 & 0xffu; cnt = 2;
-                            if (j + 2 < L && used >= 2 && used <= 24) {
-                                const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(15 + used)) & 0xffffu;
-                                const uint32_t u2 = used + (e2 >> 12);
-                                if (e2 && u2 <= have) {
-                                    used = u2; o2 = e2 & 0xffu; cnt = 3;
-                                    if (j + 3 < L && used >= 3 && used <= 26) {
-                                        const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)(37 + used)) & 0xffffu;
-                                        const uint32_t u3 = used + (e3 >> 12);
-                                        if (e3 && u3 <= have) { used = u3; o3 = e3 & 0xffu; cnt = 4; }
-                                    }
-                                }
-                            }
+                // (round 4) Up to TS symbols per trip.  Lane o stands for bit offset o of the window: it looks up, for each of the next
+                // T symbols, the entry that symbol has IF it starts at offset o - T independent table reads per lane, in flight
+                // together.  The chain is then resolved with scalar reads: the entry of symbol t sits in the lane its predecessor's
+                // code ends at.  (Round 3 looked four symbols ahead, with the lanes split among them: a trip - a table latency, the
+                // scalar chain, the refill - cost ~1100 cycles whatever it decoded, 275 per symbol; the reads of unequal length that the
+                // speculative kernels do not take decoded at 0.4 GB/s.)
+                const uint32_t T = L - j < TS ? L - j : TS;
+                uint32_t ev[TS];
+                {
+                    const uint32_t so = sh + lane, d = so >> 5, r = so & 31u;           // (so <= 94: dwords d, d + 1 of the four)
+                    const uint32_t hi = d == 0 ? w0 : (d == 1 ? w1 : w2), lo = d == 0 ? w1 : (d == 1 ? w2 : w3);
+                    const uint32_t field = (uint32_t)(((((uint64_t)hi << 32) | lo) << r) >> (64 - K));
+#pragma unroll
+                    for (uint32_t t = 0; t < TS; ++t) {
+                        ev[t] = 0;
+                        if (t < T) {
+                            const uint32_t row = PER_POS ? (j + 1 + t < nrows ? j + 1 + t : nrows - 1) : 0;
+                            ev[t] = tab[((size_t)row << K) + field];
                         }
                     }
-                    win <<= used; have -= used;
-                } else {   // a code longer than K bits: walk the tree
-                    const DTree &T = trees[PER_POS ? j + 1 : 0];
-                    const uint32_t tn = U(T.n);
-                    uint32_t node = U(T.root), steps = 0;
-                    while (node >= tn) {
-                        if (have <= 32 && wi <= limit + 1) { win |= (uint64_t)U(s_in[wi - base]) << (32 - have); have += 32; ++wi; }
-                        if (!have || ++steps > 64) { bad = 1; break; }
-                        const uint32_t idx = node - tn;
-                        node = U((win >> 63) ? T.rc[idx] : T.lc[idx]);
-                        win <<= 1; --have;
+                }
+                uint32_t o = 0, cnt = 0;
+#pragma unroll
+                for (uint32_t t = 0; t < TS; ++t) {
+                    if (t < T && cnt == t && o < 64) {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev[t], (int)o) & 0xffffu;
+                        uint32_t sym = e & 0xffu, len = e >> 12;
+                        bool ok = e != 0;
+                        if (!e && t_lc) {   // longer than K bits (or a one-symbol tree): the row's tree, bit by bit out of the window
+                            const uint32_t row = PER_POS ? (j + 1 + t < nrows ? j + 1 + t : nrows - 1) : 0, rowo = row * t_nq;
+                            uint32_t node = U(t_root[row]);
+                            len = 0;
+                            ok = true;
+                            while (node >= t_nq) {
+                                const uint32_t bp = sh + o + len;
+                                if (bp >= 128 || len >= 32) { ok = false; break; }
+                                const uint32_t wsel = bp < 32 ? w0 : (bp < 64 ? w1 : (bp < 96 ? w2 : w3));
+                                node = U(((wsel << (bp & 31u)) >> 31) ? t_rc[rowo + node - t_nq] : t_lc[rowo + node - t_nq]);
+                                ++len;
+                            }
+                            sym = U(map[node & 0xffu]);
+                        }
+                        if (ok) {
+                            s_out[ko + t] = (uint8_t)sym;
+                            kc += sym < 128;
+                            o += len;
+                            cnt = t + 1;
+                        }
                     }
-                    o0 = U(map[node & 0xffu]);
+                }
+                if (cnt) consume(o);
+                else {   // a code longer than K bits (or a one-symbol tree, whose codes have no bits): walk the tree
+                    const DTree &Tr = trees[PER_POS ? j + 1 : 0];
+                    const uint32_t tn = U(Tr.n);
+                    uint32_t node = U(Tr.root), steps = 0;
+                    while (node >= tn) {
+                        if (wi > limit + 2 || ++steps > 64) { bad = 1; break; }
+                        const uint32_t idx = node - tn;
+                        node = U(((w0 << sh) >> 31) ? Tr.rc[idx] : Tr.lc[idx]);
+                        consume(1);
+                    }
+                    const uint32_t sym = U(map[node & 0xffu]);
+                    s_out[ko] = (uint8_t)sym;
+                    kc += sym < 128;
                     cnt = 1;
                 }
-                s_out[ko] = (uint8_t)o0;
-                kc += o0 < 128;
-                if (cnt > 1) { s_out[ko + 1] = (uint8_t)o1; kc += o1 < 128; }
-                if (cnt > 2) { s_out[ko + 2] = (uint8_t)o2; kc += o2 < 128; }
-                if (cnt > 3) { s_out[ko + 3] = (uint8_t)o3; kc += o3 < 128; }
                 ko += cnt; j += cnt;
-                if (have <= 32) {   // (the tree walk refills by itself and may have moved wi: then nxv is stale)
-                    const uint32_t nx = e0 ? U(nxv) : U(s_in[wi - base]);
-                    win |= (uint64_t)nx << (32 - have); have += 32; ++wi;
-                }
             }
             if (i < n && j == L && i + 1 == n) { if (kept) kept[i] = kc; ++i; }   // the last record closes without a successor
-            const uint64_t pos = (uint64_t)wi * 32 - have;
+            const uint64_t pos = (uint64_t)(wi - 4) * 32 + sh;
             if (pos > nbits) bad = 1;
             if (lane == 0) {
                 C.pos = pos;
@@ -1280,9 +1296,29 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
         s_map[lane] = C.qsym[lane]; s_map[lane + 64] = C.qsym[lane + 64]; s_map[lane + 128] = C.qsym[lane + 128]; s_map[lane + 192] = C.qsym[lane + 192];
         if (C.spec == 2 && lane == 0) C.pos -= D.rs[n];   // (the chain had moved it to the stream's end)
         __syncthreads();
-        const uint32_t Kl = dec_fill_lds_table(s_qtab, lds_entries, C.qtab, C.Kq, C.max_q + 1);
-        if (Kl) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, Kl, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
-        else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, C.max_q + 1);
+        // LDS: the per-position tables, as many look-ahead bits as fit, and - for alphabets of up to 128 symbols, when they leave the
+        // tables at least half of the room - the rows' trees as byte child tables, for the codes the tables do not hold
+        const uint32_t rows = C.max_q + 1, nq = C.nqual;
+        uint32_t tree_bytes = (nq >= 1 && nq <= 128) ? ((rows * (2 * nq + 1) + 15u) & ~15u) : 0u;
+        if (tree_bytes > lds_entries) tree_bytes = 0;   // (lds_entries 16-bit entries = 2 lds_entries bytes)
+        const uint32_t tab_entries = lds_entries - tree_bytes / 2;
+        uint8_t *t_lc = nullptr, *t_rc = nullptr, *t_root = nullptr;
+        if (tree_bytes) {
+            t_lc = reinterpret_cast<uint8_t *>(s_qtab + tab_entries);
+            t_rc = t_lc + (size_t)rows * nq;
+            t_root = t_rc + (size_t)rows * nq;
+            for (uint32_t k = lane; k < rows * nq; k += 64) {
+                const uint32_t row = k / nq, i = k % nq;
+                const DTree &Q = C.qt[row];
+                const bool in = Q.n == nq && i + 1 < nq;   // internal nodes nq .. 2 nq - 2
+                t_lc[k] = in ? (uint8_t)Q.lc[i] : (uint8_t)0;
+                t_rc[k] = in ? (uint8_t)Q.rc[i] : (uint8_t)0;
+            }
+            for (uint32_t k = lane; k < rows; k += 64) t_root[k] = C.qt[k].n == nq ? (uint8_t)C.qt[k].root : (uint8_t)0;
+        }
+        const uint32_t Kl = dec_fill_lds_table(s_qtab, tab_entries, C.qtab, C.Kq, rows);
+        if (Kl) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, Kl, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, rows, t_lc, t_rc, t_root, tree_bytes ? nq : 0u);
+        else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, rows);
         __syncthreads();
         if (C.err) { if (lane == 0) O.err = C.err; return; }
     }
@@ -1623,7 +1659,10 @@ void launch_dec_streams(hipStream_t st, const uint8_t *sub, const uint64_t *sb_o
                         uint64_t stride, uint32_t rec_cap, uint64_t tcap, uint64_t qcap, void *out, void *ctl, uint16_t *hop, const uint64_t *hop_off,
                         uint32_t max_tiles, uint32_t spec_max_q, uint32_t spec_max_nq)
 {
-    const uint32_t lds_entries = 30u << 10;   // 60 KB of 16-bit table entries: the per-position tables of reads up to 59 bases
+    // LDS of k_dec_tail's (single-wave) workgroups: 16-bit table entries and the rows' trees as byte tables.  A batch that cannot fill
+    // the chip anyway (up to a wave per CU) gets 120 KB each - seven look-ahead bits for reads of up to 400 bases beside their trees;
+    // larger batches 60 KB, so that two workgroups share a CU
+    const uint32_t lds_entries = n_sb <= 256 ? (60u << 10) : (30u << 10);
     double t0 = 0;
     dec_lap(st, t0, nullptr);
     if (hop && spec_max_q) {

@@ -766,6 +766,328 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 }
 
 // ====================================================================================================
+// (round 4) UNEVENLY long reads, staged: the CHUNKS of a batch of records dealt to the lanes.  With a lane (or four) per record
+// the wave walks as many trips as its longest read needs - on 36..300-base reads half of the lane-trips are idle - and the
+// one-lane-per-record form pulls every chunk in with scattered loads besides (k_sq_stats_reg<BURST>: 0.63 ms per 400 MB, the
+// longest kernel of that configuration).  Here a wave takes FR consecutive records (a contiguous span of the file, staged in LDS
+// with coalesced rows like the other staged forms) and lists their 16-base chunks chunk-index-major - all first chunks, all second
+// chunks, ... of the records that have one - so that lane x of a trip takes entry 64 t + x: no idle lanes but in the last trip,
+// and neighbouring lanes hold the same chunk index of neighbouring records, which is what the chunk-major copies want
+// (coalesced stores).  What a record's chunks find (base counts, ambiguity codes and their positions) meets in per-record LDS
+// words; the record's own lane closes it (transfer decision, lengths, the second look at its ambiguous positions).
+constexpr uint32_t FK = 32;          // chunk indices per record at most (reads of up to 512 bases)
+template <uint32_t FR>               // FR: records per wave and batch (16, or 8 where the spans of 16 would leave a CU with two waves per SIMD)
+struct FlatWave {                    // a wave's tables for its batch
+    uint32_t s0[FR], q0[FR], L[FR];  // offsets in the span, read length
+    uint32_t mask[FK];               // bit r: record r has a chunk of this index
+    uint32_t first[FK + 1];          // entries in front of this chunk index
+    uint32_t fl[FR], namb[FR], nall[FR], apos[FR][4];
+    unsigned long long cnt[FR];      // c0 | c1 << 16 | c01 << 32 | nok << 48 over the record's chunks
+};
+
+template <uint32_t THREADS, uint32_t FR>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3))) void k_sq_stats_flat(Arena A, uint32_t lds_rows, uint32_t rpw, uint32_t span_cap)
+{
+    static_assert(FR == 8 || FR == 16, "the record select below walks a 16-bit mask");
+    if (*A.err) return;
+    // histogram: 16-bit counters, two positions per word, as in k_sq_stats_multi (a workgroup sees at most 1024 records)
+    extern __shared__ __align__(16) uint32_t s_hist[];   // [slots][SR_HSTRIDE], 64 trash words, the waves' spans
+    __shared__ uint32_t s_occ[256];
+    __shared__ uint8_t s_amb[256];
+    __shared__ uint32_t s_red[3];
+    __shared__ FlatWave<FR> s_fw[THREADS / 64];
+    const uint32_t s = blockIdx.y;
+    const SbState &sb = A.sb[s];
+    const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo;
+    const uint32_t first = blockIdx.x * rpw;
+    if (first >= n) return;
+    const uint32_t last = first + rpw < n ? first + rpw : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nslots = 8 * ((lds_rows + 14) / 16);
+    const uint32_t hwords = nslots * SR_HSTRIDE;
+    uint8_t *const span = reinterpret_cast<uint8_t *>(s_hist + ((hwords + 64 + 3) & ~3u)) + (size_t)wave * span_cap;
+    FlatWave<FR> &W = s_fw[wave];
+
+    for (uint32_t k = tid; k < hwords; k += THREADS) s_hist[k] = 0;
+    if (tid < 256) { s_occ[tid] = 0; s_amb[tid] = (uint8_t)amb_code((uint8_t)tid); }
+    if (tid < 3) s_red[tid] = 0;
+    __syncthreads();
+
+    uint32_t *qh = A.qhist + (size_t)s * A.qrows * 256;
+    uint8_t *hb = reinterpret_cast<uint8_t *>(s_hist);
+    const uint32_t trash = (hwords + lane) * 4;
+    uint32_t t0 = 0, t1 = 0, t01 = 0, nok = 0, mq = 0, ms = 0, sum_l = 0;   // (lanes 0 .. FR - 1: over their records)
+    const uint32_t lj = (uint32_t)lane & 3;
+    uint32_t bsh[4], boff[4];
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) {
+        const uint32_t bb = (b + ((uint32_t)lane >> 2)) & 3;
+        bsh[b] = 8 * bb;
+        boff[b] = bb * SR_HSTRIDE * 4;
+    }
+    auto sync_wave = []() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    for (uint32_t base = first + wave * FR; base < last; base += (THREADS / 64) * FR) {
+        // ---- the batch's records: lanes 0 .. FR - 1 ----
+        const uint32_t i = base + (uint32_t)lane;
+        const bool valid = (uint32_t)lane < FR && i < last;
+        const uint32_t g = rec_lo + (valid ? i : base);
+        const uint32_t te = A.te[g], se = A.se[g];
+        const uint32_t L = valid ? se - te - 1 : 0;
+        const uint32_t s0 = te + 1, q0 = se + 3;
+        if (valid) {
+            if (L == 0 && (load8_unaligned(A.buf, se, A.buf_len).x & 0x00ffff00u) != 0x000a2b00u) atomicMin(A.err, (int32_t)ERR_FORMAT);
+            if (i == 0 && L >= 1 && !A.cs_mode) {
+                if (cs_first_read(A.buf[s0], A.buf[s0 + 1])) atomicMin(A.err, (int32_t)ERR_COLORSPACE);
+            }
+        }
+        const unsigned long long vm = __ballot(valid);   // (a prefix of the lanes; not empty: base < last)
+        const uint32_t nrec = (uint32_t)__builtin_popcountll(vm);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0) & ~15u;
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(q0 + L), (int)nrec - 1);
+        {   // the batch's bytes -> LDS, 1 KB per row
+            const uint32_t rows = (hi - lo + 1023u) >> 10;
+            for (uint32_t r0 = 0; r0 < rows; r0 += 4) {
+                uint4 v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (r0 + k < rows) v[k] = load16_guarded_sq(A.buf, lo + 1024u * (r0 + k) + 16u * (uint32_t)lane, A.buf_len);
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)   // (span_cap is a multiple of 16, not of a row: the last row stops at the span's end)
+                    if (r0 + k < rows && 1024u * (r0 + k) + 16u * (uint32_t)lane < span_cap) *reinterpret_cast<uint4 *>(span + 1024u * (r0 + k) + 16u * (uint32_t)lane) = v[k];
+            }
+        }
+        const uint32_t nch = (L + 15) / 16;
+        if ((uint32_t)lane < FR) {
+            W.s0[lane] = s0 - lo; W.q0[lane] = q0 - lo; W.L[lane] = L;
+            W.fl[lane] = 0; W.namb[lane] = 0; W.nall[lane] = 0; W.cnt[lane] = 0ull;
+            W.apos[lane][0] = W.apos[lane][1] = W.apos[lane][2] = W.apos[lane][3] = 0;
+        }
+        // chunk-index-major list of the batch's chunks: mask[k] = the records that have chunk k, first[k] = entries in front
+        uint32_t total = 0, kmax = 0;
+        for (uint32_t k = 0; k < FK; ++k) {
+            const uint32_t m = (uint32_t)__ballot(valid && nch > k);
+            if (lane == 0) { W.mask[k] = m; W.first[k] = total; }
+            if (!m) break;
+            total += (uint32_t)__builtin_popcount(m);
+            kmax = k + 1;
+        }
+        if (lane == 0) W.first[kmax] = total;
+        if (__any(valid && nch > FK)) atomicMin(A.err, (int32_t)ERR_UNSUPPORTED);   // (the launcher takes this form for reads of up to 16 FK bases only)
+        sync_wave();
+
+        // ---- the chunks: entry 64 t + lane ----
+        for (uint32_t x0 = 0; x0 < total; x0 += 64) {
+            const uint32_t x = x0 + (uint32_t)lane;
+            const bool act = x < total;
+            // chunk index: the level whose entries hold x (a trip's 64 entries span few levels: from the first lane's level on)
+            uint32_t k = 0;
+            {
+                uint32_t kf = 0;
+                while (kf + 1 < kmax && W.first[kf + 1] <= x0) ++kf;   // (uniform)
+                k = kf;
+                for (uint32_t j = kf + 1; j < kmax && W.first[j] < x0 + 64; ++j) k += (W.first[j] <= x) ? 1u : 0u;   // (uniform trip count)
+            }
+            // the record: the (x - first[k])-th set bit of mask[k]
+            uint32_t r = 0;
+            {
+                uint32_t m = act ? W.mask[k] : 1u, j = act ? x - W.first[k] : 0u, c;
+                c = (uint32_t)__builtin_popcount(m & 0xffu); if (j >= c) { j -= c; r += 8; m >>= 8; }
+                c = (uint32_t)__builtin_popcount(m & 0xfu);  if (j >= c) { j -= c; r += 4; m >>= 4; }
+                c = (uint32_t)__builtin_popcount(m & 0x3u);  if (j >= c) { j -= c; r += 2; m >>= 2; }
+                c = m & 1u;                                  if (j >= c) { r += 1; }
+            }
+            const uint32_t Lr = act ? W.L[r] : 0u, ch = k;
+            const uint32_t nv = Lr > 16 * ch ? (Lr - 16 * ch < 16 ? Lr - 16 * ch : 16) : 0;
+            const uint32_t gr = rec_lo + base + r;
+            uint4 S = make_uint4(0, 0, 0, 0), Q = S;
+            if (nv) {
+                auto ld16 = [&](uint32_t o) __attribute__((always_inline)) -> uint4 {   // (aligned dwords + funnel shifts: see k_sq_stats_reg)
+                    const uint32_t sh = (o & 3u) * 8u;
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(span + (o & ~3u));
+                    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                    return make_uint4(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), __builtin_amdgcn_alignbit(d3, d2, sh),
+                                      __builtin_amdgcn_alignbit(d4, d3, sh));
+                };
+                S = ld16(W.s0[r] + 16 * ch);
+                Q = ld16(W.q0[r] + 16 * ch);
+                sq_chunk_keep(A, gr, 16 * ch, S, Q);
+            }
+            const uint32_t sw[4] = {S.x, S.y, S.z, S.w}, qw[4] = {Q.x, Q.y, Q.z, Q.w};
+            if (nv != 0 && Lr <= 16 * ch + 16) {   // the end of the read: "\n+\n" follows (in the span: it holds the records whole)
+                const uint32_t o = W.s0[r] + Lr;
+                const uint32_t two = (uint32_t)span[o + 1] | ((uint32_t)span[o + 2] << 8);
+                if (two != 0x0a2bu) atomicMin(A.err, (int32_t)ERR_FORMAT);
+            }
+            uint32_t d[4] = {0, 0, 0, 0}, idx[4] = {0, 0, 0, 0}, dacc = 0, qbad = 0, c0 = 0, c1 = 0, c01 = 0;
+#pragma unroll
+            for (uint32_t kk = 0; kk < 4; ++kk) {
+                const uint32_t vmk = t_lowbytes32((int32_t)nv - 4 * (int32_t)kk);
+                const uint32_t w = (sw[kk] & vmk) | (0x41414141u & ~vmk);
+                idx[kk] = sr_idx(w);
+                d[kk] = sr_not_acgt(w, idx[kk]);
+                dacc |= d[kk];
+                qbad |= sr_q_out(qw[kk]) & vmk;
+                const uint32_t p0 = idx[kk] & 0x01010101u, p1 = (idx[kk] >> 1) & 0x01010101u;
+                c0 += __builtin_popcount(p0);
+                c1 += __builtin_popcount(p1);
+                c01 += __builtin_popcount(p0 & p1);
+            }
+            const uint32_t rb = 8 * ch * SR_HSTRIDE * 4 - 33 * 4;   // (per lane: the lanes of a trip are at different chunk indices)
+            uint32_t cnok = nv;
+            if (!__any(nv != 0 && (nv != 16 || dacc != 0 || qbad != 0))) {
+                if (nv) {   // sixteen plain qualities, only A / C / G / T
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 4; ++kk) {
+                        const uint32_t j = (kk + lj) & 3;
+                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                        const uint32_t joff = rb + (j & 1) * (4 * SR_HSTRIDE * 4), inc = 1u << (16 * (j >> 1));
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                            atomicAdd(reinterpret_cast<uint32_t *>(hb + joff + boff[b] + 4 * q), inc);
+                        }
+                    }
+                }
+            } else {
+                uint32_t ambm = 0, qbm = 0;
+#pragma unroll
+                for (uint32_t kk = 0; kk < 4; ++kk) {
+                    ambm |= t_movemask(t_nonzero01(d[kk])) << (4 * kk);
+                    qbm |= t_movemask((sr_q_out(qw[kk]) >> 7) & 0x01010101u) << (4 * kk);
+                }
+                const uint32_t validm = (1u << nv) - 1u;
+                ambm &= validm;
+                const uint32_t okm = validm & ~ambm & ~qbm;
+                const uint32_t glm = validm & ~ambm & ~okm;
+                if (ambm) {
+                    c0 = c1 = c01 = 0;
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 4; ++kk) {
+                        const uint32_t ok01 = t_nonzero01(d[kk]) ^ 0x01010101u;
+                        const uint32_t p0 = idx[kk] & ok01, p1 = (idx[kk] >> 1) & ok01;
+                        c0 += __builtin_popcount(p0);
+                        c1 += __builtin_popcount(p1);
+                        c01 += __builtin_popcount(p0 & p1);
+                    }
+                }
+                cnok = nv - __builtin_popcount(ambm);
+                if (__any(okm)) {
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 4; ++kk) {
+                        const uint32_t j = (kk + lj) & 3;
+                        const uint32_t wsel = j == 0 ? qw[0] : (j == 1 ? qw[1] : (j == 2 ? qw[2] : qw[3]));
+                        const uint32_t joff = rb + (j & 1) * (4 * SR_HSTRIDE * 4), inc = 1u << (16 * (j >> 1));
+                        const uint32_t okw = okm >> (4 * j);
+#pragma unroll
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t q = (wsel >> bsh[b]) & 0xffu;
+                            const uint32_t a = ((okw >> (bsh[b] >> 3)) & 1u) ? joff + boff[b] + 4 * q : trash;
+                            atomicAdd(reinterpret_cast<uint32_t *>(hb + a), inc);
+                        }
+                    }
+                }
+                if (__any(glm)) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u)
+                        if ((glm >> u) & 1u) atomicAdd(&qh[(size_t)(16 * ch + u + 1) * 256 + sr_byte(qw, u)], 1u);
+                }
+                if (__any(ambm)) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 16; ++u) {
+                        if ((ambm >> u) & 1u) {
+                            const uint32_t a = s_amb[sr_byte(sw, u)];
+                            uint32_t f = 2u;
+                            if (a != 0) {
+                                const uint32_t q = sr_byte(qw, u);
+                                f = (q < 33 || q > 40) ? 2u : 1u;
+                                atomicAdd(&W.namb[r], 1u);
+                            }
+                            atomicOr(&W.fl[r], f);
+                            const uint32_t slot = atomicAdd(&W.nall[r], 1u);
+                            if (slot < 4) W.apos[r][slot] = 16 * ch + u;
+                        }
+                    }
+                }
+            }
+            if (nv) atomicAdd(&W.cnt[r], (unsigned long long)c0 | ((unsigned long long)c1 << 16) | ((unsigned long long)c01 << 32) | ((unsigned long long)cnok << 48));
+        }
+        sync_wave();
+
+        // ---- the records again: what their chunks found ----
+        const uint32_t fl_r = valid ? W.fl[lane] : 0u, namb_r = valid ? W.namb[lane] : 0u, nall_r = valid ? W.nall[lane] : 0u;
+        const bool xfer = (fl_r & 1) && !(fl_r & 2);
+        const uint32_t kept = L - (xfer ? namb_r : 0);
+        if (valid) {
+            const unsigned long long cn = W.cnt[lane];
+            const uint32_t r0 = (uint32_t)(cn & 0xffffu), r1 = (uint32_t)((cn >> 16) & 0xffffu), r01 = (uint32_t)((cn >> 32) & 0xffffu), rok = (uint32_t)(cn >> 48);
+            A.slen[g] = kept | ((nall_r < 7 ? nall_r : 7u) << 28) | ((uint32_t)xfer << 31);
+            if (nall_r >= 1 && nall_r <= 4) A.apos[g] = AmbPos{W.apos[lane][0] | (W.apos[lane][1] << 16), W.apos[lane][2] | (W.apos[lane][3] << 16)};
+            A.bcnt[g] = (uint64_t)(rok - r0 - r1 + r01) | ((uint64_t)(r0 - r01) << 16) | ((uint64_t)(r1 - r01) << 32) | ((uint64_t)r01 << 48);
+            t0 += r0; t1 += r1; t01 += r01; nok += rok;
+            mq = L > mq ? L : mq;
+            ms = kept > ms ? kept : ms;
+            sum_l += L;
+        }
+        // the ambiguous positions, now that the record's transfer decision is known (phyNGSC.cpp:573-599)
+        if (__any(valid && nall_r != 0)) {
+            if (valid && nall_r != 0) {
+                auto one = [&](uint32_t pos, uint32_t c, uint32_t q) __attribute__((always_inline)) {
+                    const uint32_t a = s_amb[c], row = pos + 1;
+                    if (xfer && a > 1) {
+                        atomicAdd(&qh[(size_t)row * 256 + transfer_quality(a, (uint8_t)q)], 1u);   // 128..247: no LDS column
+                    } else {
+                        const uint32_t col = q - 33;
+                        if (col < SR_HCOLS && row < lds_rows) atomicAdd(&s_hist[(8 * (pos >> 4) + (pos & 7)) * SR_HSTRIDE + col], 1u << (2 * (pos & 8)));
+                        else atomicAdd(&qh[(size_t)row * 256 + q], 1u);
+                        atomicAdd(&s_occ[c], 1u);
+                    }
+                };
+                const uint8_t *sp = span + (s0 - lo), *qp = span + (q0 - lo);
+                if (nall_r <= 4) {
+                    for (uint32_t k = 0; k < nall_r; ++k) { const uint32_t pos = W.apos[lane][k]; one(pos, sp[pos], qp[pos]); }
+                } else {
+                    for (uint32_t pos = 0; pos < L; ++pos) {
+                        const uint32_t c = sp[pos];
+                        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) one(pos, c, qp[pos]);
+                    }
+                }
+            }
+        }
+        sync_wave();   // (the span and the tables are rewritten by the next batch)
+    }
+
+    // ---- workgroup totals ----
+    {
+        const uint32_t nG = t01, nC = t0 - t01, nT = t1 - t01, nA = nok - t0 - t1 + t01;
+        const uint32_t wa = sr_wsum(nA), wc = sr_wsum(nC), wg = sr_wsum(nG), wt = sr_wsum(nT);
+        const uint32_t wq = sr_wmax(mq), wms = sr_wmax(ms), wl = sr_wsum(sum_l);
+        if (lane == 0) {
+            atomicAdd(&s_occ['A'], wa); atomicAdd(&s_occ['C'], wc); atomicAdd(&s_occ['G'], wg); atomicAdd(&s_occ['T'], wt);
+            atomicMax(&s_red[0], wq); atomicMax(&s_red[1], wms); atomicAdd(&s_red[2], wl);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nslots * SR_HCOLS; k += THREADS) {
+        const uint32_t slot = k / SR_HCOLS, col = k % SR_HCOLS;
+        const uint32_t x = s_hist[slot * SR_HSTRIDE + col];
+        const uint32_t row = 16 * (slot >> 3) + (slot & 7) + 1;   // the low half's row; the high half's is eight further on
+        if (x & 0xffffu) atomicAdd(&qh[(size_t)row * 256 + 33 + col], x & 0xffffu);
+        if (x >> 16) atomicAdd(&qh[(size_t)(row + 8) * 256 + 33 + col], x >> 16);
+    }
+    if (tid < 256 && s_occ[tid]) atomicAdd(&A.dna_occ[(size_t)s * 256 + tid], s_occ[tid]);
+    if (tid == 0) {
+        atomicMax(&A.sb[s].max_q, s_red[0]);
+        atomicMax(&A.sb[s].max_s, s_red[1]);
+        atomicAdd(&A.sb[s].n_bases, s_red[2]);
+    }
+}
+
+// ====================================================================================================
 // Measure / pack
 // ====================================================================================================
 // Quality code tables in LDS, indexed by the raw quality byte: column = q - 33 (64 columns), row = position
@@ -1543,6 +1865,28 @@ void launch_sq_stats_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint3
             auto mk = k_sq_stats_multi<lpr>;
             if (mlds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mk), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
             hipLaunchKernelGGL(mk, mgrid, dim3(SR_THREADS), mlds, st, A, A.qrows, mrpw, mcap);
+            return;
+        }
+    }
+    // (round 4) unevenly long reads of up to 16 FK bases: the chunks of 16-record batches dealt to the lanes on staged spans
+    // (NGSC_SQ_FLAT=0: the burst form, which reads longer than that and jobs whose table does not fit LDS take anyway)
+    if (!staged && sr_burst(A) && max_rec_bytes && !even && A.qrows - 1 <= 16 * FK &&
+        !(getenv("NGSC_SQ_FLAT") && !strcmp(getenv("NGSC_SQ_FLAT"), "0"))) {
+        // 256 threads with 16 records per wave and batch, or - where that would leave a CU with two workgroups = two waves per SIMD
+        // (a [301]-row histogram beside four 11 KB spans) - 512 threads with 8: eight smaller spans beside one histogram, 16 waves per CU
+        const uint32_t nslots = 8 * ((A.qrows + 14) / 16);
+        const size_t hbytes = (((size_t)nslots * SR_HSTRIDE + 64) * 4 + 15) & ~(size_t)15;
+        const uint32_t cap16 = (16u * max_rec_bytes + 64u + 15u) & ~15u, cap8 = (8u * max_rec_bytes + 64u + 15u) & ~15u;   // (+ the alignment of the span's start and the reach of the last chunk's dword reads)
+        const size_t lds16 = hbytes + 4 * (size_t)cap16, lds8 = hbytes + 8 * (size_t)cap8;
+        const bool wide_wg = lds16 > (50u << 10) && lds8 <= (76u << 10);
+        const size_t flds = wide_wg ? lds8 : lds16;
+        if (flds <= (76u << 10)) {
+            const uint32_t rpb = wide_wg ? 8u * 8u : 4u * 16u;   // records per workgroup round
+            uint32_t frpw = rpw < rpb ? rpb : rpw / rpb * rpb;
+            dim3 fgrid((max_rec + frpw - 1) / frpw, A.n_sb);
+            auto fk = wide_wg ? k_sq_stats_flat<512, 8> : k_sq_stats_flat<256, 16>;
+            if (flds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+            hipLaunchKernelGGL(fk, fgrid, dim3(wide_wg ? 512 : 256), flds, st, A, A.qrows, frpw, wide_wg ? cap8 : cap16);
             return;
         }
     }
