@@ -75,6 +75,26 @@ def draw_dialect(rnd: random.Random, max_mb: float):
     d["P"] = rnd.choice([2, 2, 3, 4, 5, 7, 8, 8, 13, 16])
     mb = rnd.choice([0.02, 0.1, 0.5, 1.0, 3.0, 9.0, 17.0, max_mb])
     d["bytes"] = int(min(mb, max_mb) * (1 << 20))
+    # drawn last, so that every earlier seed keeps its dialect: now and then a title of more than 64 fields
+    if rnd.random() < 0.05:
+        extra = rnd.choice([64, 70, 100, 200, 500]) - nf
+        for _ in range(max(extra, 0)):
+            kind = rnd.choice(["const", "inc", "rand", "text", "fixnum"])
+            f = dict(kind=kind)
+            if kind == "const":
+                f["tok"] = bytes(rnd.choice(TEXT) for _ in range(rnd.randint(0, 3)))
+            elif kind == "inc":
+                f["start"], f["step"], f["every"] = rnd.randint(0, 10 ** 6), 1, rnd.choice([1, 33])
+            elif kind == "rand":
+                f["hi"] = rnd.choice([1, 9, 255, 65536])
+                f["lo"] = 0
+            elif kind == "text":
+                f["alpha"] = bytes(rnd.sample(list(TEXT), rnd.randint(1, 4)))
+                f["len"] = (1, 2)
+            else:
+                f["val"] = rnd.choice([0, 7, 100])
+            d["fields"].append(f)
+            d["seps"].append(rnd.choice(SEPS))
     return d
 
 
