@@ -443,10 +443,16 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const bool zero_on_side = !serial;
     void *const prezero_ptr = c->zero.p;
     const size_t prezero = std::min(c->zero_hint, c->zero.cap);
+    // (round 4) ... the output's clearing only for longer records.  With short ones (under 128 bytes on average: 36-base reads) the
+    // cut planner - 0.05 ms since it looks its windows up with sixteen waves - would wait for the clearing beside it (0.07 ms), while
+    // the sequence/quality side chain behind the statistics kernel has 0.1 ms to spare beside the title statistics: the clearing
+    // goes there (1.960 -> 1.941 ms per GB of 36-base reads; 150-base and 36..300-base jobs, whose side chain has no slack, lose
+    // 1-2 % that way: profiles/r04_ab_zero_late.txt).  The record count is the previous job's (the prediction) or none.
+    const bool zero_late = zero_on_side && spec && (uint64_t)last.n_rec_total * 128 > (uint64_t)len;
     if (zero_on_side) {
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        if (out_prefix) launch_zero_range(c->side_stream, d_out, out_prefix);
+        if (out_prefix && !zero_late) launch_zero_range(c->side_stream, d_out, out_prefix);
         if (spec && prezero) launch_zero_range(c->side_stream, c->zero.p, prezero);
         HIPCHK(c, hipEventRecord(c->ev_join, c->side_stream));
     } else {
@@ -457,7 +463,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         KScope k(c, st, "k_cuts_validate");
         launch_cuts_validate(st, file_size, P, rank_lo, n_ranks, buf_off, d_te, d_se, d_ls, len / 96 + 1, d_total, d_first, d_cuts,
                              max_cuts, d_plans, d_maxq, d_maxrec, d_maxtitle, d_err, buf_off + buf_len == file_size ? buf : nullptr, from,
-                             part ? buf_off + buf_len : 0);
+                             part ? buf_off + buf_len : 0, d_tiles, ntiles);
     }
     if (zero_on_side) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
 
@@ -664,6 +670,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             A.dtail_b = tail_b;
         }
     }
+    // (round 4, measured and not kept: measure and pack dealing each tile's 256 records to their lanes in the order of their lengths,
+    // so that a wave's lanes finish together - no change on 36..300-base reads, 1.849 against 1.854 ms: the pack kernel walks its
+    // table windows behind workgroup barriers whatever its waves hold - and the extra registers and LDS cost the 36-base job
+    // 4 % of its pack kernel; profiles/r04_ab_planner_sorted_lanes.txt)
     A.out = (uint8_t *)d_out;
     uint32_t *d_qrowoff = (uint32_t *)(pb + p_qrowoff);
 
@@ -729,6 +739,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else { KScope k(c, st, "k_seq_qual_stats"); launch_seq_qual_stats(st, A, max_rec); }
     if ((rc = fork_s())) return rc;
     if (stagger) HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
+    if (zero_late && out_prefix && stagger) launch_zero_range(sts, d_out, out_prefix);
+    else if (zero_late && out_prefix) launch_zero_range(st, d_out, out_prefix);
     { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
     { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
     // (round 4, measured and not kept: the payload measure kernel - the side chain's one throughput kernel - on a stream of ordinary
@@ -739,6 +751,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, sts, "k_sq_measure_reg"); launch_sq_measure_reg(sts, A, max_rec); }
     }
     else { KScope k(c, sts, "k_measure_sq"); launch_measure_sq(sts, A, max_rec); }
+    // (round 4, measured and not kept: these small kernels of the title chain on a high-priority stream of their own, so that their
+    // workgroups are not dispatched behind the payload measure kernel's - the two extra stream hops cost what the earlier dispatch
+    // gains: 1.221 / 1.224 ms on 150-base reads, 1.937 / 1.935 on 36..300-base reads, 0.8 % slower at 36 bases; profiles/r04_ab_*)
     if (wide) { KScope k(c, st, "k_title_wide_stats"); launch_title_wide_stats(st, A, max_rec); }
     else {
         if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
@@ -775,7 +790,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // what it shares it loses - 452 against 462 GB/s)
     if (wide) { KScope k(c, st, "k_title_wide_pack"); launch_title_wide_pack(st, A, max_rec); }
     else { KScope k(c, st, "k_title_pack_reg"); launch_title_pack_reg(st, A, max_rec); }
-    if ((rc = join_s())) return rc;
+    // (round 4) the side stream's headers, length tables and result copies are joined BEHIND the payload pack kernel, which reads
+    // nothing of theirs: with long or unequal reads (few records: a short title pack kernel, but as many header bytes) they
+    // used to hold it back - 40 us of a 36..300-base step
     if (sq_reg) {
         // LDS staging of a tile's output: room for 5 quality bits and 2.5 DNA bits per base of R reads of the job's average
         // length, + 10 % (from the record count: no stream size has to come back to the host first; a tile that needs
@@ -792,6 +809,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_sq_pack_reg"); launch_sq_pack_reg(st, A, max_rec, sw_q, sw_d); }
     }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
+    if ((rc = join_s())) return rc;
     // ---- the one sync of a predicted step (the second of a synchronous one): error word, sizes, result tables ----
     uint8_t *hfin = h_small + cs.off + 64;
     HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));

@@ -138,7 +138,9 @@ struct Pool {   // bump allocator over the sub-block's scratch
     }
 };
 
-__device__ bool tree_load(BitIn &r, uint32_t expect_n, Pool &pool, DTree &t, uint16_t *stack /* 2n + 2 */)
+// lc_pre / rc_pre: child tables of n + 1 entries each that the caller has set aside (else they come from the pool)
+__device__ bool tree_load(BitIn &r, uint32_t expect_n, Pool &pool, DTree &t, uint16_t *stack /* 2n + 2 */, uint16_t *lc_pre = nullptr,
+                          uint16_t *rc_pre = nullptr)
 {
     const uint32_t blen = r.u32();
     const uint64_t end = r.pos + (uint64_t)blen * 8;
@@ -146,8 +148,8 @@ __device__ bool tree_load(BitIn &r, uint32_t expect_n, Pool &pool, DTree &t, uin
     (void)r.u8();
     if (r.bad || n != expect_n || n == 0 || n > 512 || root >= 2 * n || end > r.nbits) { r.bad = 1; return false; }
     t.n = n;
-    t.lc = (uint16_t *)pool.take(2 * (n + 1));
-    t.rc = (uint16_t *)pool.take(2 * (n + 1));
+    t.lc = lc_pre ? lc_pre : (uint16_t *)pool.take(2 * (n + 1));
+    t.rc = rc_pre ? rc_pre : (uint16_t *)pool.take(2 * (n + 1));
     if (!t.lc || !t.rc) { r.bad = 2; return false; }
     uint32_t bits_per_id = 0;
     while ((2u << bits_per_id) <= n) ++bits_per_id;
@@ -310,6 +312,13 @@ struct DecCtl {   // state of one sub-block's decode: lane 0 -> wave inside a ke
     uint8_t qsym[256];       // quality alphabet: symbol index -> byte
 };
 
+// vdst's lane `lane_imm` := the scalar s (v_writelane_b32; this compiler has no builtin for it)
+__device__ __forceinline__ uint32_t dec_writelane(uint32_t v, uint32_t s, int lane_imm)
+{
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(lane_imm));
+    return v;
+}
+
 // lens[i] symbols for record i = 0..n-1; PER_POS: symbol j of a record uses table row j + 1 (tasks.cpp:609-619) and its
 // tree trees[j + 1]; else one table / trees[0].  map: symbol index -> output byte (LDS).  kept (nullable): per record, the
 // number of output bytes below 128.  Returns through C.pos / C.err; all lanes call it.
@@ -317,8 +326,9 @@ template <bool PER_POS>
 __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const uint16_t *tab, uint32_t K, const DTree *trees,
                                                  const uint32_t *lens, uint32_t n, uint8_t *dst, uint32_t *kept, const uint8_t *map, uint32_t *s_in,
                                                  uint8_t *s_out, uint32_t nrows, const uint8_t *t_lc = nullptr, const uint8_t *t_rc = nullptr,
-                                                 const uint8_t *t_root = nullptr, uint32_t t_nq = 0)
+                                                 const uint8_t *t_root = nullptr, uint32_t t_nq = 0, bool tab_lds = false)
 {
+    // tab_lds: the per-position table lies in LDS (rows behind a record's last symbol may then be read and thrown away)
     // t_lc / t_rc / t_root (LDS, optional): the rows' trees as byte child tables [row][t_nq] (alphabets of up to 128 symbols) - a code
     // longer than the table's K bits is then walked inside the chain, out of LDS, instead of ending the trip for a walk in global memory
     const uint32_t lane = threadIdx.x;
@@ -339,7 +349,10 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
     // values are wave-uniform, the compiler keeps them in scalar registers and branches without exec-mask bookkeeping (a loop
     // under `if (lane == 0)` was ~190 instructions per symbol, most of them mask handling); stores of identical values to one
     // address are harmless.
-    if (n) { L = U(lens[0]); Lnext = n > 1 ? U(lens[1]) : 0; }
+    // record lengths: the one after next is fetched (into a vector register: no wait) when a record begins, and has that record's
+    // whole decode to arrive - a length read where it was needed cost the chain a trip to memory per record
+    uint32_t Lpre = 0;
+    if (n) { L = U(lens[0]); Lnext = n > 1 ? U(lens[1]) : 0; Lpre = n > 2 ? lens[2] : 0; }
     constexpr uint32_t TS = 12;   // symbols per trip at most
     for (;;) {
         const uint32_t base = wi;
@@ -355,16 +368,19 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
                 opened = true;
             }
             // nb bits leave the window (whole dwords come in from the staged bit string)
+            // (the dword that comes in next is fetched - into a vector register, no wait - as soon as its place is known)
+            uint32_t wpre = s_in[wi - base];
             auto consume = [&](uint32_t nb) __attribute__((always_inline)) {
                 sh += nb;
-                while (sh >= 32) { w0 = w1; w1 = w2; w2 = w3; w3 = U(s_in[wi - base]); ++wi; sh -= 32; }
+                while (sh >= 32) { w0 = w1; w1 = w2; w2 = w3; w3 = U(wpre); ++wi; sh -= 32; wpre = s_in[wi - base]; }
             };
             while (i < n && wi < limit && ko + TS <= DEC_OUT && !bad) {
                 if (j == L) {   // next record (also the empty ones)
                     if (kept) kept[i] = kc;
                     kc = 0; j = 0; ++i;
                     L = Lnext;
-                    Lnext = i + 1 < n ? U(lens[i + 1]) : 0;
+                    Lnext = U(Lpre);
+                    Lpre = i + 2 < n ? lens[i + 2] : 0;
                     continue;
                 }
                 // (round 4) Up to TS symbols per trip.  Lane o stands for bit offset o of the window: it looks up, for each of the next
@@ -378,47 +394,82 @@ __device__ __forceinline__ void dec_symbols_wave(const uint8_t *p, uint64_t nbit
                 {
                     const uint32_t so = sh + lane, d = so >> 5, r = so & 31u;           // (so <= 94: dwords d, d + 1 of the four)
                     const uint32_t hi = d == 0 ? w0 : (d == 1 ? w1 : w2), lo = d == 0 ? w1 : (d == 1 ? w2 : w3);
-                    const uint32_t field = (uint32_t)(((((uint64_t)hi << 32) | lo) << r) >> (64 - K));
+                    // the K bits at offset so: the top of (hi:lo) << r, with 32-bit funnel shifts
+                    const uint32_t top = r ? __builtin_amdgcn_alignbit(hi, lo, 32u - r) : hi;
+                    const uint32_t field = top >> (32u - K);
+                    if (!PER_POS || (tab_lds && j + TS < nrows)) {
+                        // rows j + 1 .. j + TS, all of them inside the table: one address and a stride (what lies behind the
+                        // record's last symbol is read and never looked at)
+                        const uint16_t *pl = tab + (PER_POS ? ((size_t)(j + 1) << K) : (size_t)0) + field;
+                        const uint32_t rs = PER_POS ? (1u << K) : 0u;
 #pragma unroll
-                    for (uint32_t t = 0; t < TS; ++t) {
-                        ev[t] = 0;
-                        if (t < T) {
-                            const uint32_t row = PER_POS ? (j + 1 + t < nrows ? j + 1 + t : nrows - 1) : 0;
-                            ev[t] = tab[((size_t)row << K) + field];
+                        for (uint32_t t = 0; t < TS; ++t) ev[t] = pl[(size_t)t * rs];
+                    } else {
+#pragma unroll
+                        for (uint32_t t = 0; t < TS; ++t) {
+                            ev[t] = 0;
+                            if (t < T) {
+                                const uint32_t row = PER_POS ? (j + 1 + t < nrows ? j + 1 + t : nrows - 1) : 0;
+                                ev[t] = tab[((size_t)row << K) + field];
+                            }
                         }
                     }
                 }
-                uint32_t o = 0, cnt = 0;
+                // (round 4, second step) The chain is branch-free: lane o of nx[t] holds the offset behind symbol t if it starts at o
+                // (o itself where the entry is an escape: the chain then stays put), and symbol t + 1's start is ONE v_readlane of
+                // nx[t] at symbol t's start - twelve dependent instructions.  Which symbols were really there is decided afterwards,
+                // in vector form: lane t gets symbol t's start and entry (written with v_writelane), a symbol counts while every one
+                // before it had an entry and started inside the window.  (The scalar loop this replaces tested, branched and stored
+                // per symbol: ~30 scalar instructions and four taken branches each, 400 cycles per symbol with one wave on the SIMD.)
+                uint32_t so[TS + 1];
+                so[0] = 0;
+                uint32_t ovec = 0, evec = 0;
 #pragma unroll
                 for (uint32_t t = 0; t < TS; ++t) {
-                    if (t < T && cnt == t && o < 64) {
-                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ev[t], (int)o) & 0xffffu;
-                        uint32_t sym = e & 0xffu, len = e >> 12;
-                        bool ok = e != 0;
-                        if (!e && t_lc) {   // longer than K bits (or a one-symbol tree): the row's tree, bit by bit out of the window
-                            const uint32_t row = PER_POS ? (j + 1 + t < nrows ? j + 1 + t : nrows - 1) : 0, rowo = row * t_nq;
-                            uint32_t node = U(t_root[row]);
-                            len = 0;
-                            ok = true;
-                            while (node >= t_nq) {
-                                const uint32_t bp = sh + o + len;
-                                if (bp >= 128 || len >= 32) { ok = false; break; }
-                                const uint32_t wsel = bp < 32 ? w0 : (bp < 64 ? w1 : (bp < 96 ? w2 : w3));
-                                node = U(((wsel << (bp & 31u)) >> 31) ? t_rc[rowo + node - t_nq] : t_lc[rowo + node - t_nq]);
-                                ++len;
-                            }
-                            sym = U(map[node & 0xffu]);
-                        }
-                        if (ok) {
-                            s_out[ko + t] = (uint8_t)sym;
-                            kc += sym < 128;
-                            o += len;
-                            cnt = t + 1;
-                        }
-                    }
+                    const uint32_t nx = lane + (ev[t] >> 12);
+                    const uint32_t at = so[t] & 63u;
+                    so[t + 1] = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)at);   // (behind a symbol that starts beyond the window: anything - it does not count, nor do its successors)
+                    const uint32_t e_t = (uint32_t)__builtin_amdgcn_readlane((int)ev[t], (int)at);
+                    ovec = dec_writelane(ovec, so[t], t);
+                    evec = dec_writelane(evec, e_t, t);
                 }
-                if (cnt) consume(o);
-                else {   // a code longer than K bits (or a one-symbol tree, whose codes have no bits): walk the tree
+                const bool there = lane < T && ovec < 64u && (evec >> 12) != 0;
+                const unsigned long long gone = ~__ballot(there);
+                uint32_t cnt = (uint32_t)__builtin_ctzll(gone);   // (lanes >= T are never there: gone != 0)
+                uint32_t o_end = 0;
+                if (cnt) {
+                    const uint32_t sym = evec & 0xffu;
+                    if (lane < cnt) s_out[ko + lane] = (uint8_t)sym;
+                    kc += (uint32_t)__popcll(__ballot(lane < cnt && sym < 128u));
+                    o_end = (uint32_t)__builtin_amdgcn_readlane((int)(ovec + (evec >> 12)), (int)(cnt - 1));
+                }
+                if (t_lc && cnt < T && o_end < 64u) {
+                    // the symbol the chain stopped at has a code longer than K bits (or its tree one symbol): the row's tree out of LDS,
+                    // bit by bit out of the window - from the node its first K bits lead to where the table knows it (entry 0x800 |
+                    // internal node, dec_mark_long_codes), else from the root
+                    const uint32_t e_x = (uint32_t)__builtin_amdgcn_readlane((int)evec, (int)cnt);
+                    const uint32_t row = PER_POS ? (j + 1 + cnt < nrows ? j + 1 + cnt : nrows - 1) : 0, rowo = row * t_nq;
+                    const bool from_node = (e_x & 0x800u) != 0;
+                    uint32_t node = from_node ? t_nq + (e_x & 0x7ffu) : U(t_root[row]), len = from_node ? K : 0u;
+                    bool ok = true;
+                    while (node >= t_nq) {
+                        const uint32_t bp = sh + o_end + len;
+                        if (bp >= 128 || len >= 32) { ok = false; break; }
+                        const uint32_t wsel = bp < 32 ? w0 : (bp < 64 ? w1 : (bp < 96 ? w2 : w3));
+                        node = U(((wsel << (bp & 31u)) >> 31) ? t_rc[rowo + node - t_nq] : t_lc[rowo + node - t_nq]);
+                        ++len;
+                    }
+                    if (ok) {
+                        const uint32_t sym = U(map[node & 0xffu]);
+                        s_out[ko + cnt] = (uint8_t)sym;
+                        kc += sym < 128;
+                        o_end += len;
+                        ++cnt;
+                    } else if (!cnt) bad = 1;   // (with symbols in hand the window moves on and the next trip looks again)
+                }
+                if (cnt) consume(o_end);
+                else if (t_lc) { if (!bad) bad = 1; }   // (cannot happen: the first symbol of a trip starts at offset 0, inside the window)
+                else {   // ... or in global memory
                     const DTree &Tr = trees[PER_POS ? j + 1 : 0];
                     const uint32_t tn = U(Tr.n);
                     uint32_t node = U(Tr.root), steps = 0;
@@ -553,45 +604,87 @@ __device__ int dec_head(BitIn &r, DecScratch &D, Pool &pool, DecSub &O, DField *
     return OK;
 }
 
-// Lane 0, behind the title body: quality alphabet and trees.
-__device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qsym, uint16_t *s_qtab, uint32_t lds_entries, DecCtl &C, uint16_t *stack)
+// The whole wave, behind the title body: quality alphabet and trees.
+// (round 4) The max_q + 1 trees are loaded by the LANES, a tree each: lane 0 reads the alphabet and hops from blob to blob over their
+// length words, then every lane parses its trees' pre-order strings and fills their tables.  One lane doing all of it took 120 us
+// per tree: 37 ms of a 36..300-base sub-block's decode.
+__device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qsym, DecCtl &C, uint32_t *s_x /* 8 words of LDS */)
 {
-    const uint32_t n = C.n, max_q = C.max_q, nqual = C.nqual;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t max_q = C.max_q, nqual = C.nqual;
     const uint64_t qual_total = C.qual_total;
-    (void)n;
-    // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees; the codes are decoded by the wave ----
-    const uint64_t text = C.text;   // bytes of the text area the value table and the text fields' characters take
-    const uint64_t q_at = (text + 15) & ~15ull, s_at = q_at + ((qual_total + 15) & ~15ull);
-    if (s_at + qual_total > D.tcap) return ERR_CAPACITY;
-    D.lay[0] = q_at; D.lay[1] = s_at;
-    r.align();
-    for (uint32_t i = 0; i < 256; ++i) qsym[i] = 0;
-    for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
-    DTree *qt = (DTree *)pool.take(sizeof(DTree) * ((uint64_t)max_q + 1));
-    if (!qt) return ERR_NOMEM;
-    // the per-position tables, DEC_K bits wide, in the pool: the kernels that decode the symbols copy what fits into LDS
-    // (narrower if need be: dec_fill_lds_table)
-    // (as wide as the pool allows next to the trees themselves - two child tables of nqual + 1 entries each - and what the base
-    // stream needs later: reads of 3 000 bases and more have 3 001 trees, whose 9-bit tables alone are 3.4 MB of the 4 MB pool;
-    // found by the round-3 fuzz run, seeds 400796 / 400922: NGSC_ERR_NOMEM for such files)
-    uint32_t Kq = DEC_K;
+    const uint64_t rows = (uint64_t)max_q + 1;
+    // s_x: [0] error, [1] Kq, [2..3] qt, [4..5] qtab, [6..7] the lanes' work area
+    if (lane == 0) {
+        int err = OK;
+        // ---- quality (cf. FetchQuality tasks.cpp:1036-1101): alphabet, max_q + 1 trees; the codes are decoded by the wave ----
+        const uint64_t text = C.text;   // bytes of the text area the value table and the text fields' characters take
+        const uint64_t q_at = (text + 15) & ~15ull, s_at = q_at + ((qual_total + 15) & ~15ull);
+        if (s_at + qual_total > D.tcap) err = ERR_CAPACITY;
+        D.lay[0] = q_at; D.lay[1] = s_at;
+        r.align();
+        for (uint32_t i = 0; i < 256; ++i) qsym[i] = 0;
+        for (uint32_t i = 0; i < nqual; ++i) qsym[i] = (uint8_t)r.bits(8);
+        DTree *qt = (DTree *)pool.take(sizeof(DTree) * rows);
+        // per tree: two child tables of nqual + 1 entries; per lane: a traversal stack of 2 nqual + 2 entries; a start position per tree
+        const uint64_t per_tree = (4ull * (nqual + 1) + 7) & ~7ull, per_lane = (2ull * (2 * nqual + 2) + 7) & ~7ull;
+        uint8_t *work = (uint8_t *)pool.take(rows * per_tree + 64 * per_lane + 8 * rows);
+        // the per-position tables, DEC_K bits wide, in the pool: the kernels that decode the symbols copy what fits into LDS
+        // (narrower if need be: dec_fill_lds_table)
+        // (as wide as the pool allows next to what the base stream needs later: reads of 3 000 bases and more have 3 001 trees,
+        // whose 9-bit tables alone are 3.4 MB of the 4 MB pool; found by the round-3 fuzz run, seeds 400796 / 400922:
+        // NGSC_ERR_NOMEM for such files)
+        uint32_t Kq = DEC_K;
+        {
+            const uint64_t keep = 96u << 10;
+            const uint64_t room = pool.cap > pool.off + keep ? pool.cap - pool.off - keep : 0;
+            while (Kq > 5 && ((rows << Kq) * 2) > room) --Kq;
+        }
+        uint16_t *qtab = (uint16_t *)pool.take((rows << Kq) * 2);
+        if (!err && (!qt || !work || !qtab)) err = ERR_NOMEM;
+        if (!err) {
+            uint64_t *start = (uint64_t *)(work + rows * per_tree + 64 * per_lane);
+            for (uint32_t p = 0; p <= max_q; ++p) {   // blob p: a length word, then that many bytes
+                r.align();
+                start[p] = r.pos;
+                const uint32_t blen = r.u32();
+                if (r.bad || r.pos + (uint64_t)blen * 8 > r.nbits) { err = ERR_FORMAT; break; }
+                r.seek(r.pos + (uint64_t)blen * 8);
+            }
+        }
+        s_x[0] = (uint32_t)err; s_x[1] = Kq;
+        s_x[2] = (uint32_t)(uintptr_t)qt; s_x[3] = (uint32_t)((uintptr_t)qt >> 32);
+        s_x[4] = (uint32_t)(uintptr_t)qtab; s_x[5] = (uint32_t)((uintptr_t)qtab >> 32);
+        s_x[6] = (uint32_t)(uintptr_t)work; s_x[7] = (uint32_t)((uintptr_t)work >> 32);
+    }
+    __syncthreads();
+    if (s_x[0]) return (int)s_x[0];
+    const uint32_t Kq = s_x[1];
+    DTree *qt = (DTree *)(uintptr_t)(((uint64_t)s_x[3] << 32) | s_x[2]);
+    uint16_t *qtab = (uint16_t *)(uintptr_t)(((uint64_t)s_x[5] << 32) | s_x[4]);
+    uint8_t *work = (uint8_t *)(uintptr_t)(((uint64_t)s_x[7] << 32) | s_x[6]);
     {
-        const uint64_t rows = (uint64_t)max_q + 1;
-        const uint64_t trees = rows * (4ull * (nqual + 2) + 16) + (96u << 10);
-        const uint64_t room = pool.cap > pool.off + trees ? pool.cap - pool.off - trees : 0;
-        while (Kq > 5 && ((rows << Kq) * 2) > room) --Kq;
+        const uint64_t per_tree = (4ull * (nqual + 1) + 7) & ~7ull, per_lane = (2ull * (2 * nqual + 2) + 7) & ~7ull;
+        const uint64_t *start = (const uint64_t *)(work + rows * per_tree + 64 * per_lane);
+        uint16_t *stack = (uint16_t *)(work + rows * per_tree + (uint64_t)lane * per_lane);
+        uint32_t bad = 0;
+        for (uint32_t p = lane; p <= max_q; p += 64) {
+            BitIn rr = r;
+            rr.bad = 0;
+            rr.seek(start[p]);
+            qt[p].n = 0;
+            uint16_t *lc = (uint16_t *)(work + (uint64_t)p * per_tree);
+            if (tree_load(rr, nqual, pool, qt[p], stack, lc, lc + nqual + 1)) tree_table(qt[p], qtab + ((size_t)p << Kq), Kq, qsym);
+            bad |= rr.bad;
+        }
+        if (__any(bad != 0)) return ERR_FORMAT;
     }
-    (void)s_qtab; (void)lds_entries;
-    uint16_t *qtab = (uint16_t *)pool.take((((uint64_t)max_q + 1) << Kq) * 2);
-    if (!qtab) return ERR_NOMEM;
-    for (uint32_t p = 0; p <= max_q && !r.bad; ++p) {
-        qt[p].n = 0;
-        if (tree_load(r, nqual, pool, qt[p], stack)) tree_table(qt[p], qtab + ((size_t)p << Kq), Kq, qsym);
+    __syncthreads();
+    if (lane == 0) {
+        r.align();
+        C.Kq = Kq; C.q_lds = 0u; C.qtab = qtab; C.qt = qt;
+        C.pos = r.pos;
     }
-    r.align();
-    if (r.bad) return r.bad == 2 ? ERR_NOMEM : ERR_FORMAT;
-    C.Kq = Kq; C.q_lds = 0u; C.qtab = qtab; C.qt = qt;
-    C.pos = r.pos;
     return OK;
 }
 
@@ -604,11 +697,17 @@ __device__ int dec_head_quality(BitIn &r, DecScratch &D, Pool &pool, uint8_t *qs
 // words with all its threads.  Every lane runs the walk on the same values (readfirstlane on what comes from memory), so
 // it compiles to scalar code as in dec_symbols_wave; the bit string comes through the same LDS staging.
 constexpr uint32_t DEC_TPTR_FIELDS = 4, DEC_TPTR_POS = 32;   // text-field table pointers cached in LDS: fields x positions
+constexpr uint32_t DEC_TSLOTS = 24;   // ... and as many of the tables themselves (1 KB each)
+constexpr uint32_t DEC_THAM = 64;     // ... and the first bytes of those fields' Hamming flags / first values
 
 __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t nbits, DecCtl &C, const VField *VF, uint32_t nvf, uint32_t nvw,
                                                     const DField *F, uint32_t *vtab, uint8_t *tchars, uint64_t tchar_cap, uint32_t *s_in,
-                                                    int32_t *s_prev, uint32_t *s_gv, const uint16_t *const *s_tptr, uint8_t *s_gfl)
+                                                    int32_t *s_prev, uint32_t *s_gv, const uint16_t *const *s_tptr, uint8_t *s_gfl,
+                                                    const uint8_t *s_tslot, const uint16_t *s_ttab, const uint8_t *s_ham, const uint8_t *s_d0)
 {
+    // s_tslot / s_ttab / s_ham / s_d0 (round 4): LDS copies of the first text fields' per-position tables, Hamming flags and first
+    // values - a character read them from global memory one after the other, two or three round trips each: 4 us per record of a
+    // title with a flag and a six-letter barcode, 100 ms per sub-block
     // s_gfl: the group flags of the varying fields from the 65th on (a byte each; the first 64 live in a register pair)
     const uint32_t lane = threadIdx.x;
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(p);
@@ -700,14 +799,19 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
             const DTree *tl = (const DTree *)(uintptr_t)ptr64(fd.l);
             for (uint32_t j = 0; j < L && !bad; ++j) {
                 uint32_t ch;
-                if (j < c.len0 && U(ham[j])) ch = U(d0[j]);
+                const bool cached = k < DEC_TPTR_FIELDS && j < DEC_THAM;
+                if (j < c.len0 && U(cached ? s_ham[k * DEC_THAM + j] : ham[j])) ch = U(cached ? s_d0[k * DEC_THAM + j] : d0[j]);
                 else {
                     const uint32_t tj = j < MAX_STAT_LEN ? j : MAX_STAT_LEN;
                     const DTree *t = tl + tj;
                     const uint16_t *tab;
                     if (k < DEC_TPTR_FIELDS && tj < DEC_TPTR_POS) {
-                        tab = (const uint16_t *)(uintptr_t)ptr64(s_tptr[k * DEC_TPTR_POS + tj]);
-                        if (!tab && !U(t->n)) { bad = 1; break; }
+                        const uint32_t slot = U(s_tslot[k * DEC_TPTR_POS + tj]);
+                        if (slot != 0xffu) tab = s_ttab + ((size_t)slot << DEC_K);
+                        else {
+                            tab = (const uint16_t *)(uintptr_t)ptr64(s_tptr[k * DEC_TPTR_POS + tj]);
+                            if (!tab && !U(t->n)) { bad = 1; break; }
+                        }
                     } else {
                         if (!U(t->n)) { bad = 1; break; }
                         tab = (const uint16_t *)(uintptr_t)ptr64(t->tab);
@@ -801,6 +905,9 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     __shared__ int32_t *s_prevp;
     __shared__ uint32_t *s_gvp;
     __shared__ const uint16_t *s_tptr[DEC_TPTR_FIELDS * DEC_TPTR_POS];
+    __shared__ uint8_t s_tslot[DEC_TPTR_FIELDS * DEC_TPTR_POS];
+    __shared__ __align__(16) uint16_t s_ttab[DEC_TSLOTS << DEC_K];
+    __shared__ uint8_t s_ham[DEC_TPTR_FIELDS * DEC_THAM], s_d0[DEC_TPTR_FIELDS * DEC_THAM];
     __shared__ uint32_t s_in[DEC_IN_DW + 4];
     __shared__ DecCtl C;
     __shared__ uint32_t s_nv[2];
@@ -903,12 +1010,33 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
     }
     __syncthreads();
     if (C.err) return;
+    {   // the first text fields' tables, Hamming flags and first values into LDS (all lanes)
+        if (lane == 0) {
+            uint32_t ns = 0;
+            for (uint32_t k = 0; k < DEC_TPTR_FIELDS * DEC_TPTR_POS; ++k) s_tslot[k] = (s_tptr[k] && ns < DEC_TSLOTS) ? (uint8_t)ns++ : (uint8_t)0xff;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < DEC_TPTR_FIELDS * DEC_TPTR_POS; ++k) {
+            const uint32_t slot = s_tslot[k];
+            if (slot == 0xffu) continue;
+            const uint16_t *src = s_tptr[k];
+            for (uint32_t x = lane; x < (1u << DEC_K); x += 64) s_ttab[(slot << DEC_K) + x] = src[x];
+        }
+        const uint32_t nvf = s_nv[0];
+        for (uint32_t k = 0; k < DEC_TPTR_FIELDS && k < nvf; ++k) {
+            const VField &v = s_VFp[k];
+            uint8_t hm = 0, dv = 0;
+            if (v.kind == 2 && lane < v.len0 && lane < DEC_THAM) { const DField &fd = s_Fp[v.f]; hm = fd.ham[lane]; dv = fd.data0[lane]; }
+            if (lane < DEC_THAM) { s_ham[k * DEC_THAM + lane] = hm; s_d0[k * DEC_THAM + lane] = dv; }
+        }
+        __syncthreads();
+    }
     const uint64_t tp2 = wall_clock64();
     {
         const uint64_t vbytes = O.tchar_off;
         const uint64_t room = D.tcap - vbytes - 2 * C.qual_total;   // what is left for the text fields' characters (32 bytes kept for alignment)
         dec_title_body_wave(r.p, r.nbits, C, s_VFp, s_nv[0], s_nv[1], s_Fp, (uint32_t *)D.titles, D.titles + vbytes, room > 64 ? room - 64 : 0, s_in,
-                            s_prevp, s_gvp, s_tptr, s_gfl);
+                            s_prevp, s_gvp, s_tptr, s_gfl, s_tslot, s_ttab, s_ham, s_d0);
     }
     if (C.err) { if (lane == 0) O.err = C.err; return; }
     const uint64_t tp3 = wall_clock64();
@@ -942,7 +1070,15 @@ __global__ __launch_bounds__(64) void k_dec_head(const uint8_t *sub, const uint6
         O.t_ph[0] = tp1 - t0; O.t_ph[1] = tp2 - tp1; O.t_ph[2] = tp3 - tp2; O.t_ph[3] = tp4 - tp3;
         C.text += O.tchar_off;   // the value table and the characters
         r.seek(C.pos);
-        C.err = dec_head_quality(r, D, pool, C.qsym, nullptr, 0, C, stack);
+    }
+    __syncthreads();
+    {
+        __shared__ uint32_t s_x[8];
+        const int qerr = dec_head_quality(r, D, pool, C.qsym, C, s_x);
+        __syncthreads();
+        if (lane == 0 && qerr) C.err = qerr;
+    }
+    if (lane == 0) {
         if (C.err) O.err = C.err;
         C.pool_off = pool.off;
         C.t_head = wall_clock64() - t0;
@@ -1317,7 +1453,20 @@ __global__ __launch_bounds__(64) void k_dec_tail(const uint8_t *sub, const uint6
             for (uint32_t k = lane; k < rows; k += 64) t_root[k] = C.qt[k].n == nq ? (uint8_t)C.qt[k].root : (uint8_t)0;
         }
         const uint32_t Kl = dec_fill_lds_table(s_qtab, tab_entries, C.qtab, C.Kq, rows);
-        if (Kl) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, Kl, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, rows, t_lc, t_rc, t_root, tree_bytes ? nq : 0u);
+        if (Kl && tree_bytes) {
+            // (dec_mark_long_codes) a prefix whose code is longer than Kl bits: the internal node those Kl bits lead to, so that the
+            // decoder's walk starts there instead of at the root
+            const uint32_t total = rows << Kl;
+            for (uint32_t k = lane; k < total; k += 64) {
+                if (s_qtab[k]) continue;
+                const uint32_t row = k >> Kl, x = k & ((1u << Kl) - 1u);
+                uint32_t node = t_root[row], b = Kl;
+                while (b && node >= nq) { --b; node = ((x >> b) & 1u) ? t_rc[row * nq + node - nq] : t_lc[row * nq + node - nq]; }
+                if (!b && node >= nq && node - nq < 0x800u) s_qtab[k] = (uint16_t)(0x800u | (node - nq));
+            }
+            __syncthreads();
+        }
+        if (Kl) dec_symbols_wave<true>(r.p, r.nbits, C, s_qtab, Kl, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, rows, t_lc, t_rc, t_root, tree_bytes ? nq : 0u, true);
         else dec_symbols_wave<true>(r.p, r.nbits, C, C.qtab, C.Kq, C.qt, D.qlen, n, d_qual, D.slen, s_map, s_in, s_out, rows);
         __syncthreads();
         if (C.err) { if (lane == 0) O.err = C.err; return; }

@@ -381,7 +381,28 @@ struct CachedSearch {
     uint32_t nwin;
     mutable uint32_t next;          // the stretch the next window's bounds are expected in
     WaveSearch ws;
-    __device__ uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const { return ws.one(a, n, key); }
+    const uint32_t *tile_off, *total_lines;   // the index kernel's line count in front of every 64 KiB tile (or nullptr)
+    uint32_t n_tiles;
+#ifdef NGSC_PLAN_TIMING
+    mutable uint32_t miss_pair = 0, miss_at = 0;
+#endif
+    // the records among which ls[r] >= key begins: those of the tile that holds byte key - 1 (ls[r] >= key <=> r >= (lines that end
+    // in front of byte key - 1, + 1) / 4, rounded up, and the tile's line counts bracket that number)
+    __device__ bool bracket(uint64_t key, uint32_t &lo, uint32_t &span) const
+    {
+        const uint64_t t = key ? (key - 1) / TILE_BYTES : 0;
+        if (!tile_off || t >= n_tiles) return false;
+        const uint32_t l_lo = tile_off[t], l_hi = t + 1 < n_tiles ? tile_off[t + 1] : *total_lines;
+        lo = l_lo / 4 ? l_lo / 4 - 1 : 0;
+        span = l_hi / 4 + 3 - lo;
+        return true;
+    }
+    __device__ uint32_t one(const uint32_t *a, uint32_t n, uint64_t key) const
+    {
+        uint32_t lo, span, r0, r1;
+        if (a == ls_ptr && bracket(key, lo, span)) { ws.pair(a, n, key, a, 0, 0, lo, span, r0, r1); return r0; }
+        return ws.one(a, n, key);
+    }
     // lower bound of key among the parked entries of stretch k, if they decide it (sorted; entries behind the table's end are ~0)
     __device__ bool lookup(const uint32_t (*tab)[PL_ENT], uint32_t k, uint64_t key, uint32_t &res) const
     {
@@ -413,6 +434,9 @@ struct CachedSearch {
             rb = fb < lb ? lb : (fb > hib ? hib : fb);
             return;
         }
+#ifdef NGSC_PLAN_TIMING
+        ++miss_pair;
+#endif
         ws.pair(a, na, ka, b, nb, kb, lo, span, ra, rb, hint);
     }
     __device__ uint32_t at(const uint32_t *a, uint32_t idx) const
@@ -428,6 +452,9 @@ struct CachedSearch {
                 }
             }
         }
+#ifdef NGSC_PLAN_TIMING
+        ++miss_at;
+#endif
         return a[idx];
     }
 };
@@ -435,12 +462,13 @@ struct CachedSearch {
 // One launch, two jobs that do not depend on each other: workgroups [0, n_ranks) plan the sub-block cuts of
 // one rank each (a serial chain of binary searches over the record table, see plan_rank()), the others
 // validate the structure of every record and reduce the job-wide maxima while those chains run.
-__global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks,
+constexpr uint32_t CV_THREADS = 1024;   // (round 4) sixteen waves: a window of the planner's look-ahead each, see below
+__global__ __launch_bounds__(CV_THREADS) void k_cuts_validate(uint64_t file_size, uint32_t P, uint32_t rank_lo, uint32_t n_ranks,
                                                        uint64_t buf_off, const uint32_t *te, const uint32_t *se, const uint32_t *ls,
                                                        const uint32_t *total_lines, const uint64_t *first_abs, Cut *cuts,
                                                        uint32_t max_cuts, RankPlan *plans, uint32_t *max_q, uint32_t *max_rec,
                                                        uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, PlanResume from,
-                                                       uint64_t buf_end_abs)
+                                                       uint64_t buf_end_abs, const uint32_t *tile_off, uint32_t n_tiles)
 {
     const uint32_t n_rec_total = *total_lines / 4;
     // tail_buf: the job buffer when it ends where the file ends.  Two real newlines behind the last complete record (the
@@ -452,6 +480,10 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
     if (blockIdx.x < n_ranks) {
         const uint32_t i = blockIdx.x;
         __shared__ PlanCache s_pc;
+        const CachedSearch cs0{&s_pc, te, ls, 0, 0, WaveSearch(), tile_off, total_lines, n_tiles};
+#ifdef NGSC_PLAN_TIMING
+        const uint64_t tm0 = wall_clock64();
+#endif
         const RankGeom g = rank_geometry(file_size, P, rank_lo + i);
         uint32_t nwin = 0;
         {
@@ -465,15 +497,24 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
                 const uint64_t w = ((uint64_t)g.region + D - 1) / D + 1;
                 nwin = w < PL_WIN ? (uint32_t)w : PL_WIN;
             }
-            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            for (uint32_t k = wave; k < nwin; k += 4) {
+            // (round 4) The look-ahead was 55 of the kernel's 95 us on the 1 GB job: four waves took four windows each, one after the
+            // other, and a window's search by record density went wrong often enough to cost eight trips to memory.  Now a wave per
+            // window, and the search starts from the index kernel's line count in front of the window's 64 KiB tile: the bound
+            // lies among that tile's records (two 64-way rounds).  (Whatever is parked is checked when it is used: a wrong range
+            // here costs a search later, never a wrong cut.)
+            const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+            for (uint32_t k = wave; k < nwin; k += nwaves) {
                 const uint64_t key = x0 - buf_off + (uint64_t)(k + 1) * D;
                 uint32_t b0 = 0xffffffffu;
                 if (key <= (uint64_t)last_ls) {
-                    // where the job's record density puts the bound; the probes of the first round lie around it
-                    const uint64_t guess = key * n_rec_total / ((uint64_t)last_ls + 1);
-                    uint32_t r0, r1;
-                    WaveSearch().pair(ls, (uint32_t)n_ls, key, ls, (uint32_t)n_ls, key, 0, (uint32_t)n_ls, r0, r1, (uint32_t)guess);
+                    uint32_t r0, r1, lo, span;
+                    if (cs0.bracket(key, lo, span)) {
+                        WaveSearch().pair(ls, (uint32_t)n_ls, key, ls, (uint32_t)n_ls, key, lo, span, r0, r1);
+                    } else {
+                        // where the job's record density puts the bound; the probes of the first round lie around it
+                        const uint64_t guess = key * n_rec_total / ((uint64_t)last_ls + 1);
+                        WaveSearch().pair(ls, (uint32_t)n_ls, key, ls, (uint32_t)n_ls, key, 0, (uint32_t)n_ls, r0, r1, (uint32_t)guess);
+                    }
                     b0 = r0 >= 8 ? r0 - 8 : 0;
                     for (uint32_t j = lane; j < PL_ENT; j += 64) {
                         const uint64_t e = (uint64_t)b0 + j;
@@ -486,9 +527,17 @@ __global__ __launch_bounds__(256) void k_cuts_validate(uint64_t file_size, uint3
         }
         __syncthreads();
         if (threadIdx.x >= 64) return;   // one wave per rank runs the chain; all its lanes run the (uniform) planner, the searches are wave-wide
-        CachedSearch cs{&s_pc, te, ls, nwin, 0, WaveSearch()};
+#ifdef NGSC_PLAN_TIMING
+        const uint64_t tm1 = wall_clock64();
+#endif
+        CachedSearch cs{&s_pc, te, ls, nwin, 0, WaveSearch(), tile_off, total_lines, n_tiles};
         int rc = plan_rank_with(cs, file_size, P, rank_lo + i, buf_off, te, ls, n_rec_total, first_abs[i],
                                 cuts + (size_t)i * max_cuts, max_cuts, &plans[i], &from, buf_end_abs);
+#ifdef NGSC_PLAN_TIMING
+        if (threadIdx.x == 0 && (i == 0 || i + 1 == n_ranks))
+            printf("plan rank %u: nwin %u, cache fill %.2f us, chain %.2f us, cuts %u, searches not answered by the cache %u, loads %u\n", i, nwin,
+                   (double)(tm1 - tm0) / 100.0, (double)(wall_clock64() - tm1) / 100.0, plans[i].n_cuts, cs.miss_pair, cs.miss_at);
+#endif
         // ... and behind the first record of a window the loop does not skip that byte (phyNGSC.cpp:295-300): there two
         // blank lines qualify as well
         if (!rc && tail_buf && (*total_lines & 3u) == 3u && n_rec_total) {
@@ -541,15 +590,16 @@ void launch_cuts_validate(hipStream_t st, uint64_t file_size, uint32_t P, uint32
                           const uint32_t *te, const uint32_t *se, const uint32_t *ls, uint32_t n_rec, const uint32_t *total_lines,
                           const uint64_t *first_abs, Cut *cuts, uint32_t max_cuts, RankPlan *plans, uint32_t *max_q,
                           uint32_t *max_rec, uint32_t *max_title, int32_t *err, const uint8_t *tail_buf, const PlanResume &from,
-                          uint64_t buf_end_abs)
+                          uint64_t buf_end_abs, const uint32_t *tile_off, uint32_t n_tiles)
 {
     // ~8 records per validating thread (grid-stride, so any estimate works): few fat workgroups instead of one tiny
     // wave per 64 records
-    uint32_t vblocks = (n_rec + 2047) / 2048;
+    uint32_t vblocks = (n_rec + 8 * CV_THREADS - 1) / (8 * CV_THREADS);
     if (vblocks < 1) vblocks = 1;
-    if (vblocks > 16384) vblocks = 16384;
-    hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(256), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
-                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs);
+    if (vblocks > 4096) vblocks = 4096;
+    hipLaunchKernelGGL(k_cuts_validate, dim3(n_ranks + vblocks), dim3(CV_THREADS), 0, st, file_size, P, rank_lo, n_ranks, buf_off, te, se,
+                       ls, total_lines, first_abs, cuts, max_cuts, plans, max_q, max_rec, max_title, err, tail_buf, from, buf_end_abs,
+                       tile_off, n_tiles);
 }
 
 }  // namespace ngsc

@@ -221,14 +221,14 @@ constexpr uint32_t NH_LDS_FIELDS = 8;
 constexpr uint32_t TH_BATCHES = 16;
 constexpr uint32_t TH_TEXT = 2, TH_ROWS = 16;
 
-__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv)
+__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
     const uint32_t n = sb.n_rec, rec_lo = sb.rec_lo, nf = sb.nf;
-    const uint32_t wg_first = blockIdx.x * TS_OWNED * TH_BATCHES;
+    const uint32_t wg_first = blockIdx.x * TS_OWNED * batches;
     if (wg_first >= n) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint8_t *buf = A.buf;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     if (!need) return;
     const bool walk = s_walk != 0;
 
-    for (uint32_t batch = 0; batch < TH_BATCHES; ++batch) {
+    for (uint32_t batch = 0; batch < batches; ++batch) {
         const uint32_t b_first = wg_first + batch * TS_OWNED;
         if (b_first >= n) break;
         const int64_t i = (int64_t)b_first + tid - 1;
@@ -332,7 +332,19 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
                             bool act = x < len;
                             const uint32_t c = !act ? 0x100u : (x < 4 ? (f8.x >> (8 * x)) & 0xffu : (x < 8 ? (f8.y >> (8 * (x - 4))) & 0xffu : buf[pc + x]));
                             if (kt != 0xff && x < TH_ROWS) {   // LDS counters (wave-uniform condition)
-                                if (act) atomicAdd(&s_th[kt][x][c >> 1], 1u << (16 * (c & 1)));
+                                // (round 4) the characters of a text field repeat from record to record (a flag, a barcode): one
+                                // atomic per distinct character for the first three of them - sixty-four lanes adding to one word
+                                // are served one after the other - and a lane each for whatever is left (free text)
+                                unsigned long long m = __ballot(act);
+                                for (int round = 0; round < 3 && m; ++round) {
+                                    const int leader = __ffsll((long long)m) - 1;
+                                    const uint32_t c0 = __shfl(c, leader);
+                                    const unsigned long long same = __ballot(act && c == c0);
+                                    if (lane == leader) atomicAdd(&s_th[kt][x][c0 >> 1], (uint32_t)__popcll(same) << (16 * (c0 & 1)));
+                                    if (c == c0) act = false;
+                                    m &= ~same;
+                                }
+                                if (m && act) atomicAdd(&s_th[kt][x][c >> 1], 1u << (16 * (c & 1)));
                                 continue;
                             }
                             const uint32_t row = x < MAX_STAT_LEN ? x : MAX_STAT_LEN;
@@ -357,15 +369,23 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
             const uint32_t k = s_k[f];
             if (k == 0xff || !((need >> f) & 1) || fd[f].kind != KIND_NUM) continue;
             const FieldDesc &d = fd[f];
+            uint32_t idx = 0xffffffffu, wgt = 0;
             if (owned) {
                 const uint32_t v = s_val[k][tid];
-                if (!d.delta_coding) {
-                    const uint32_t idx = v - (uint32_t)d.min_v;
-                    if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], i == 0 ? 2u : 1u);
-                } else if (i >= 1) {
-                    const uint32_t idx = v - s_val[k][tid - 1] - (uint32_t)d.min_d;
-                    if (idx < d.n_sym) atomicAdd(&s_nh[k][idx], 1u);
-                }
+                if (!d.delta_coding) { idx = v - (uint32_t)d.min_v; wgt = i == 0 ? 2u : 1u; }
+                else if (i >= 1) { idx = v - s_val[k][tid - 1] - (uint32_t)d.min_d; wgt = 1u; }
+            }
+            // (round 4) a counter that every lane of the wave hits - the delta of a running index, a constant lane number -
+            // takes ONE atomic with the lanes' sum: sixty-four lanes adding to one LDS word are served one after the other
+            const bool act = wgt != 0 && idx < d.n_sym;
+            const unsigned long long m = __ballot(act);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t i0 = (uint32_t)__shfl((int)idx, leader);
+                if (__ballot(act && idx == i0) == m) {
+                    const uint32_t sum = (uint32_t)__popcll(m) + (uint32_t)__popcll(__ballot(act && wgt == 2u));
+                    if (lane == leader) atomicAdd(&s_nh[k][i0], sum);
+                } else if (act) atomicAdd(&s_nh[k][idx], wgt);
             }
         }
         __syncthreads();   // s_val is rewritten by the next batch
@@ -411,8 +431,12 @@ void launch_field_finalize(hipStream_t st, const Arena &A)
 
 void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv)
 {
-    dim3 grid((max_rec + TS_OWNED * TH_BATCHES - 1) / (TS_OWNED * TH_BATCHES), A.n_sb);
-    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u);
+    // batches of 255 records per workgroup: as many as leave the job ~2000 workgroups (a workgroup's batches are a serial chain of
+    // loads, and its LDS histograms are flushed once), at most TH_BATCHES - the 16-bit text counters hold 255 * 16 records
+    uint32_t batches = (uint32_t)(((uint64_t)max_rec * A.n_sb) / ((uint64_t)TS_OWNED * 2048));
+    batches = batches < 1 ? 1 : (batches > TH_BATCHES ? TH_BATCHES : batches);
+    dim3 grid((max_rec + TS_OWNED * batches - 1) / (TS_OWNED * batches), A.n_sb);
+    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u, batches);
 }
 
 }  // namespace ngsc

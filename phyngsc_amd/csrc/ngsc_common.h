@@ -843,6 +843,7 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
                            RankPlan *plan, const PlanResume *from = nullptr, uint64_t buf_end_abs = 0)
 {
     RankGeom g = rank_geometry(file_size, P, r);
+    uint32_t n_cuts = 0;
     plan->n_cuts = 0;
     plan->overlap_used = (int32_t)((int64_t)first_abs - g.wr_start);
     plan->done = 0;
@@ -886,8 +887,9 @@ NGSC_HD int plan_rank_with(const Search &search, uint64_t file_size, uint32_t P,
         uint32_t cnt = last - cur + 1;
         hint = cnt;
         if (cnt > MAX_RECORDS) return ERR_TOOMANY;
-        if (plan->n_cuts >= max_cuts) return ERR_NOMEM;
-        Cut &c = cuts[plan->n_cuts++];
+        if (n_cuts >= max_cuts) return ERR_NOMEM;
+        Cut &c = cuts[n_cuts++];
+        plan->n_cuts = n_cuts;   // (stored, never read back: the chain of windows does not wait for memory here)
         c.rank = r; c.rec_lo = cur; c.n_rec = cnt; c.overlap = overlap;
         c.win_pos = (uint64_t)win_pos; c.wsize = (uint64_t)bsize;
         int64_t next_abs = (int64_t)search.at(ls, last + 1) + (int64_t)buf_off;
