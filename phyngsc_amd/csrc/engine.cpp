@@ -389,7 +389,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     const uint32_t max_cuts = (uint32_t)(region >> 22) + 8;
     Carver cs;
     size_t o_err = cs.take(4), o_total = cs.take(4), o_start = cs.take(4), o_maxq = cs.take(4), o_slotc = cs.take(4);
-    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4), o_done = cs.take(4), o_bigt = cs.take(4), o_wide = cs.take(4);
+    size_t o_maxrec = cs.take(4), o_maxtitle = cs.take(4), o_done = cs.take(4), o_bigt = cs.take(4), o_wide = cs.take(4), o_numhuff = cs.take(4);
     size_t o_outtot = cs.take(8);
     size_t o_first = cs.take(sizeof(uint64_t) * n_ranks);
     size_t o_plans = cs.take(sizeof(RankPlan) * n_ranks);
@@ -634,6 +634,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     A.nblob_len = (uint32_t *)(pb + p_nblen);
     A.slot_counter = d_slotc;
     A.big_trees = (uint32_t *)(sm + o_bigt);
+    A.num_huff = (uint32_t *)(sm + o_numhuff);
     A.wide_needed = (uint32_t *)(sm + o_wide);
     A.fcap = fcap;
     A.slot_owner = (uint32_t *)(tb + t_owner);

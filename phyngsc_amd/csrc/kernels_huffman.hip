@@ -279,6 +279,7 @@ __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffma
     // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
     // used to find that out pair by pair, 40-60 dependent loads each: 35-64 us behind the small instance on the same stream)
     if (!SMALL && t0 + nt <= A.qrows + 1 && !*A.big_trees) return;
+    if (!SMALL && t0 > A.qrows && !*A.num_huff) return;   // (numeric title fields only, none of them Huffman-coded)
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
     __shared__ Tree Ts[TPW];

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
         else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
     }
     if (rc) atomicMin(A.err, (int32_t)rc);
+    if (!rc && d.kind == KIND_NUM && d.has_huff && !*A.num_huff) atomicOr(A.num_huff, 1u);
     // compact index among the non-constant fields (all lanes with f < nf are still here)
     unsigned long long ncm = __ballot(d.kind != KIND_CONST);
     d.kf = (uint32_t)__popcll(ncm & ((1ull << f) - 1ull));

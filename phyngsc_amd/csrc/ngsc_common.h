@@ -354,6 +354,9 @@ struct Arena {
     // (round 3) set by k_sq_finalize when some sub-block's quality or base alphabet exceeds SMALL_TREE symbols: the 512-symbol
     // Huffman instance has quality / base trees to build (else its workgroups leave at once)
     uint32_t *big_trees;
+    // (round 4) raised by the field finalisation when some numeric title field is Huffman-coded: else the launch that builds those
+    // trees has nothing to do and its workgroups leave at once (they used to find that out field by field: 23 us on the title chain)
+    uint32_t *num_huff;
     // (round 3) the quality code table of every sub-block in the layout the pack kernel keeps in LDS (k_sq_format_qtab):
     // [qrows + 17][57] dwords, qfmt_stride dwords per sub-block
     uint32_t *qfmt;
