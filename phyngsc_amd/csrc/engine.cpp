@@ -762,8 +762,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
         { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
     }
-    { KScope k(c, st, "k_huffman_fields"); launch_huffman_fields(st, A); }
-    { KScope k(c, st, "k_huffman_text"); launch_huffman_text(st, A); }
+    { KScope k(c, st, "k_huffman_title"); launch_huffman_title(st, A); }
     if (wide) { KScope k(c, st, "k_title_wide_measure"); launch_title_wide_measure(st, A, max_rec); }
     else { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if ((rc = join_s())) return rc;

@@ -771,7 +771,7 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
     // tables - so that a character costs one table read instead of three or four dependent ones (4 us per record of a title with
     // a flag and a barcode: 100 ms per sub-block).
     struct VFc { uint32_t f, kind, vidx, delta, has_g, bits_val, bits_num, bits_len, is_len_const, len0, min_len, max_len; int32_t min_v, min_d;
-                 uint32_t ham8, d0a, d0b, sla, slb; };
+                 uint32_t ham8, d0a, d0b, sla, slb, fast8; };   // fast8: the five words in front hold the field's first eight positions
     const bool lk = lane < nvf && lane < 64u;
     const VField &vl = VF[lk ? lane : 0];
     const uint32_t vc_f = lk ? vl.f : 0u, vc_kind = lk ? vl.kind : 0u, vc_vidx = lk ? vl.vidx : 0u, vc_delta = lk ? vl.delta : 0u,
@@ -796,6 +796,7 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
         c.len0 = RL(vc_len0, k); c.min_len = RL(vc_min_len, k); c.max_len = RL(vc_max_len, k); c.min_v = (int32_t)RL(vc_min_v, k);
         c.min_d = (int32_t)RL(vc_min_d, k);
         c.ham8 = RL(vc_ham8, k); c.d0a = RL(vc_d0a, k); c.d0b = RL(vc_d0b, k); c.sla = RL(vc_sla, k); c.slb = RL(vc_slb, k);
+        c.fast8 = 1;
         return c;
     };
     auto ldc_lds = [&](uint32_t k) {   // (fields from the 65th on: out of LDS / the scratch pool, as before)
@@ -804,7 +805,7 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
         c.f = U(v.f); c.kind = U(v.kind); c.vidx = U(v.vidx); c.delta = U(v.delta); c.has_g = U(v.has_g); c.bits_val = U(v.bits_val);
         c.bits_num = U(v.bits_num); c.bits_len = U(v.bits_len); c.is_len_const = U(v.is_len_const); c.len0 = U(v.len0);
         c.min_len = U(v.min_len); c.max_len = U(v.max_len); c.min_v = (int32_t)U((uint32_t)v.min_v); c.min_d = (int32_t)U((uint32_t)v.min_d);
-        c.ham8 = 0; c.d0a = c.d0b = 0; c.sla = c.slb = 0xffffffffu;
+        c.ham8 = 0; c.d0a = c.d0b = 0; c.sla = c.slb = 0xffffffffu; c.fast8 = 0;
         return c;
     };
     auto ptr64 = [&](const void *q) { const uint64_t a = (uint64_t)(uintptr_t)q; return ((uint64_t)U((uint32_t)(a >> 32)) << 32) | U((uint32_t)a); };
@@ -833,7 +834,7 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
             const DTree *tl = (const DTree *)(uintptr_t)ptr64(fd.l);
             for (uint32_t j = 0; j < L && !bad; ++j) {
                 uint32_t ch;
-                if (j < 8) {   // the field's first eight positions: everything but the table entry is in registers
+                if (c.fast8 && j < 8) {   // the field's first eight positions: everything but the table entry is in registers
                     if (j < c.len0 && ((c.ham8 >> j) & 1u)) ch = ((j < 4 ? c.d0a >> (8 * j) : c.d0b >> (8 * (j - 4))) & 0xffu);
                     else {
                         const uint32_t slot = (j < 4 ? c.sla >> (8 * j) : c.slb >> (8 * (j - 4))) & 0xffu;

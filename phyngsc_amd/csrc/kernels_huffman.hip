@@ -295,14 +295,25 @@ __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffma
 // gridDim.y (the slot count lives on the device).  Tree j of a field exists iff text_tree_needed().
 constexpr uint32_t TEXT_GRID_Y = 64;
 
-__global__ __launch_bounds__(64) void k_huffman_text(Arena A)
+// (round 4) ... and the numeric title fields' trees in the same launch (workgroups behind the text grid: t0 = first field tree, nt =
+// fields per sub-block, as in k_huffman_sb<false>): one kernel boundary less on the title chain.
+__global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs, uint32_t t0, uint32_t nt)
 {
     if (*A.err) return;
     __shared__ TreeLds T;
-    const uint32_t j = blockIdx.x;
+    if (blockIdx.x >= text_wgs) {
+        if (!*A.num_huff) return;   // (none of the numeric fields is Huffman-coded)
+        const uint32_t pairs = nt * A.n_sb, nwg = gridDim.x - text_wgs;
+        for (uint32_t p = blockIdx.x - text_wgs; p < pairs; p += nwg) {
+            huffman_sb_tree<false>(A, T, p / nt, t0 + p % nt);
+            tree_sync();   // (T is used again)
+        }
+        return;
+    }
+    const uint32_t j = blockIdx.x % TEXT_TREES, by = blockIdx.x / TEXT_TREES, ny = text_wgs / TEXT_TREES;
     const int lane = threadIdx.x;
     const uint32_t used = *A.slot_counter < A.n_slots ? *A.slot_counter : A.n_slots;
-    for (uint32_t slot = blockIdx.y; slot < used; slot += gridDim.y) {
+    for (uint32_t slot = by; slot < used; slot += ny) {
         const FieldDesc &d = A.fdesc[A.slot_owner[slot]];
         if (d.kind != KIND_TEXT || d.slot != slot || !text_tree_needed(d, j)) continue;
         const size_t tix = (size_t)slot * TEXT_TREES + j;
@@ -338,14 +349,12 @@ void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected)
     // last call met such an alphabet launches six per CU: the trees are real work then)
     launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256);
 }
-void launch_huffman_fields(hipStream_t st, const Arena &A)
+// text-field trees and numeric-field trees of the title, one launch
+void launch_huffman_title(hipStream_t st, const Arena &A)
 {
-    launch_huffman_range(st, A, false, A.qrows + 1, A.fcap);
-}
-
-void launch_huffman_text(hipStream_t st, const Arena &A)
-{
-    hipLaunchKernelGGL(k_huffman_text, dim3(TEXT_TREES, TEXT_GRID_Y), dim3(64), 0, st, A);
+    const uint32_t text_wgs = TEXT_TREES * TEXT_GRID_Y, pairs = A.fcap * A.n_sb;
+    const uint32_t field_wgs = pairs < 1024 ? pairs : 1024;
+    hipLaunchKernelGGL(k_huffman_text, dim3(text_wgs + field_wgs), dim3(64), 0, st, A, text_wgs, A.qrows + 1, A.fcap);
 }
 
 }  // namespace ngsc

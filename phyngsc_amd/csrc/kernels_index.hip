@@ -504,7 +504,12 @@ __global__ __launch_bounds__(CV_THREADS) void k_cuts_validate(uint64_t file_size
             // here costs a search later, never a wrong cut.)
             const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
             for (uint32_t k = wave; k < nwin; k += nwaves) {
-                const uint64_t key = x0 - buf_off + (uint64_t)(k + 1) * D;
+                // (the rank's last window is cut short at the end of its region and stops an overlap in front of it - no overlap for
+                // the file's last rank, plan_rank_with(): the stretch that would lie behind that place is parked around it)
+                const uint64_t stop_last = (uint64_t)g.wr_end - (rank_lo + i == P - 1 ? 0u : g.overlap);
+                uint64_t key_abs = x0 + (uint64_t)(k + 1) * D;
+                if (key_abs > stop_last && stop_last > x0) key_abs = stop_last;
+                const uint64_t key = key_abs - buf_off;
                 uint32_t b0 = 0xffffffffu;
                 if (key <= (uint64_t)last_ls) {
                     uint32_t r0, r1, lo, span;

@@ -40,8 +40,7 @@ void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool us
 
 // ---- kernels_huffman.hip ----
 void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected = false);   // quality / DNA trees (both instances)
-void launch_huffman_fields(hipStream_t st, const Arena &A);
-void launch_huffman_text(hipStream_t st, const Arena &A);
+void launch_huffman_title(hipStream_t st, const Arena &A);   // text-field and numeric-field trees of the title
 
 // ---- kernels_pack.hip ----
 void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
