@@ -279,7 +279,7 @@ __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffma
     // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
     // used to find that out pair by pair, 40-60 dependent loads each: 35-64 us behind the small instance on the same stream)
     if (!SMALL && t0 + nt <= A.qrows + 1 && !*A.big_trees) return;
-    if (!SMALL && t0 > A.qrows && !*A.num_huff) return;   // (numeric title fields only, none of them Huffman-coded)
+    if (!SMALL && t0 > A.qrows && !(*A.num_huff & 1u)) return;   // (numeric title fields only, none of them Huffman-coded)
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
     __shared__ Tree Ts[TPW];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs,
     if (*A.err) return;
     __shared__ TreeLds T;
     if (blockIdx.x >= text_wgs) {
-        if (!*A.num_huff) return;   // (none of the numeric fields is Huffman-coded)
+        if (!(*A.num_huff & 1u)) return;   // (none of the numeric fields is Huffman-coded)
         const uint32_t pairs = nt * A.n_sb, nwg = gridDim.x - text_wgs;
         for (uint32_t p = blockIdx.x - text_wgs; p < pairs; p += nwg) {
             huffman_sb_tree<false>(A, T, p / nt, t0 + p % nt);
@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs,
         }
         return;
     }
+    if (!(*A.num_huff & 2u)) return;   // (no text field in any sub-block)
     const uint32_t j = blockIdx.x % TEXT_TREES, by = blockIdx.x / TEXT_TREES, ny = text_wgs / TEXT_TREES;
     const int lane = threadIdx.x;
     const uint32_t used = *A.slot_counter < A.n_slots ? *A.slot_counter : A.n_slots;

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
         else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
     }
     if (rc) atomicMin(A.err, (int32_t)rc);
-    if (!rc && d.kind == KIND_NUM && d.has_huff && !*A.num_huff) atomicOr(A.num_huff, 1u);
+    if (!rc && d.kind == KIND_NUM && d.has_huff && !(*A.num_huff & 1u)) atomicOr(A.num_huff, 1u);
+    if (!rc && d.kind == KIND_TEXT && !(*A.num_huff & 2u)) atomicOr(A.num_huff, 2u);
     // compact index among the non-constant fields (all lanes with f < nf are still here)
     unsigned long long ncm = __ballot(d.kind != KIND_CONST);
     d.kf = (uint32_t)__popcll(ncm & ((1ull << f) - 1ull));
@@ -225,6 +226,7 @@ constexpr uint32_t TH_TEXT = 2, TH_ROWS = 16;
 __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches)
 {
     if (*A.err) return;
+    if (!*A.num_huff) return;   // (no Huffman-coded number, no text field in any sub-block - the usual title: nothing to count)
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
@@ -242,8 +244,6 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     __shared__ uint32_t s_walk;          // some needed field is text or has no LDS slot: field boundaries are needed
     __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields / text fields (0xff: global atomics)
 
-    for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
-    for (uint32_t k = tid; k < TH_TEXT * TH_ROWS * 128; k += TS_THREADS) (&s_th[0][0][0])[k] = 0;
     if (tid == 0) {
         uint32_t kk = 0, kt = 0, walk = 0;
         fmask_t need = 0;
@@ -264,8 +264,11 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     }
     __syncthreads();
     const fmask_t need = s_need;
-    if (!need) return;
+    if (!need) return;   // (the usual title of plain numbers: nothing is Huffman-coded - leave before the 24 KB of counters are cleared)
     const bool walk = s_walk != 0;
+    for (uint32_t k = tid; k < NH_LDS_FIELDS * MAX_NUM_HUF; k += TS_THREADS) (&s_nh[0][0])[k] = 0;
+    for (uint32_t k = tid; k < TH_TEXT * TH_ROWS * 128; k += TS_THREADS) (&s_th[0][0][0])[k] = 0;
+    __syncthreads();
 
     for (uint32_t batch = 0; batch < batches; ++batch) {
         const uint32_t b_first = wg_first + batch * TS_OWNED;

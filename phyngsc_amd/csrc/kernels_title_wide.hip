@@ -120,7 +120,8 @@ __global__ __launch_bounds__(WIDE_FIELDS) void k_field_finalize_wide(Arena A)
             else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
         }
         if (rc) atomicMin(A.err, (int32_t)rc);
-        if (!rc && d.kind == KIND_NUM && d.has_huff && !*A.num_huff) atomicOr(A.num_huff, 1u);
+        if (!rc && d.kind == KIND_NUM && d.has_huff && !(*A.num_huff & 1u)) atomicOr(A.num_huff, 1u);
+        if (!rc && d.kind == KIND_TEXT && !(*A.num_huff & 2u)) atomicOr(A.num_huff, 2u);
     }
     // compact index among the non-constant fields, in field order
     const bool nc = f < nf && d.kind != KIND_CONST;

@@ -356,7 +356,7 @@ struct Arena {
     uint32_t *big_trees;
     // (round 4) raised by the field finalisation when some numeric title field is Huffman-coded: else the launch that builds those
     // trees has nothing to do and its workgroups leave at once (they used to find that out field by field: 23 us on the title chain)
-    uint32_t *num_huff;
+    uint32_t *num_huff;   // bit 0: a Huffman-coded numeric field, bit 1: a text field (the histogram and tree kernels leave at once without)
     // (round 3) the quality code table of every sub-block in the layout the pack kernel keeps in LDS (k_sq_format_qtab):
     // [qrows + 17][57] dwords, qfmt_stride dwords per sub-block
     uint32_t *qfmt;

@@ -7,6 +7,7 @@
 import ctypes
 import glob
 import json
+import functools
 import os
 import re
 import struct
@@ -752,7 +753,8 @@ def test_gpu_decoder_refuses_garbage(eng):
         eng.decompress_device(sub, [res.subblocks[0].out_off], [res.subblocks[0].size])
 
 
-def _edge_cases():
+@functools.lru_cache(maxsize=None)
+def _edge_cases():   # (built once: every parametrised case used to rebuild all of them, two seconds each time)
     from tests.edge_cases import build
     return build()
 
