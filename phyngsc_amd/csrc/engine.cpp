@@ -77,6 +77,7 @@ struct ngsc_ctx {
     bool no_spec = getenv("NGSC_NO_SPEC") != nullptr;   // every call reads the job's shape back (the step's first-call form)
     JobShape shape;               // the last job's counts and maxima: the next call's prediction
     bool big_alphabets = false;   // the last call met a quality / base alphabet of more than 64 symbols (grid of the 512-symbol Huffman instance)
+    uint32_t title_need = 3;      // the last call's Arena::num_huff word: which of the title's histogram / tree launches had work (all, until a call has been through)
     std::vector<KTime> ktimes;
     std::vector<hipEvent_t> event_pool;
 
@@ -446,8 +447,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // (round 4) ... the output's clearing only for longer records.  With short ones (under 128 bytes on average: 36-base reads) the
     // cut planner - 0.05 ms since it looks its windows up with sixteen waves - would wait for the clearing beside it (0.07 ms), while
     // the sequence/quality side chain behind the statistics kernel has 0.1 ms to spare beside the title statistics: the clearing
-    // goes there (1.960 -> 1.941 ms per GB of 36-base reads; 150-base and 36..300-base jobs, whose side chain has no slack, lose
-    // 1-2 % that way: profiles/r04_ab_zero_late.txt).  The record count is the previous job's (the prediction) or none.
+    // goes there (1.960 -> 1.941 ms per GB of 36-base reads, 1.928 -> 1.901 with the round's later schedule; 150-base and
+    // 36..300-base jobs, whose side chain has no slack, lose 1-2 % that way: profiles/r04_ab_zero_late.txt).  The record count is the previous job's (the prediction) or none.
     const bool zero_late = zero_on_side && spec && (uint64_t)last.n_rec_total * 128 > (uint64_t)len;
     if (zero_on_side) {
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
@@ -743,7 +744,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (zero_late && out_prefix && stagger) launch_zero_range(sts, d_out, out_prefix);
     else if (zero_late && out_prefix) launch_zero_range(st, d_out, out_prefix);
     { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
-    { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets); }
+    // (round 4) A predicted step launches the kernels that usually have nothing to do - the 512-symbol tree instance, the title's
+    // histograms and trees - WITHOUT their LDS when the context's last job gave them nothing to do: a lone workgroup then checks
+    // that this still holds and raises ERR_SHAPE if not (the step runs again, the synchronous way, with everything).  With their
+    // LDS, thousands of workgroups queued for 26-40 KB each on CUs that the title statistics kernel fills, to find out that they
+    // could leave: 14-150 us on the side chain, 20-100 + 25 on the title chain of a 36-base step.
+    const bool big_lds = !spec || c->big_alphabets, hist_lds = !spec || (c->title_need & 3u) != 0, ttree_lds = hist_lds;
+    { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets, big_lds); }
     // (round 4, measured and not kept: the payload measure kernel - the side chain's one throughput kernel - on a stream of ordinary
     // priority, so that the title chain's small kernels are not dispatched behind it: no change on 36-base reads, 3 % slower on
     // 150-base reads, profiles/r04_ab_measure_stream_priority.txt; the side stream at low priority altogether: 1-2 % slower)
@@ -760,9 +767,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
         else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
         { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
-        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
+        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar, hist_lds); }
     }
-    { KScope k(c, st, "k_huffman_title"); launch_huffman_title(st, A); }
+    { KScope k(c, st, "k_huffman_title"); launch_huffman_title(st, A, ttree_lds); }
     if (wide) { KScope k(c, st, "k_title_wide_measure"); launch_title_wide_measure(st, A, max_rec); }
     else { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if ((rc = join_s())) return rc;
@@ -913,6 +920,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     c->qbits_x16 = c->dbits_x16 = 0;
     c->big_alphabets = false;
+    c->title_need = *(uint32_t *)(h_small + o_numhuff);
     for (uint32_t s = 0; s < S; ++s) {
         const SbState &x = h_sb[s];
         if (x.nqual > 64 || x.nsym > 64) c->big_alphabets = true;

@@ -829,10 +829,56 @@ __device__ __forceinline__ void dec_title_body_wave(const uint8_t *p, uint64_t n
         } else {
             const uint32_t L = c.is_len_const ? c.len0 : c.min_len + get(c.bits_len);
             if (L > c.max_len || tused + L > tchar_cap) { bad = L > c.max_len ? 1u : 3u; return; }
+            bool done = false;
+            if (c.fast8 && L >= 1 && L <= 8) {
+                // (round 4) A short text field - a barcode, a flag with a lane number - in one go, the way dec_symbols_wave takes a trip:
+                // lane o stands for bit offset o of the window and looks up, for every position t of the field, the entry that
+                // position's code has if it starts at o (a position that holds the first record's character takes no bits); the
+                // chain of starts is then one v_readlane per position.  A character used to cost a table read the walk waited for,
+                // its bits taken out of the window and a byte store of its own: ~770 cycles each, most of a title's time.
+                const uint32_t hi = (uint32_t)(win >> 32), lo = (uint32_t)win;
+                const uint32_t top = lane == 0 ? hi : (lane < 32 ? __builtin_amdgcn_alignbit(hi, lo, 32u - lane) : (lo << (lane - 32u)));
+                const uint32_t fieldx = top >> (32u - DEC_K);
+                uint32_t evv[8];
+                bool tabs = true;
+#pragma unroll
+                for (uint32_t t = 0; t < 8; ++t) {
+                    evv[t] = 0;
+                    if (t >= L) continue;
+                    if (t < c.len0 && ((c.ham8 >> t) & 1u)) { evv[t] = 0x10000u | ((t < 4 ? c.d0a >> (8 * t) : c.d0b >> (8 * (t - 4))) & 0xffu); continue; }
+                    const uint32_t slot = (t < 4 ? c.sla >> (8 * t) : c.slb >> (8 * (t - 4))) & 0xffu;
+                    if (slot == 0xffu) { tabs = false; continue; }
+                    evv[t] = s_ttab[(slot << DEC_K) + fieldx];
+                }
+                if (tabs) {
+                    uint32_t so = 0, cvec = 0, okv = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < 8; ++t) {
+                        const uint32_t nx = lane + ((evv[t] >> 12) & 15u);
+                        const uint32_t e_t = (uint32_t)__builtin_amdgcn_readlane((int)evv[t], (int)(so & 63u));
+                        const uint32_t son = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)(so & 63u));
+                        cvec = dec_writelane(cvec, e_t, t);
+                        okv = dec_writelane(okv, so, t);
+                        so = t < L ? son : so;
+                    }
+                    // every position had an entry (or the first record's character) and started inside the window's 64 offsets; the
+                    // field's bits are all there
+                    const bool good = lane >= L || (okv < 64u && ((cvec & 0x10000u) || ((cvec >> 12) & 15u) != 0));
+                    if (!__any(!good) && so <= have && so <= 64u) {
+                        if (lane < L) tchars[tused + lane] = (uint8_t)cvec;
+                        if (so > 32u) { (void)get(32u); (void)get(so - 32u); } else (void)get(so);
+                        done = true;
+                    }
+                }
+            }
             const DField &fd = F[c.f];
-            const uint8_t *ham = (const uint8_t *)(uintptr_t)ptr64(fd.ham), *d0 = (const uint8_t *)(uintptr_t)ptr64(fd.data0);
-            const DTree *tl = (const DTree *)(uintptr_t)ptr64(fd.l);
-            for (uint32_t j = 0; j < L && !bad; ++j) {
+            const uint8_t *ham = nullptr, *d0 = nullptr;
+            const DTree *tl = nullptr;
+            if (!done) {
+                ham = (const uint8_t *)(uintptr_t)ptr64(fd.ham); d0 = (const uint8_t *)(uintptr_t)ptr64(fd.data0);
+                tl = (const DTree *)(uintptr_t)ptr64(fd.l);
+            }
+            for (uint32_t j = 0; j < L && !bad && !done; ++j) {
                 uint32_t ch;
                 if (c.fast8 && j < 8) {   // the field's first eight positions: everything but the table entry is in registers
                     if (j < c.len0 && ((c.ham8 >> j) & 1u)) ch = ((j < 4 ? c.d0a >> (8 * j) : c.d0b >> (8 * (j - 4))) & 0xffu);
@@ -1852,8 +1898,14 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
             o += tl;
             const uint8_t *q = D.titles + D.lay[0] + o_q;
             uint64_t bi = o_b;                                   // index of the record's next base in the DNA stream
-            for (uint32_t j = 0; j < L; ++j) {
-                const uint32_t qv = q[j];
+            uint32_t j = 0;
+            // (round 4) eight positions per step where nothing was transferred into the quality stream (no byte >= 128): one 8-byte
+            // load of qualities, the sixteen bits of eight two-bit bases (or eight decoded base bytes), two 8-byte stores.  A byte per
+            // step - a quality, a base byte and the alphabet entry, each a trip to memory the next one waits for - made this
+            // kernel 24 ms per GB of 36..300-base reads: latency, not bytes.
+            const uint32_t sym4 = O.plain ? ((uint32_t)O.dsym[0] | ((uint32_t)O.dsym[1] << 8) | ((uint32_t)O.dsym[2] << 16) | ((uint32_t)O.dsym[3] << 24)) : 0u;
+            auto one = [&](uint32_t jj) __attribute__((always_inline)) {   // position jj, the general way
+                const uint32_t qv = q[jj];
                 uint8_t c, qo = (uint8_t)qv;
                 if (qv >= 128) {   // inverse of the N -> quality transfer (phyNGSC.cpp:573-588)
                     const uint32_t v = qv - 128u + 16u, a = v >> 3;
@@ -1861,14 +1913,42 @@ __global__ __launch_bounds__(256) void k_dec_assemble(const uint8_t *sub, const 
                     qo = (uint8_t)(33 + (v & 7));
                 } else if (O.plain) {
                     const uint64_t bp = O.dna_bitpos + 2 * bi;
-                    c = O.dsym[(sb[bp >> 3] >> (6 - (bp & 7))) & 3u];
+                    c = (uint8_t)(sym4 >> (8 * ((sb[bp >> 3] >> (6 - (bp & 7))) & 3u)));
                     ++bi;
                 } else {
                     c = D.titles[D.lay[1] + bi++];
                 }
-                o[j] = c;
-                o[L + 3 + j] = qo;
+                o[jj] = c;
+                o[L + 3 + jj] = qo;
+            };
+            for (; j + 8 <= L; j += 8) {
+                const U2u qq = *reinterpret_cast<const U2u *>(q + j);
+                if ((qq.x | qq.y) & 0x80808080u) {               // a transferred position among these eight: one by one
+                    for (uint32_t k = 0; k < 8; ++k) one(j + k);
+                    continue;
+                }
+                uint32_t b0, b1;                                 // the eight bases, a byte each
+                if (O.plain) {
+                    const uint64_t bp = O.dna_bitpos + 2 * bi;
+                    const uint8_t *pb = sb + (bp >> 3);
+                    const uint32_t w24 = ((uint32_t)pb[0] << 16) | ((uint32_t)pb[1] << 8) | (uint32_t)pb[2];   // (a sub-block is padded to 16 bytes: pb[2] is there)
+                    const uint32_t c16 = (w24 >> (8 - (uint32_t)(bp & 7))) & 0xffffu;                            // sixteen bits, the first base on top
+                    b0 = b1 = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        b0 |= ((sym4 >> (8 * ((c16 >> (14 - 2 * k)) & 3u))) & 0xffu) << (8 * k);
+                        b1 |= ((sym4 >> (8 * ((c16 >> (6 - 2 * k)) & 3u))) & 0xffu) << (8 * k);
+                    }
+                } else {
+                    const U2u bb = *reinterpret_cast<const U2u *>(D.titles + D.lay[1] + bi);
+                    b0 = bb.x; b1 = bb.y;
+                }
+                bi += 8;
+                U2u so = {b0, b1};
+                *reinterpret_cast<U2u *>(o + j) = so;
+                *reinterpret_cast<U2u *>(o + L + 3 + j) = qq;
             }
+            for (; j < L; ++j) one(j);
             o[L] = '\n'; o[L + 1] = '+'; o[L + 2] = '\n'; o[2 * L + 3] = '\n';
         }
         __syncthreads();

@@ -248,7 +248,7 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
         const uint32_t f = t - A.qrows - 1;
         if (f >= sb.nf) return;
         const FieldDesc &d = A.fdesc[(size_t)s * A.fcap + f];
-        if (d.kind != KIND_NUM || !d.has_huff) return;
+        if (d.kind != KIND_NUM || !d.has_huff || d.n_sym <= 1) return;   // (a one-symbol tree: written by the field finalisation)
         const uint32_t n = d.n_sym;
         const size_t tix = (size_t)s * A.fcap + f;
         const uint32_t *h = A.nhist + tix * MAX_NUM_HUF;
@@ -272,18 +272,28 @@ __device__ __forceinline__ void huffman_sb_tree(const Arena &A, Tree &T, uint32_
 // average (SQ_WAVE_CYCLES / kernel time, profiles/r03_pmc_final_cfg2_a.json), and behind 150- and 300-base statistics nothing
 // runs beside this kernel.
 constexpr uint32_t SMALL_TREES_PER_WG = 4;
+template <bool SMALL> struct SmallTrees {   // the small instance's static LDS (the other instance must not carry it)
+    __device__ static TreeLdsSmall *get() { __shared__ TreeLdsSmall Ts[SMALL_TREES_PER_WG]; return Ts; }
+};
+template <> struct SmallTrees<false> { __device__ static TreeLdsSmall *get() { return nullptr; } };
+// (round 4) has_lds (the 512-symbol instance): the launch carries the tree's 26 KB of LDS.  A predicted step (engine.cpp) launches it
+// WITHOUT when the context's last job had no alphabet of more than 64 symbols: its workgroups then only look whether that still
+// holds - with the LDS they waited for a CU with 26 KB to spare just to find out that they had nothing to do, 14-150 us on the
+// side chain beside the title statistics kernel, which fills every CU's LDS - and raise ERR_SHAPE if it does not (the step runs
+// again, with the LDS).
 template <bool SMALL>
-__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt)
+__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t has_lds)
 {
     if (*A.err) return;
     // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
     // used to find that out pair by pair, 40-60 dependent loads each: 35-64 us behind the small instance on the same stream)
     if (!SMALL && t0 + nt <= A.qrows + 1 && !*A.big_trees) return;
     if (!SMALL && t0 > A.qrows && !(*A.num_huff & 1u)) return;   // (numeric title fields only, none of them Huffman-coded)
+    if (!SMALL && !has_lds) { if (threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
-    __shared__ Tree Ts[TPW];
-    Tree &T = Ts[threadIdx.x >> 6];
+    extern __shared__ __align__(16) uint8_t s_tree_dyn[];   // (the 512-symbol instance's tree: dynamic, so that a launch can do without)
+    Tree &T = *(SMALL ? reinterpret_cast<Tree *>(SmallTrees<SMALL>::get() + (threadIdx.x >> 6)) : reinterpret_cast<Tree *>(s_tree_dyn));
     const uint32_t pairs = nt * A.n_sb;
     for (uint32_t p = blockIdx.x * TPW + (threadIdx.x >> 6); p < pairs; p += gridDim.x * TPW) {
         huffman_sb_tree<SMALL>(A, T, p / nt, t0 + p % nt);
@@ -297,10 +307,16 @@ constexpr uint32_t TEXT_GRID_Y = 64;
 
 // (round 4) ... and the numeric title fields' trees in the same launch (workgroups behind the text grid: t0 = first field tree, nt =
 // fields per sub-block, as in k_huffman_sb<false>): one kernel boundary less on the title chain.
-__global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs, uint32_t t0, uint32_t nt)
+// has_lds: as in k_huffman_sb - without, the launch only checks that no title field needs a tree.
+__global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs, uint32_t t0, uint32_t nt, uint32_t has_lds)
 {
     if (*A.err) return;
-    __shared__ TreeLds T;
+    if (!has_lds) {
+        if ((*A.num_huff & 3u) && threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE);
+        return;
+    }
+    extern __shared__ __align__(16) uint8_t s_tree_dyn[];
+    TreeLds &T = *reinterpret_cast<TreeLds *>(s_tree_dyn);
     if (blockIdx.x >= text_wgs) {
         if (!(*A.num_huff & 1u)) return;   // (none of the numeric fields is Huffman-coded)
         const uint32_t pairs = nt * A.n_sb, nwg = gridDim.x - text_wgs;
@@ -332,30 +348,34 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs,
 }
 
 // big_grid: workgroups of the 512-symbol instance
-static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uint32_t t0, uint32_t nt, uint32_t big_grid = 1024)
+static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uint32_t t0, uint32_t nt, uint32_t big_grid = 1024, bool lds = true)
 {
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
-    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt);
-    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), 0, st, A, t0, nt);
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt, 1u);
+    else if (lds) hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), sizeof(TreeLds), st, A, t0, nt, 1u);
+    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(1), dim3(64), 0, st, A, t0, nt, 0u);   // (one workgroup: a look at the flag)
 }
 
 // Two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
 // sequence/quality statistics only, the numeric title field trees the title statistics only.
-void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected)
+// big_lds false (a predicted step whose context has not met a big alphabet): the 512-symbol instance without its LDS, see k_huffman_sb
+void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected, bool big_lds)
 {
     launch_huffman_range(st, A, true, 0, A.qrows + 1);
     // (quality alphabets of more than 64 symbols are rare: a workgroup per CU - each needs 26 KB of LDS that the title statistics
     // kernel beside it is holding, and a thousand of them took 166 us to find out that they had nothing to do.  A context whose
     // last call met such an alphabet launches six per CU: the trees are real work then)
-    launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256);
+    launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256, big_lds);
 }
 // text-field trees and numeric-field trees of the title, one launch
-void launch_huffman_title(hipStream_t st, const Arena &A)
+// lds false (a predicted step whose context's last job had no title field that needs a tree): one workgroup without LDS that checks
+void launch_huffman_title(hipStream_t st, const Arena &A, bool lds)
 {
     const uint32_t text_wgs = TEXT_TREES * TEXT_GRID_Y, pairs = A.fcap * A.n_sb;
     const uint32_t field_wgs = pairs < 1024 ? pairs : 1024;
-    hipLaunchKernelGGL(k_huffman_text, dim3(text_wgs + field_wgs), dim3(64), 0, st, A, text_wgs, A.qrows + 1, A.fcap);
+    if (lds) hipLaunchKernelGGL(k_huffman_text, dim3(text_wgs + field_wgs), dim3(64), sizeof(TreeLds), st, A, text_wgs, A.qrows + 1, A.fcap, 1u);
+    else hipLaunchKernelGGL(k_huffman_text, dim3(1), dim3(64), 0, st, A, text_wgs, A.qrows + 1, A.fcap, 0u);
 }
 
 }  // namespace ngsc

@@ -203,8 +203,22 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
         else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
     }
     if (rc) atomicMin(A.err, (int32_t)rc);
-    if (!rc && d.kind == KIND_NUM && d.has_huff && !(*A.num_huff & 1u)) atomicOr(A.num_huff, 1u);
-    if (!rc && d.kind == KIND_TEXT && !(*A.num_huff & 2u)) atomicOr(A.num_huff, 2u);
+    {
+        // (round 4) which of the title's histogram / tree launches have work (Arena::num_huff); the tree of a Huffman-coded number
+        // that never changes its value - a running index's delta - is written here, by this thread
+        const bool huff = !rc && d.kind == KIND_NUM && d.has_huff;
+        if (huff && d.n_sym <= 1) {
+            const size_t tix = (size_t)s * A.fcap + f;
+            uint8_t blob[16];
+            uint32_t cl = 0;
+            const uint32_t bl = huffman_single_symbol(&cl, blob);
+            A.ncodes[tix * MAX_NUM_HUF] = cl;
+            for (uint32_t k = 0; k < bl; ++k) A.nblob[tix * BLOB_SLOT_512 + k] = blob[k];
+            A.nblob_len[tix] = bl;
+        }
+        const uint32_t want = (huff && d.n_sym > 1 ? 1u : 0u) | (!rc && d.kind == KIND_TEXT ? 2u : 0u);
+        if (want & ~*A.num_huff) atomicOr(A.num_huff, want);
+    }
     // compact index among the non-constant fields (all lanes with f < nf are still here)
     unsigned long long ncm = __ballot(d.kind != KIND_CONST);
     d.kf = (uint32_t)__popcll(ncm & ((1ull << f) - 1ull));
@@ -223,10 +237,14 @@ constexpr uint32_t NH_LDS_FIELDS = 8;
 constexpr uint32_t TH_BATCHES = 16;
 constexpr uint32_t TH_TEXT = 2, TH_ROWS = 16;
 
-__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches)
+// has_lds: the launch carries the counters' 40 KB of LDS; a predicted step whose context's last job had nothing to count launches ONE
+// workgroup without, which only checks that this still holds (ERR_SHAPE if not: the step runs again) - 2 450 workgroups that each
+// wait for 40 KB of LDS to find out that they have nothing to do took 20 us alone and 100 beside the payload measure kernel.
+__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches, uint32_t has_lds)
 {
     if (*A.err) return;
-    if (!*A.num_huff) return;   // (no Huffman-coded number, no text field in any sub-block - the usual title: nothing to count)
+    if (!(*A.num_huff & 3u)) return;   // (no Huffman-coded number with more than one value, no text field in any sub-block - the usual title)
+    if (!has_lds) { if (threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
@@ -237,9 +255,11 @@ __global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use
     const uint8_t *buf = A.buf;
     const FieldDesc *fd = A.fdesc + (size_t)s * A.fcap;
 
-    __shared__ uint32_t s_nh[NH_LDS_FIELDS][MAX_NUM_HUF];
-    __shared__ uint32_t s_val[NH_LDS_FIELDS][TS_THREADS];
-    __shared__ uint32_t s_th[TH_TEXT][TH_ROWS][128];   // two 16-bit counters per word: character c -> word c >> 1, half c & 1
+    extern __shared__ __align__(16) uint32_t s_hist_dyn[];
+    uint32_t (*const s_nh)[MAX_NUM_HUF] = reinterpret_cast<uint32_t (*)[MAX_NUM_HUF]>(s_hist_dyn);
+    uint32_t (*const s_val)[TS_THREADS] = reinterpret_cast<uint32_t (*)[TS_THREADS]>(s_hist_dyn + NH_LDS_FIELDS * MAX_NUM_HUF);
+    // two 16-bit counters per word: character c -> word c >> 1, half c & 1
+    uint32_t (*const s_th)[TH_ROWS][128] = reinterpret_cast<uint32_t (*)[TH_ROWS][128]>(s_hist_dyn + NH_LDS_FIELDS * MAX_NUM_HUF + NH_LDS_FIELDS * TS_THREADS);
     __shared__ fmask_t s_need;           // bit f: field needs a histogram
     __shared__ uint32_t s_walk;          // some needed field is text or has no LDS slot: field boundaries are needed
     __shared__ uint8_t s_k[MAX_FIELDS];  // compact LDS index of numeric Huffman fields / text fields (0xff: global atomics)
@@ -433,14 +453,16 @@ void launch_field_finalize(hipStream_t st, const Arena &A)
     hipLaunchKernelGGL(k_field_finalize, dim3(A.n_sb), dim3(64), 0, st, A);
 }
 
-void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv)
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv, bool lds)
 {
     // batches of 255 records per workgroup: as many as leave the job ~2000 workgroups (a workgroup's batches are a serial chain of
     // loads, and its LDS histograms are flushed once), at most TH_BATCHES - the 16-bit text counters hold 255 * 16 records
     uint32_t batches = (uint32_t)(((uint64_t)max_rec * A.n_sb) / ((uint64_t)TS_OWNED * 2048));
     batches = batches < 1 ? 1 : (batches > TH_BATCHES ? TH_BATCHES : batches);
     dim3 grid((max_rec + TS_OWNED * batches - 1) / (TS_OWNED * batches), A.n_sb);
-    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u, batches);
+    const size_t lds_bytes = 4 * ((size_t)NH_LDS_FIELDS * MAX_NUM_HUF + (size_t)NH_LDS_FIELDS * TS_THREADS + (size_t)TH_TEXT * TH_ROWS * 128);
+    if (lds) hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), lds_bytes, st, A, use_tv ? 1u : 0u, batches, 1u);
+    else hipLaunchKernelGGL(k_title_hist, dim3(1, 1), dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u, batches, 0u);
 }
 
 }  // namespace ngsc

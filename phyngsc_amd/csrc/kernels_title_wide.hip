@@ -120,8 +120,22 @@ __global__ __launch_bounds__(WIDE_FIELDS) void k_field_finalize_wide(Arena A)
             else { d.slot = slot; A.slot_owner[slot] = s * A.fcap + f; }
         }
         if (rc) atomicMin(A.err, (int32_t)rc);
-        if (!rc && d.kind == KIND_NUM && d.has_huff && !(*A.num_huff & 1u)) atomicOr(A.num_huff, 1u);
-        if (!rc && d.kind == KIND_TEXT && !(*A.num_huff & 2u)) atomicOr(A.num_huff, 2u);
+        {
+            // (round 4) which of the title's histogram / tree launches have work (Arena::num_huff); the tree of a Huffman-coded number
+            // that never changes its value - a running index's delta - is written here, by this thread
+            const bool huff = !rc && d.kind == KIND_NUM && d.has_huff;
+            if (huff && d.n_sym <= 1) {
+                const size_t tix = (size_t)s * A.fcap + f;
+                uint8_t blob[16];
+                uint32_t cl = 0;
+                const uint32_t bl = huffman_single_symbol(&cl, blob);
+                A.ncodes[tix * MAX_NUM_HUF] = cl;
+                for (uint32_t k = 0; k < bl; ++k) A.nblob[tix * BLOB_SLOT_512 + k] = blob[k];
+                A.nblob_len[tix] = bl;
+            }
+            const uint32_t want = (huff && d.n_sym > 1 ? 1u : 0u) | (!rc && d.kind == KIND_TEXT ? 2u : 0u);
+            if (want & ~*A.num_huff) atomicOr(A.num_huff, want);
+        }
     }
     // compact index among the non-constant fields, in field order
     const bool nc = f < nf && d.kind != KIND_CONST;

@@ -356,7 +356,8 @@ struct Arena {
     uint32_t *big_trees;
     // (round 4) raised by the field finalisation when some numeric title field is Huffman-coded: else the launch that builds those
     // trees has nothing to do and its workgroups leave at once (they used to find that out field by field: 23 us on the title chain)
-    uint32_t *num_huff;   // bit 0: a Huffman-coded numeric field, bit 1: a text field (the histogram and tree kernels leave at once without)
+    uint32_t *num_huff;   // bit 0: a Huffman-coded numeric field of more than one value (a histogram, a tree), bit 1: a text field (histograms,
+                          // trees); the histogram and tree kernels leave at once without theirs
     // (round 3) the quality code table of every sub-block in the layout the pack kernel keeps in LDS (k_sq_format_qtab):
     // [qrows + 17][57] dwords, qfmt_stride dwords per sub-block
     uint32_t *qfmt;
@@ -770,6 +771,19 @@ NGSC_HD uint32_t huffman_sequential(const uint64_t *sorted, uint32_t n, uint32_t
     huffman_clear(code, len, n);
     const int root = huffman_core(sorted, n, zeros, ifreq, lc, rc, code, len, max_len_out);
     return huffman_blob(n, root, huffman_min_len(len, n), lc, rc, stack, blob);
+}
+
+// The tree of a ONE-symbol alphabet (a numeric title field whose delta never changes): what the tree kernels would build for it,
+// by one thread - the field finalisation writes it, so that such a field does not make the tree launch carry its LDS (round 4).
+NGSC_HD uint32_t huffman_single_symbol(uint32_t *code_len_out, uint8_t *blob /* >= 16 bytes */)
+{
+    const uint64_t sorted[1] = {0};
+    uint32_t ifreq[1] = {0}, code[2] = {0, 0}, max_len = 0;
+    uint16_t lc[2] = {0, 0}, rc[2] = {0, 0}, stack[4] = {0, 0, 0, 0};
+    uint8_t len[2] = {0, 0};
+    const uint32_t n = huffman_sequential(sorted, 1, ifreq, lc, rc, code, len, stack, blob, &max_len);
+    *code_len_out = (code[0] << 5) | len[0];
+    return n;
 }
 
 // =====================================================================================================

@@ -395,6 +395,25 @@ def test_titles_of_more_than_64_fields(eng):
         assert api.decompress_bytes(out, engine=eng) == data
 
 
+def test_predicted_step_meets_what_its_probes_did_not_expect(eng):
+    """A predicted step (the context's second job of a kind onwards) launches the title's histogram and tree kernels and the 512-symbol
+    tree instance WITHOUT their LDS when the context's last job gave them nothing to do; a job of the same size that does - a text
+    field that varies, a Huffman-coded number, a quality alphabet of more than 64 symbols - raises ERR_SHAPE on the device and the
+    step runs again with everything (engine.cpp: big_lds / hist_lds / ttree_lds).  Same bytes as the oracle either way, in any order."""
+    n = 6000
+    quiet = "".join(f"@ab.{i:06d} k:100\nACGTACGTACGTACGTACGT\n+\n{'I' * 20}\n" for i in range(n)).encode()
+    wide_q = "".join(chr(40 + (i * 7 + j * 3) % 70) for i in range(n) for j in range(20))
+    busy = "".join(f"@{'ab' if (i // 3) % 2 else 'cd'}.{i:06d} k:{100 + (i * i) % 50:03d}\nACGTACGTACGTACGTACGT\n+\n{wide_q[20 * i:20 * i + 20]}\n"
+                   for i in range(n)).encode()
+    assert len(quiet) == len(busy)
+    want_quiet, _ = orc.compress_file(quiet, 4)
+    want_busy, _ = orc.compress_file(busy, 4)
+    for data, want in ((quiet, want_quiet), (quiet, want_quiet), (quiet, want_quiet), (busy, want_busy), (busy, want_busy),
+                       (quiet, want_quiet), (busy, want_busy), (quiet, want_quiet), (quiet, want_quiet)):
+        _, out = _gpu(eng, data, 4)
+        assert out == want
+
+
 def test_error_numeric_overflow(eng):
     _expect_error(eng, _fq(400, title=lambda i: f"@r:{3_000_000_000 + i}"), 2, -5)
 
