@@ -138,13 +138,26 @@ __global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
     const uint32_t max_q = sb.max_q;
     uint32_t tot = 0;
     {
-        uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, row = 1;
+        // (round 4: thirty-two loads in flight per thread instead of eight - the kernel is nothing but their latency, 19 rounds of
+        // it for 150-base reads: 63 us at the head of the side chain)
+        constexpr uint32_t NF = 32;
+        uint32_t t[NF], row = 1;
+#pragma unroll
+        for (uint32_t k = 0; k < NF; ++k) t[k] = 0;
+        for (; row + NF - 1 <= max_q; row += NF) {
+            uint32_t v[NF];
+#pragma unroll
+            for (uint32_t k = 0; k < NF; ++k) v[k] = qh[(size_t)(row + k) * 256 + tid];
+#pragma unroll
+            for (uint32_t k = 0; k < NF; ++k) t[k] += v[k];
+        }
         for (; row + 7 <= max_q; row += 8) {
 #pragma unroll
             for (uint32_t k = 0; k < 8; ++k) t[k] += qh[(size_t)(row + k) * 256 + tid];
         }
         for (; row <= max_q; ++row) t[0] += qh[(size_t)row * 256 + tid];
-        tot = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+#pragma unroll
+        for (uint32_t k = 0; k < NF; ++k) tot += t[k];
     }
     qh[tid] = tot;  // row 0: position-independent histogram (quality_stats[0], tasks.cpp:283)
     const bool hasq = tot != 0;

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--reference", action="store_true",
                     help="build container only: compare the oracle with oracle/_ref/phyNGSC (mpiexec -np P) instead")
     ap.add_argument("--seeds", type=int, default=10 ** 9)
+    ap.add_argument("--twice", action="store_true", help="compress every input twice in a row on the context (the second call is a predicted step)")
     ap.add_argument("--tiny", action="store_true",
                     help="files of 20..200 KB split over 8..24 ranks: rank regions of a record's size, records owned by two ranks")
     ap.add_argument("--driver", action="store_true",
@@ -137,6 +138,12 @@ def main():
                 res = eng.compress_device(d_in, arr.size, d["P"])
                 got = api.assemble_container(res, d["P"], arr.size)
                 g_rc = 0
+                if a.twice:
+                    # the same job again: the context PREDICTS this call's shape from the first (no sync in the middle of the step, the
+                    # histogram / tree kernels launched as the first call's flags say) - it has to write the same bytes
+                    res2 = eng.compress_device(d_in, arr.size, d["P"])
+                    if api.assemble_container(res2, d["P"], arr.size) != got:
+                        got = b"the predicted second call differs from the first"
             except api.NgscError as e:
                 got, g_rc = None, e.code
             if o_rc == 0 and g_rc == -8 and max((len(x) + 1 for x in _ln[0::4]), default=0) > 512:
