@@ -120,7 +120,6 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
         if (hipMemcpyAsync(d_off, sb_off + b0, 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(d_len, sb_len + b0, 4ull * nb, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(d_hoff, hoff.data(), 8ull * nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
-        if (use_hop && hipMemsetAsync(d_hop, 0xFF, 2ull * hpos, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         uint32_t spec_sum[2] = {0, 0};   // longest read, largest quality alphabet among the sub-blocks the speculative kernels take
         if (hipMemsetAsync(d_sum, 0, 8, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         launch_dec_head(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop, d_sum);
@@ -128,6 +127,9 @@ int ngsc_decompress_device(ngsc_ctx *c, const void *d_sub, const uint64_t *sb_of
             rc = NGSC_ERR_HIP;
             break;
         }
+        // the hop table is cleared ("no hop known") only when some sub-block of the batch will be decoded speculatively: 16 bytes per
+        // compressed byte - 4 GB for a batch of 36..300-base reads, none of which takes that path
+        if (use_hop && spec_sum[0] && hipMemsetAsync(d_hop, 0xFF, 2ull * hpos, st) != hipSuccess) { rc = NGSC_ERR_HIP; break; }
         launch_dec_streams(st, (const uint8_t *)d_sub, d_off, d_len, nb, scratch, stride, rec_cap, tcap, qcap, d_res, d_ctl, use_hop ? d_hop : nullptr,
                            d_hoff, max_tiles, spec_sum[0], spec_sum[1]);
         if (hipMemcpyAsync(h_res.data(), d_res, rb * nb, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
