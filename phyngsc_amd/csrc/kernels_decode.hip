@@ -1363,53 +1363,6 @@ __device__ __forceinline__ uint32_t qs_record_len(const uint32_t *p32, uint32_t 
     return total;
 }
 
-// (round 4) Two records' lengths at once, from two bit offsets, in lock-step: a lane's walk is a chain of dependent LDS lookups - one in
-// flight per wave, six waves per SIMD at 150 bases - and two chains per lane keep two in flight.  Same results as two calls of
-// qs_record_len (a chain that meets a code longer than the table - rare - finishes through that function).
-__device__ __forceinline__ void qs_record_len2(const uint32_t *p32, uint32_t ndw, uint64_t b0, uint64_t b1, bool on1, uint32_t L, const QsLenTabs &T,
-                                               const DTree *qt, uint32_t &t0, uint32_t &t1)
-{
-    auto dw = [&](uint32_t k) -> uint32_t { return k < ndw ? __builtin_bswap32(p32[k]) : 0u; };
-    uint32_t d[2], hi[2], lo[2], have[2], total[2] = {0, 0}, j[2] = {0, 0};
-    bool slow[2] = {false, false};
-    const uint64_t bb[2] = {b0, b1};
-#pragma unroll
-    for (uint32_t c = 0; c < 2; ++c) {
-        d[c] = (uint32_t)(bb[c] >> 5);
-        const uint32_t sh = (uint32_t)(bb[c] & 31);
-        const uint64_t w0 = (((uint64_t)dw(d[c]) << 32) | dw(d[c] + 1)) << sh;
-        hi[c] = (uint32_t)(w0 >> 32); lo[c] = (uint32_t)w0; have[c] = 64 - sh;
-        d[c] += 2;
-    }
-    if (!on1) j[1] = L;
-    const uint32_t ksh = 32 - T.K;
-    while (j[0] < L || j[1] < L) {
-        uint32_t ent[2];
-#pragma unroll
-        for (uint32_t c = 0; c < 2; ++c) ent[c] = j[c] < L ? T.len[((j[c] + 1) << T.K) + (hi[c] >> ksh)] : 0u;
-#pragma unroll
-        for (uint32_t c = 0; c < 2; ++c) {
-            if (j[c] >= L) continue;
-            uint32_t len = ent[c] & 15u;
-            if (!len) { slow[c] = true; j[c] = L; continue; }   // (finished below, the general way)
-            ++j[c];
-            if (ent[c] >> 4) { len += ent[c] >> 4; ++j[c]; }
-            hi[c] = len < 32 ? __builtin_amdgcn_alignbit(hi[c], lo[c], 32 - len) : lo[c];
-            lo[c] = len < 32 ? lo[c] << len : 0u;
-            have[c] -= len;
-            total[c] += len;
-            while (have[c] <= 32) {
-                const uint32_t x = dw(d[c]++);
-                hi[c] |= have[c] < 32 ? x >> have[c] : 0u;
-                lo[c] = have[c] ? x << (32 - have[c]) : 0u;
-                have[c] += 32;
-            }
-        }
-    }
-    t0 = slow[0] ? qs_record_len(p32, ndw, b0, L, T, qt) : total[0];
-    t1 = !on1 ? 0u : (slow[1] ? qs_record_len(p32, ndw, b1, L, T, qt) : total[1]);
-}
-
 // A: hop[b - q0] for the bit offsets q0 + [cov_lo, cov_hi) of a sub-block.  The stream's end is not known before it is
 // decoded; with two-bit bases it is at least (sub-block end - what the bases can take at most), which is what the first
 // phase covers; the chain kernel asks for more (records with transferred bases make the quality stream longer and the
@@ -1463,16 +1416,16 @@ __global__ __launch_bounds__(QS_THREADS) void k_dec_qspec_a(const uint8_t *sub, 
     const uint32_t ndw = (uint32_t)((nbits + 31) >> 5);
     uint16_t *h = hop + hop_off[s];
     const uint64_t cov_hi = C.cov_hi;
+    // (round 4, measured and not kept: two offsets per thread walked in lock-step, so that a lane keeps two table lookups in flight -
+    // 0.31 s against 0.21 per GB of 150-base reads: the second chain's registers and the lock-step's idle halves cost more than the
+    // overlap gains; profiles/r04_decode_two_chains_not_kept.txt)
 #pragma unroll 1
-    for (uint32_t o = 0; o < QS_PER_THREAD; o += 2) {
-        const uint64_t rel = first + threadIdx.x + (uint64_t)o * QS_THREADS, rel1 = rel + QS_THREADS;
+    for (uint32_t o = 0; o < QS_PER_THREAD; ++o) {
+        const uint64_t rel = first + threadIdx.x + (uint64_t)o * QS_THREADS;
         if (rel >= cov_hi) break;
-        const bool on1 = rel1 < cov_hi;
-        const uint64_t b = q0 + rel, b1 = q0 + rel1;
-        uint32_t t, t1;
-        qs_record_len2(p32, ndw, b, b1, on1, L, T, C.qt, t, t1);
+        const uint64_t b = q0 + rel;
+        const uint32_t t = qs_record_len(p32, ndw, b, L, T, C.qt);
         h[rel] = (t == ~0u || t >= QS_INVALID || b + t > nbits) ? (uint16_t)QS_INVALID : (uint16_t)t;
-        if (on1) h[rel1] = (t1 == ~0u || t1 >= QS_INVALID || b1 + t1 > nbits) ? (uint16_t)QS_INVALID : (uint16_t)t1;
     }
 }
 
