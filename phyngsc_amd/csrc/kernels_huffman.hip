@@ -303,6 +303,9 @@ template <> struct SmallTrees<false> { __device__ static TreeLdsSmall *get() { r
 // side chain beside the title statistics kernel, which fills every CU's LDS - and raise ERR_SHAPE if it does not (the step runs
 // again, with the LDS).
 template <bool SMALL>
+// (measured and not kept: amdgpu_waves_per_eu(5) / (6) for the register-resident tree build, which takes 97 VGPRs = four workgroups per
+// CU - five fit 90 registers: steps within +-1.5 %; six spill two registers and the scratch segment that brings makes the kernel 3.5x
+// slower alone; profiles/r04_ab_tree_kernel_occupancy.txt)
 __global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t has_lds)
 {
     if (*A.err) return;

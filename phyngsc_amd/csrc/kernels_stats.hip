@@ -127,6 +127,9 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
 // 36..300-base reads in 95 us, on the chain statistics -> trees -> measure with nothing beside it).  256 threads: a 1024-thread
 // form with the rows in four parts was faster alone and SLOWER in the step - beside the title statistics kernel a workgroup of
 // sixteen waves waited 200-300 us for a CU with room (kernel trace, profiles/r03_final_kernel_stats.csv history).
+// (round 4, measured and not kept: eight workgroups per sub-block adding up every eighth row each - atomics into row 0 - with the
+// last one to finish going on.  The release fence in front of the "I am done" counter writes the XCD's whole L2 back on this chip:
+// the kernel went from 0.011 to 0.092 ms and the 36-base step from 1.870 to 2.109; profiles/r04_ab_finalize_split_not_kept.txt)
 __global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
 {
     if (*A.err) return;
