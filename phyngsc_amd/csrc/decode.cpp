@@ -348,6 +348,9 @@ int ngsc_decompress_file(ngsc_ctx *c, const char *in_path, const char *out_path,
     for (uint32_t w = 0; w < F.PS; ++w) s_at[w] = std::min<uint64_t>(F.FS, (uint64_t)w * (F.FS / F.PS) + F.OV[w]);
     s_at[F.PS] = F.FS;
     for (uint32_t w = 0; w < F.PS; ++w) if (s_at[w + 1] < s_at[w]) { close(fd); return NGSC_ERR_FORMAT; }
+    // a footer that claims more text than any stream of this size can hold (a 1-base read under a 512-byte constant title is
+    // about 1 KiB of text for a few bits of streams) is refused before a byte of the output is reserved
+    if (F.FS > (size << 12) + (1ull << 20)) { close(fd); return NGSC_ERR_FORMAT; }
     const int ofd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (ofd < 0) { close(fd); return NGSC_ERR_IO; }
     // the file's size is known: its pages are reserved up front (as the compress driver does: preallocated page-cache pages take

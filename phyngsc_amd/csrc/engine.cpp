@@ -348,6 +348,35 @@ const ngsc_rank_t *ngsc_result_ranks(ngsc_ctx *c) { return c ? c->res_rank.data(
 // The whole path for ranks [rank_lo, rank_hi).  part != nullptr: ONE rank, walked in several calls (ngsc_compress_rank_part):
 // from tells where its loop stands (resume == 0: at its first record), the buffer may end before the rank does, and
 // *part receives where the loop stands afterwards.
+#ifdef NGSC_HOST_TIMING
+// developer build: where a call's host time goes (stderr, every 16 calls): outside = between the previous call's return and this
+// call's entry (the caller), first = entry -> first launch enqueued, enqueue = entry -> everything enqueued, wait = the one wait,
+// tail = wait over -> return
+namespace {
+struct HostTiming {
+    double t_entry = 0, t_first = 0, t_enq = 0, t_waited = 0, t_prev_ret = 0, acc[5] = {0, 0, 0, 0, 0};
+    int n = 0;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void done()
+    {
+        const double t_ret = now();
+        if (t_prev_ret > 0 && t_first > 0 && t_enq > 0 && t_waited > 0) {
+            acc[0] += t_entry - t_prev_ret; acc[1] += t_first - t_entry; acc[2] += t_enq - t_entry; acc[3] += t_waited - t_enq; acc[4] += t_ret - t_waited;
+            if (++n == 16) {
+                fprintf(stderr, "[host us] outside %.1f first %.1f enqueue %.1f wait %.1f tail %.1f\n", acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n);
+                n = 0; for (double &a : acc) a = 0;
+            }
+        }
+        t_prev_ret = t_ret; t_first = t_enq = t_waited = 0;
+    }
+};
+thread_local HostTiming g_ht;
+}
+#define HT(x) g_ht.x = HostTiming::now()
+#else
+#define HT(x) (void)0
+#endif
+
 static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
                          uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream,
                          const PlanResume &from, ngsc_rank_part_t *part)
@@ -405,7 +434,7 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
     RankPlan *d_plans = (RankPlan *)(sm + o_plans);
     Cut *d_cuts = (Cut *)(sm + o_cuts);
-    launch_zero_range(st, sm, o_first);   // (a kernel of ours: the runtime's fill kernel left the GPU idle for ~20 us behind it)
+    launch_zero_range(st, sm, o_first); HT(t_first);   // (a kernel of ours: the runtime's fill kernel left the GPU idle for ~20 us behind it)
 
     const uint32_t ntiles = index_num_tiles(len);
     // The record table is sized for the smallest possible record (5 bytes), so the line count never has to come back
@@ -773,7 +802,11 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (wide) { KScope k(c, st, "k_title_wide_measure"); launch_title_wide_measure(st, A, max_rec); }
     else { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if ((rc = join_s())) return rc;
-    if (R) { KScope k(c, st, "k_layout"); launch_layout(st, A, R, d_qrowoff, out_cap, d_outtot, d_done); }
+    // A predicted step whose output was cleared early as far as the previous job's reached has (almost always) nothing left to clear
+    // once its size is known: the layout kernel sees to that itself - up to 1 MiB beyond the early clearing is cleared by its last
+    // wave, more raises ERR_SHAPE - and the step saves a launch and its gap on the critical path (12 us)
+    const bool zero_by_layout = spec && R && out_prefix;
+    if (R) { KScope k(c, st, "k_layout"); launch_layout(st, A, R, d_qrowoff, out_cap, d_outtot, d_done, zero_by_layout ? d_out : nullptr, zero_by_layout ? out_prefix : 0); }
     else {
         { KScope k(c, st, "k_scan_sb"); launch_scan_sb(st, A); }
         { KScope k(c, st, "k_sizes_offsets"); launch_sizes_offsets(st, A, d_qrowoff, out_cap, d_outtot); }
@@ -785,8 +818,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     HIPCHK(c, hipMemcpyAsync(hp, A.sb, sb_bytes, hipMemcpyDeviceToHost, sts));
     HIPCHK(c, hipMemcpyAsync(h_small, sm, cs.off, hipMemcpyDeviceToHost, sts));
     // ---- pack ----
-    { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap, out_prefix); }
-    if (stagger) {   // the side stream's kernels write into the cleared output
+    if (!zero_by_layout) { KScope k(c, st, "k_zero_output"); launch_zero_output(st, d_out, d_outtot, out_cap, out_prefix); }
+    if (stagger && !zero_by_layout) {   // the side stream's kernels write into the cleared output (it follows the layout kernel already)
         HIPCHK(c, hipEventRecord(c->ev_fork, st));
         HIPCHK(c, hipStreamWaitEvent(sts, c->ev_fork, 0));
     }
@@ -820,15 +853,20 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- the one sync of a predicted step (the second of a synchronous one): error word, sizes, result tables ----
     uint8_t *hfin = h_small + cs.off + 64;
     HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));
+    HT(t_enq);
     {   // the step's one wait: polled for its first millisecond-scale stretch (a blocking wait wakes up 10-20 us after the copy
         // has landed - one percent of a step), then handed to the runtime
         const auto t_poll = std::chrono::steady_clock::now();
         hipError_t q;
         while ((q = hipStreamQuery(st)) == hipErrorNotReady)
             if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
-        if (q != hipSuccess && q != hipErrorNotReady) HIPCHK(c, q);
+        if (q != hipSuccess) HIPCHK(c, hipStreamSynchronize(st));
     }
-    HIPCHK(c, hipStreamSynchronize(st));
+    // (host time of a call, -DNGSC_HOST_TIMING: 4 us to the first launch, 125-145 us to enqueue the step, 6-13 us from here to the
+    // return - prefetching the pinned result lines did not change that - and 8-17 us in the Python caller: 25-35 of the ~47 us
+    // the GPU idles between two steps of the bench; the rest is the copy's completion reaching the host and the first launch
+    // reaching the GPU, profiles/r04_host_time_of_a_call.txt)
+    HT(t_waited);
     HIPCHK(c, hipGetLastError());
     const int32_t err3 = *(int32_t *)(h_small + o_err);   // state behind the layout kernels
     const int32_t err4 = *(int32_t *)hfin;
@@ -836,6 +874,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
         // the prediction did not hold (nothing was written behind k_init_sb): once more, reading the shape back
         c->shape.valid = 0;
         if (!spec) return NGSC_ERR_HIP;   // (the synchronous path sizes everything from the job's own numbers)
+#ifdef NGSC_HOST_TIMING
+        fprintf(stderr, "[host] the prediction did not hold: once more\n");
+#endif
         HIPCHK(c, hipStreamSynchronize(c->side_stream));
         return compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, part);
     }
@@ -954,10 +995,14 @@ extern "C" {
 int ngsc_compress_device(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint64_t buf_off, uint64_t file_size,
                          uint32_t P, uint32_t rank_lo, uint32_t rank_hi, void *d_out, uint64_t out_cap, void *hip_stream)
 {
+    HT(t_entry);
     PlanResume from;
     memset(&from, 0, sizeof from);
     const int rc = compress_impl(c, d_buf, buf_len, buf_off, file_size, P, rank_lo, rank_hi, d_out, out_cap, hip_stream, from, nullptr);
     if (rc != NGSC_OK && c && c->side_stream) (void)hipStreamSynchronize(c->side_stream);   // (the early clearing of d_out may still run)
+#ifdef NGSC_HOST_TIMING
+    g_ht.done();
+#endif
     return rc;
 }
 

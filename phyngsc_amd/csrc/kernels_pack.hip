@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_sizes(Arena A, uint32_t *qrow_off)
 // One wave: exclusive prefix sum of the sub-block sizes = their offsets in the output.
 // (fresh: the totals were written by other workgroups of the same launch - read them past the L1)
 template <bool FRESH>
-__device__ __forceinline__ void offsets_wave(const Arena &A, uint32_t lane, uint64_t out_cap, uint64_t *total_out)
+__device__ __forceinline__ uint64_t offsets_wave(const Arena &A, uint32_t lane, uint64_t out_cap, uint64_t *total_out)
 {
     uint64_t off = 0;
     for (uint32_t base = 0; base < A.n_sb; base += 64) {
@@ -219,6 +219,7 @@ __device__ __forceinline__ void offsets_wave(const Arena &A, uint32_t lane, uint
         *total_out = off;
         if (off > out_cap) atomicMin(A.err, (int32_t)ERR_CAPACITY);
     }
+    return off;
 }
 
 __global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint64_t *total_out)
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(64) void k_offsets(Arena A, uint64_t out_cap, uint6
 // step's critical path cost more in launch gaps than in work: a workgroup scans its sub-block's tile and group totals, its first
 // wave derives the stream sizes, and the workgroup that finishes last (a counter in the step's small state) lays the
 // sub-blocks out.
-__global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done)
+constexpr uint64_t LAYOUT_CLEARS = 1ull << 20;   // bytes one wave clears in passing (a few us per 100 KB)
+// zero_out / cleared (a predicted step): the output buffer and the bytes of it - a multiple of 16 - that were cleared early; what the
+// sub-blocks take beyond that is cleared here when it is little (the step then needs no k_zero_output), and is a missed prediction
+// when it is not.
+__global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done,
+                                                uint4 *zero_out, uint64_t cleared)
 {
     if (*A.err) return;
     __shared__ uint32_t s_wave[17];
@@ -254,7 +260,13 @@ __global__ __launch_bounds__(1024) void k_layout(Arena A, uint32_t R, uint32_t *
     last = (uint32_t)__shfl((int)last, 0);
     if (!last) return;
     __threadfence();
-    offsets_wave<true>(A, threadIdx.x, out_cap, total_out);
+    const uint64_t total = offsets_wave<true>(A, threadIdx.x, out_cap, total_out);
+    if (zero_out && total > cleared && total <= out_cap) {
+        if (total - cleared <= LAYOUT_CLEARS) {
+            for (uint64_t k = (cleared >> 4) + threadIdx.x; k < (total + 15) >> 4; k += 64) zero_out[k] = make_uint4(0, 0, 0, 0);
+        }
+        else if (threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -643,9 +655,11 @@ void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R)
     hipLaunchKernelGGL(k_scan_tile, dim3(A.n_sb), dim3(1024), 0, st, A, R);
 }
 
-void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done)
+void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done,
+                   void *zero_out, uint64_t cleared)
 {
-    hipLaunchKernelGGL(k_layout, dim3(A.n_sb), dim3(1024), 0, st, A, R, qrow_off, out_cap, total_out, done);
+    hipLaunchKernelGGL(k_layout, dim3(A.n_sb), dim3(1024), 0, st, A, R, qrow_off, out_cap, total_out, done, reinterpret_cast<uint4 *>(zero_out),
+                       cleared);
 }
 
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out)

@@ -47,7 +47,8 @@ void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);
 void launch_scan_sb(hipStream_t st, const Arena &A);
 void launch_scan_tile(hipStream_t st, const Arena &A, uint32_t R);   // (lane-per-record path: per-tile bit counts)
 void launch_sizes_offsets(hipStream_t st, const Arena &A, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out);
-void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done);   // scan_tile + sizes + offsets
+void launch_layout(hipStream_t st, const Arena &A, uint32_t R, uint32_t *qrow_off, uint64_t out_cap, uint64_t *total_out, uint32_t *done,
+                   void *zero_out = nullptr, uint64_t cleared = 0);   // scan_tile + sizes + offsets
 void launch_zero_output(hipStream_t st, void *d_out, const uint64_t *total_ptr, uint64_t out_cap, uint64_t cleared = 0);   // cleared: leading bytes that are zero already
 void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes);
 void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,

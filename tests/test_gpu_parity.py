@@ -414,6 +414,38 @@ def test_predicted_step_meets_what_its_probes_did_not_expect(eng):
         assert out == want
 
 
+def test_predicted_step_whose_output_outgrows_what_was_cleared(eng):
+    """A predicted step has its output cleared early as far as the context's last job's reached (+ 1/64) and leaves the rest to the layout
+    kernel: a little more (up to 1 MiB) is cleared by that kernel's last wave in passing, much more is a missed prediction (ERR_SHAPE on
+    the device, the step runs again).  Jobs of one shape whose qualities - and so whose sub-blocks - grow a little, then a lot, and
+    shrink again; the output buffer is full of ones before every call (the pack kernels OR their shared words into it)."""
+    n = 60000
+    rnd = np.random.default_rng(12)
+    seqs = rnd.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, 100))
+    noise = rnd.choice(np.frombuffer(b"#+5:>CFI", dtype=np.uint8), size=(n, 100))
+
+    def job(every):   # every k-th record with noisy qualities (0: none)
+        q = np.full((n, 100), ord("I"), dtype=np.uint8)
+        if every:
+            q[::every] = noise[::every]
+        return b"".join(b"@run7.%06d\n%s\n+\n%s\n" % (i, seqs[i].tobytes(), q[i].tobytes()) for i in range(n))
+
+    quiet, some, all_ = job(0), job(16), job(1)
+    assert len(quiet) == len(some) == len(all_)
+    want = {id(d): orc.compress_file(d, 4)[0] for d in (quiet, some, all_)}
+    out = torch.empty(len(quiet), dtype=torch.uint8, device="cuda")
+    sizes = []
+    for data in (quiet, quiet, some, quiet, all_, all_, quiet, some, some):
+        out.fill_(0xFF)
+        d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        res = eng.compress_device(d_in, len(data), 4, out=out)
+        sizes.append(res.total_bytes)
+        assert api.assemble_container(res, 4, len(data)) == want[id(data)]
+    # the third job outgrew the early clearing by less than the layout kernel's limit, the fifth by more
+    assert sizes[1] + sizes[1] // 64 < sizes[2] <= sizes[1] + sizes[1] // 64 + (1 << 20) - 64, sizes
+    assert sizes[4] > sizes[3] + sizes[3] // 64 + (1 << 20), sizes
+
+
 def test_error_numeric_overflow(eng):
     _expect_error(eng, _fq(400, title=lambda i: f"@r:{3_000_000_000 + i}"), 2, -5)
 
