@@ -772,13 +772,13 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     if (stagger) HIPCHK(c, hipStreamWaitEvent(st, c->ev_zero, 0));   // (the title kernels below read the table)
     if (zero_late && out_prefix && stagger) launch_zero_range(sts, d_out, out_prefix);
     else if (zero_late && out_prefix) launch_zero_range(st, d_out, out_prefix);
-    { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A); }
-    // (round 4) A predicted step launches the kernels that usually have nothing to do - the 512-symbol tree instance, the title's
-    // histograms and trees - WITHOUT their LDS when the context's last job gave them nothing to do: a lone workgroup then checks
-    // that this still holds and raises ERR_SHAPE if not (the step runs again, the synchronous way, with everything).  With their
-    // LDS, thousands of workgroups queued for 26-40 KB each on CUs that the title statistics kernel fills, to find out that they
-    // could leave: 14-150 us on the side chain, 20-100 + 25 on the title chain of a 36-base step.
     const bool big_lds = !spec || c->big_alphabets, hist_lds = !spec || (c->title_need & 3u) != 0, ttree_lds = hist_lds;
+    { KScope k(c, sts, "k_sq_finalize"); launch_sq_finalize(sts, A, !big_lds); }
+    // (round 4) A predicted step does NOT launch the kernels that usually have nothing to do - the 512-symbol tree instance, the
+    // title's histograms and trees - when the context's last job gave them nothing to do: the finalisation kernels in front of them
+    // raise ERR_SHAPE if this job does (the step runs again, the synchronous way, with everything).  Launched, thousands of
+    // workgroups queued for 26-40 KB of LDS each on CUs that the title statistics kernel fills, to find out that they could
+    // leave: 14-150 us on the side chain, 20-100 + 25 on the title chain of a 36-base step.
     { KScope k(c, sts, "k_huffman_sb"); launch_huffman_sq(sts, A, c->big_alphabets, big_lds); }
     // (round 4, measured and not kept: the payload measure kernel - the side chain's one throughput kernel - on a stream of ordinary
     // priority, so that the title chain's small kernels are not dispatched behind it: no change on 36-base reads, 3 % slower on
@@ -795,10 +795,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     else {
         if (t_swar) { KScope k(c, st, "k_title_stats_swar"); launch_title_stats_swar(st, A, max_rec, max_title); }
         else { KScope k(c, st, "k_title_stats_reg"); launch_title_stats_reg(st, A, max_rec); }
-        { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A); }
-        { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar, hist_lds); }
+        { KScope k(c, st, "k_field_finalize"); launch_field_finalize(st, A, !hist_lds); }
+        if (hist_lds) { KScope k(c, st, "k_title_hist"); launch_title_hist(st, A, max_rec, t_swar); }
     }
-    { KScope k(c, st, "k_huffman_title"); launch_huffman_title(st, A, ttree_lds); }
+    if (ttree_lds) { KScope k(c, st, "k_huffman_title"); launch_huffman_title(st, A); }
     if (wide) { KScope k(c, st, "k_title_wide_measure"); launch_title_wide_measure(st, A, max_rec); }
     else { KScope k(c, st, t_swar ? "k_title_measure_swar" : "k_title_measure_reg"); launch_title_measure_reg(st, A, max_rec, t_swar); }
     if ((rc = join_s())) return rc;
@@ -850,6 +850,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     }
     else { KScope k(c, st, "k_pack_sq"); launch_pack_sq(st, A, max_rec); }
     if ((rc = join_s())) return rc;
+    // (measured and not kept, profiles/r04_ab_fewer_events.txt: (1) no join here - either stream copies the error word behind its own
+    // last kernel, the host waits for both and takes the lower: no gain, 1.920 -> 1.920/1.932 ms per GB, 125 MB jobs 0.451 -> 0.455;
+    // (2) the zero arena - the context's own - cleared on the side stream from the step's first microsecond, without the event that
+    // holds it behind the index kernels: the planner starts 7 us earlier, the clearing slows the newline count beside it down by more)
     // ---- the one sync of a predicted step (the second of a synchronous one): error word, sizes, result tables ----
     uint8_t *hfin = h_small + cs.off + 64;
     HIPCHK(c, hipMemcpyAsync(hfin, d_err, 4, hipMemcpyDeviceToHost, st));

@@ -297,23 +297,23 @@ template <bool SMALL> struct SmallTrees {   // the small instance's static LDS (
     __device__ static TreeLdsSmall *get() { __shared__ TreeLdsSmall Ts[SMALL_TREES_PER_WG]; return Ts; }
 };
 template <> struct SmallTrees<false> { __device__ static TreeLdsSmall *get() { return nullptr; } };
-// (round 4) has_lds (the 512-symbol instance): the launch carries the tree's 26 KB of LDS.  A predicted step (engine.cpp) launches it
-// WITHOUT when the context's last job had no alphabet of more than 64 symbols: its workgroups then only look whether that still
-// holds - with the LDS they waited for a CU with 26 KB to spare just to find out that they had nothing to do, 14-150 us on the
-// side chain beside the title statistics kernel, which fills every CU's LDS - and raise ERR_SHAPE if it does not (the step runs
-// again, with the LDS).
+// (round 4) The 512-symbol instance's tree is DYNAMIC LDS, and a predicted step (engine.cpp) does not launch the instance at all when
+// the context's last job had no alphabet of more than 64 symbols (k_sq_finalize raises ERR_SHAPE if the job has one after all): with
+// static LDS its workgroups waited for a CU with 26 KB to spare just to find out that they had nothing to do, 14-150 us on the side
+// chain beside the title statistics kernel, which fills every CU's LDS.  (An LDS-less one-workgroup launch that only looked did that
+// job for most of the round; folding the look into the finalisation kernels takes three launches off a step: 125 MB jobs
+// 0.448 -> 0.438 ms, profiles/r04_ab_no_probe_launches.txt)
 template <bool SMALL>
 // (measured and not kept: amdgpu_waves_per_eu(5) / (6) for the register-resident tree build, which takes 97 VGPRs = four workgroups per
 // CU - five fit 90 registers: steps within +-1.5 %; six spill two registers and the scratch segment that brings makes the kernel 3.5x
 // slower alone; profiles/r04_ab_tree_kernel_occupancy.txt)
-__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt, uint32_t has_lds)
+__global__ __launch_bounds__(SMALL ? 64 * SMALL_TREES_PER_WG : 64) void k_huffman_sb(Arena A, uint32_t t0, uint32_t nt)
 {
     if (*A.err) return;
     // (the 512-symbol instance over quality / base trees only: nothing to do unless some alphabet is that big - its workgroups
     // used to find that out pair by pair, 40-60 dependent loads each: 35-64 us behind the small instance on the same stream)
     if (!SMALL && t0 + nt <= A.qrows + 1 && !*A.big_trees) return;
     if (!SMALL && t0 > A.qrows && !(*A.num_huff & 1u)) return;   // (numeric title fields only, none of them Huffman-coded)
-    if (!SMALL && !has_lds) { if (threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
     using Tree = typename std::conditional<SMALL, TreeLdsSmall, TreeLds>::type;
     constexpr uint32_t TPW = SMALL ? SMALL_TREES_PER_WG : 1;
     extern __shared__ __align__(16) uint8_t s_tree_dyn[];   // (the 512-symbol instance's tree: dynamic, so that a launch can do without)
@@ -331,14 +331,10 @@ constexpr uint32_t TEXT_GRID_Y = 64;
 
 // (round 4) ... and the numeric title fields' trees in the same launch (workgroups behind the text grid: t0 = first field tree, nt =
 // fields per sub-block, as in k_huffman_sb<false>): one kernel boundary less on the title chain.
-// has_lds: as in k_huffman_sb - without, the launch only checks that no title field needs a tree.
-__global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs, uint32_t t0, uint32_t nt, uint32_t has_lds)
+// (not launched by a predicted step whose context's last job had no title field that needs a tree: k_field_finalize)
+__global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs, uint32_t t0, uint32_t nt)
 {
     if (*A.err) return;
-    if (!has_lds) {
-        if ((*A.num_huff & 3u) && threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE);
-        return;
-    }
     extern __shared__ __align__(16) uint8_t s_tree_dyn[];
     TreeLds &T = *reinterpret_cast<TreeLds *>(s_tree_dyn);
     if (blockIdx.x >= text_wgs) {
@@ -372,34 +368,31 @@ __global__ __launch_bounds__(64) void k_huffman_text(Arena A, uint32_t text_wgs,
 }
 
 // big_grid: workgroups of the 512-symbol instance
-static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uint32_t t0, uint32_t nt, uint32_t big_grid = 1024, bool lds = true)
+static void launch_huffman_range(hipStream_t st, const Arena &A, bool small, uint32_t t0, uint32_t nt, uint32_t big_grid = 1024)
 {
     const uint32_t pairs = nt * A.n_sb;
     if (!pairs) return;
-    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt, 1u);
-    else if (lds) hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), sizeof(TreeLds), st, A, t0, nt, 1u);
-    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(1), dim3(64), 0, st, A, t0, nt, 0u);   // (one workgroup: a look at the flag)
+    if (small) hipLaunchKernelGGL(k_huffman_sb<true>, dim3((pairs + SMALL_TREES_PER_WG - 1) / SMALL_TREES_PER_WG), dim3(64 * SMALL_TREES_PER_WG), 0, st, A, t0, nt);
+    else hipLaunchKernelGGL(k_huffman_sb<false>, dim3(pairs < big_grid ? pairs : big_grid), dim3(64), sizeof(TreeLds), st, A, t0, nt);
 }
 
 // Two launches for the two chains of the staggered schedule (engine.cpp): quality / DNA trees need the
 // sequence/quality statistics only, the numeric title field trees the title statistics only.
-// big_lds false (a predicted step whose context has not met a big alphabet): the 512-symbol instance without its LDS, see k_huffman_sb
-void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected, bool big_lds)
+// with_big false (a predicted step whose context has not met a big alphabet): without the 512-symbol instance, see k_huffman_sb
+void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected, bool with_big)
 {
     launch_huffman_range(st, A, true, 0, A.qrows + 1);
     // (quality alphabets of more than 64 symbols are rare: a workgroup per CU - each needs 26 KB of LDS that the title statistics
     // kernel beside it is holding, and a thousand of them took 166 us to find out that they had nothing to do.  A context whose
     // last call met such an alphabet launches six per CU: the trees are real work then)
-    launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256, big_lds);
+    if (with_big) launch_huffman_range(st, A, false, 0, A.qrows + 1, big_expected ? 1536 : 256);
 }
 // text-field trees and numeric-field trees of the title, one launch
-// lds false (a predicted step whose context's last job had no title field that needs a tree): one workgroup without LDS that checks
-void launch_huffman_title(hipStream_t st, const Arena &A, bool lds)
+void launch_huffman_title(hipStream_t st, const Arena &A)
 {
     const uint32_t text_wgs = TEXT_TREES * TEXT_GRID_Y, pairs = A.fcap * A.n_sb;
     const uint32_t field_wgs = pairs < 1024 ? pairs : 1024;
-    if (lds) hipLaunchKernelGGL(k_huffman_text, dim3(text_wgs + field_wgs), dim3(64), sizeof(TreeLds), st, A, text_wgs, A.qrows + 1, A.fcap, 1u);
-    else hipLaunchKernelGGL(k_huffman_text, dim3(1), dim3(64), 0, st, A, text_wgs, A.qrows + 1, A.fcap, 0u);
+    hipLaunchKernelGGL(k_huffman_text, dim3(text_wgs + field_wgs), dim3(64), sizeof(TreeLds), st, A, text_wgs, A.qrows + 1, A.fcap);
 }
 
 }  // namespace ngsc

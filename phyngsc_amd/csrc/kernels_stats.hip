@@ -130,7 +130,9 @@ __global__ __launch_bounds__(SQ_THREADS) void k_seq_qual_stats(Arena A, uint32_t
 // (round 4, measured and not kept: eight workgroups per sub-block adding up every eighth row each - atomics into row 0 - with the
 // last one to finish going on.  The release fence in front of the "I am done" counter writes the XCD's whole L2 back on this chip:
 // the kernel went from 0.011 to 0.092 ms and the 36-base step from 1.870 to 2.109; profiles/r04_ab_finalize_split_not_kept.txt)
-__global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
+// small_only (a predicted step whose context's last job had no alphabet of more than 64 symbols): the 512-symbol tree instance is not
+// launched at all; a sub-block that needs it after all is a missed prediction (ERR_SHAPE: the step runs again, with it).
+__global__ __launch_bounds__(256) void k_sq_finalize(Arena A, uint32_t small_only)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.x;
@@ -194,12 +196,17 @@ __global__ __launch_bounds__(256) void k_sq_finalize(Arena A)
         sb.flags = flags;
         sb.lt_bits = bit_length(max_q);
         if (!nqual || !nsym) atomicMin(A.err, (int32_t)ERR_FORMAT);
-        if (nqual > SMALL_TREE || nsym > SMALL_TREE) atomicOr(A.big_trees, 1u);
+        if (nqual > SMALL_TREE || nsym > SMALL_TREE) {
+            atomicOr(A.big_trees, 1u);
+            if (small_only) atomicMin(A.err, (int32_t)ERR_SHAPE);
+        }
     }
 }
 
 // One thread per (sub-block, field).
-__global__ __launch_bounds__(64) void k_field_finalize(Arena A)
+// quiet (a predicted step whose context's last job had no title field with a histogram or a tree to build): the title's histogram and
+// tree kernels are not launched at all; a field that needs them after all is a missed prediction (ERR_SHAPE: the step runs again).
+__global__ __launch_bounds__(64) void k_field_finalize(Arena A, uint32_t quiet)
 {
     if (*A.err) return;
     const uint32_t s = blockIdx.x, f = threadIdx.x;
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(64) void k_field_finalize(Arena A)
         }
         const uint32_t want = (huff && d.n_sym > 1 ? 1u : 0u) | (!rc && d.kind == KIND_TEXT ? 2u : 0u);
         if (want & ~*A.num_huff) atomicOr(A.num_huff, want);
+        if (want && quiet) atomicMin(A.err, (int32_t)ERR_SHAPE);
     }
     // compact index among the non-constant fields (all lanes with f < nf are still here)
     unsigned long long ncm = __ballot(d.kind != KIND_CONST);
@@ -253,14 +261,13 @@ constexpr uint32_t NH_LDS_FIELDS = 8;
 constexpr uint32_t TH_BATCHES = 16;
 constexpr uint32_t TH_TEXT = 2, TH_ROWS = 16;
 
-// has_lds: the launch carries the counters' 40 KB of LDS; a predicted step whose context's last job had nothing to count launches ONE
-// workgroup without, which only checks that this still holds (ERR_SHAPE if not: the step runs again) - 2 450 workgroups that each
+// The counters' 40 KB of LDS are dynamic, and a predicted step whose context's last job had nothing to count does not launch the
+// kernel (k_field_finalize raises ERR_SHAPE if the job has something after all: the step runs again) - 2 450 workgroups that each
 // wait for 40 KB of LDS to find out that they have nothing to do took 20 us alone and 100 beside the payload measure kernel.
-__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches, uint32_t has_lds)
+__global__ __launch_bounds__(TS_THREADS) void k_title_hist(Arena A, uint32_t use_tv, uint32_t batches)
 {
     if (*A.err) return;
     if (!(*A.num_huff & 3u)) return;   // (no Huffman-coded number with more than one value, no text field in any sub-block - the usual title)
-    if (!has_lds) { if (threadIdx.x == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
     const uint32_t s = blockIdx.y;
     const SbState &sb = A.sb[s];
     const uint32_t slot_bias = sb.slot_bias;   // (read once: the stores below could alias A.sb)
@@ -459,17 +466,17 @@ void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec)
     hipLaunchKernelGGL(k_seq_qual_stats, grid, dim3(SQ_THREADS), lds, st, A, rows);
 }
 
-void launch_sq_finalize(hipStream_t st, const Arena &A)
+void launch_sq_finalize(hipStream_t st, const Arena &A, bool small_only)
 {
-    hipLaunchKernelGGL(k_sq_finalize, dim3(A.n_sb), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_sq_finalize, dim3(A.n_sb), dim3(256), 0, st, A, small_only ? 1u : 0u);
 }
 
-void launch_field_finalize(hipStream_t st, const Arena &A)
+void launch_field_finalize(hipStream_t st, const Arena &A, bool quiet)
 {
-    hipLaunchKernelGGL(k_field_finalize, dim3(A.n_sb), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_field_finalize, dim3(A.n_sb), dim3(64), 0, st, A, quiet ? 1u : 0u);
 }
 
-void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv, bool lds)
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv)
 {
     // batches of 255 records per workgroup: as many as leave the job ~2000 workgroups (a workgroup's batches are a serial chain of
     // loads, and its LDS histograms are flushed once), at most TH_BATCHES - the 16-bit text counters hold 255 * 16 records
@@ -477,8 +484,7 @@ void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool us
     batches = batches < 1 ? 1 : (batches > TH_BATCHES ? TH_BATCHES : batches);
     dim3 grid((max_rec + TS_OWNED * batches - 1) / (TS_OWNED * batches), A.n_sb);
     const size_t lds_bytes = 4 * ((size_t)NH_LDS_FIELDS * MAX_NUM_HUF + (size_t)NH_LDS_FIELDS * TS_THREADS + (size_t)TH_TEXT * TH_ROWS * 128);
-    if (lds) hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), lds_bytes, st, A, use_tv ? 1u : 0u, batches, 1u);
-    else hipLaunchKernelGGL(k_title_hist, dim3(1, 1), dim3(TS_THREADS), 0, st, A, use_tv ? 1u : 0u, batches, 0u);
+    hipLaunchKernelGGL(k_title_hist, grid, dim3(TS_THREADS), lds_bytes, st, A, use_tv ? 1u : 0u, batches);
 }
 
 }  // namespace ngsc

@@ -34,13 +34,13 @@ void launch_cs(hipStream_t st, const Arena &A, uint32_t max_rec, const uint8_t *
 
 // ---- kernels_stats.hip ----
 void launch_seq_qual_stats(hipStream_t st, const Arena &A, uint32_t max_rec);
-void launch_sq_finalize(hipStream_t st, const Arena &A);
-void launch_field_finalize(hipStream_t st, const Arena &A);
-void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv, bool lds = true);
+void launch_sq_finalize(hipStream_t st, const Arena &A, bool small_only = false);
+void launch_field_finalize(hipStream_t st, const Arena &A, bool quiet = false);
+void launch_title_hist(hipStream_t st, const Arena &A, uint32_t max_rec, bool use_tv);
 
 // ---- kernels_huffman.hip ----
-void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected = false, bool big_lds = true);   // quality / DNA trees (both instances)
-void launch_huffman_title(hipStream_t st, const Arena &A, bool lds = true);   // text-field and numeric-field trees of the title
+void launch_huffman_sq(hipStream_t st, const Arena &A, bool big_expected = false, bool with_big = true);   // quality / DNA trees (with_big: both instances)
+void launch_huffman_title(hipStream_t st, const Arena &A);   // text-field and numeric-field trees of the title
 
 // ---- kernels_pack.hip ----
 void launch_measure_sq(hipStream_t st, const Arena &A, uint32_t max_rec);

@@ -396,9 +396,9 @@ def test_titles_of_more_than_64_fields(eng):
 
 
 def test_predicted_step_meets_what_its_probes_did_not_expect(eng):
-    """A predicted step (the context's second job of a kind onwards) launches the title's histogram and tree kernels and the 512-symbol
-    tree instance WITHOUT their LDS when the context's last job gave them nothing to do; a job of the same size that does - a text
-    field that varies, a Huffman-coded number, a quality alphabet of more than 64 symbols - raises ERR_SHAPE on the device and the
+    """A predicted step (the context's second job of a kind onwards) does not launch the title's histogram and tree kernels and the
+    512-symbol tree instance when the context's last job gave them nothing to do; a job of the same size that does - a text field that
+    varies, a Huffman-coded number, a quality alphabet of more than 64 symbols - raises ERR_SHAPE in the finalisation kernels and the
     step runs again with everything (engine.cpp: big_lds / hist_lds / ttree_lds).  Same bytes as the oracle either way, in any order."""
     n = 6000
     quiet = "".join(f"@ab.{i:06d} k:100\nACGTACGTACGTACGTACGT\n+\n{'I' * 20}\n" for i in range(n)).encode()
