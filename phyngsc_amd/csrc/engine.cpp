@@ -434,7 +434,8 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     uint64_t *d_outtot = (uint64_t *)(sm + o_outtot), *d_first = (uint64_t *)(sm + o_first);
     RankPlan *d_plans = (RankPlan *)(sm + o_plans);
     Cut *d_cuts = (Cut *)(sm + o_cuts);
-    launch_zero_range(st, sm, o_first); HT(t_first);   // (a kernel of ours: the runtime's fill kernel left the GPU idle for ~20 us behind it)
+    // (the small state in front of the per-rank words is cleared by the step's first kernel, k_sync_first - by a kernel of ours in
+    // front of it when the call has many ranks; the runtime's fill kernel left the GPU idle for ~20 us behind it)
 
     const uint32_t ntiles = index_num_tiles(len);
     // The record table is sized for the smallest possible record (5 bytes), so the line count never has to come back
@@ -463,8 +464,9 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- stage A: line index ----
     {
         KScope k(c, st, "k_sync_first");
-        launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err, from.resume ? from.next_pos : 0);
+        launch_sync_first(st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, d_first, d_start, d_err, from.resume ? from.next_pos : 0, sm, o_first);
     }
+    HT(t_first);
     { KScope k(c, st, "k_nl_count"); launch_nl_count(st, buf, len, d_start, d_tiles, d_nlmask, buf_off + buf_len == file_size); }
     { KScope k(c, st, "k_scan_tiles"); launch_scan_tiles(st, d_tiles, ntiles, d_total); }
     { KScope k(c, st, "k_nl_write"); launch_nl_write(st, d_nlmask, len, d_start, d_tiles, d_te, d_se, d_ls, (uint32_t)rec_bound); }

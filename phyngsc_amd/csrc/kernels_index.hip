@@ -255,23 +255,28 @@ __device__ __forceinline__ void validate_records(const uint32_t *te, const uint3
 // the region start, then the first newline after it; if the byte after that newline is '@' the record
 // starts there, otherwise at the first '@'.  One wave per rank, 64 bytes per step.
 // resume_abs != 0: the rank is taken up at this file offset (the first record of its next window): nothing to search.
-__global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size,
-                                                   uint32_t P, uint32_t rank_lo, uint64_t *first_abs, uint32_t *start_rel,
-                                                   int32_t *err, uint64_t resume_abs)
+__global__ __launch_bounds__(64) void k_zero_words(uint32_t *p, uint32_t n)
 {
-    const uint32_t r = rank_lo + blockIdx.x;
-    const int lane = threadIdx.x;
+    for (uint32_t k = threadIdx.x; k < n; k += 64) p[k] = 0;
+}
+
+// b: the rank's index in the call (rank_lo + b is the rank), one wave.
+__device__ __forceinline__ void sync_first_rank(const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P, uint32_t rank_lo,
+                                                uint32_t b, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs)
+{
+    const uint32_t r = rank_lo + b;
+    const int lane = threadIdx.x & 63;
     if (resume_abs) {
         if (lane == 0) {
             if (resume_abs < buf_off || resume_abs - buf_off >= len) atomicMin(err, (int32_t)ERR_ARG);
-            first_abs[blockIdx.x] = resume_abs;
-            if (blockIdx.x == 0) *start_rel = (uint32_t)(resume_abs - buf_off);
+            first_abs[b] = resume_abs;
+            if (b == 0) *start_rel = (uint32_t)(resume_abs - buf_off);
         }
         return;
     }
     RankGeom g = rank_geometry(file_size, P, r);
     if (r == 0) {
-        if (lane == 0) { first_abs[blockIdx.x] = 0; if (blockIdx.x == 0) *start_rel = 0; }
+        if (lane == 0) { first_abs[b] = 0; if (b == 0) *start_rel = 0; }
         return;
     }
     int64_t rel0 = g.wr_start - (int64_t)buf_off;
@@ -295,12 +300,29 @@ __global__ __launch_bounds__(64) void k_sync_first(const uint8_t *buf, uint32_t 
         }
     }
     if (lane == 0) {
-        if (at < 0 || nl < 0) { atomicMin(err, (int32_t)ERR_FORMAT); first_abs[blockIdx.x] = 0; return; }
+        if (at < 0 || nl < 0) { atomicMin(err, (int32_t)ERR_FORMAT); first_abs[b] = 0; return; }
         // (the look at the byte behind the newline stays inside the rank's first window, like the two scans: phyNGSC.cpp:131-156)
         uint64_t res = (nl + 1 < (int64_t)limit && buf[nl + 1] == '@') ? (uint64_t)(nl + 1) : (uint64_t)at;
-        first_abs[blockIdx.x] = res + buf_off;
-        if (blockIdx.x == 0) *start_rel = (uint32_t)res;
+        first_abs[b] = res + buf_off;
+        if (b == 0) *start_rel = (uint32_t)res;
     }
+}
+
+// A wave per rank.  zero / n_zero (a call of up to SYNC_ONE_WG ranks: ONE workgroup): the words of the step's small state - the
+// error word first - are cleared here, in front of a workgroup barrier, instead of by a launch of their own in front of this one
+// (the head of a step is bound by the host's launches: 4 us each with the GPU waiting).
+constexpr uint32_t SYNC_ONE_WG = 64, SYNC_WAVES = 16;
+__global__ __launch_bounds__(64 * SYNC_WAVES) void k_sync_first(const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size,
+                                                                uint32_t P, uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel,
+                                                                int32_t *err, uint64_t resume_abs, uint32_t *zero, uint32_t n_zero)
+{
+    if (zero) {   // (gridDim.x == 1)
+        for (uint32_t k = threadIdx.x; k < n_zero; k += blockDim.x) zero[k] = 0;
+        __syncthreads();   // (workgroup-scope release / acquire: the stores have left for the L2 before any wave's atomic on the error word)
+    }
+    const uint32_t waves = blockDim.x >> 6;
+    for (uint32_t b = blockIdx.x * waves + (threadIdx.x >> 6); b < n_ranks; b += gridDim.x * waves)
+        sync_first_rank(buf, len, buf_off, file_size, P, rank_lo, b, first_abs, start_rel, err, resume_abs);
 }
 
 // plan_rank() search policy for a whole wave: 64 probes per round (a 2^21-record window needs 4 rounds instead of 21
@@ -563,11 +585,21 @@ __global__ __launch_bounds__(CV_THREADS) void k_cuts_validate(uint64_t file_size
 // ---- launchers ---------------------------------------------------------------------------------------
 uint32_t index_num_tiles(uint32_t len) { return len / TILE_BYTES + 1; }   // covers position len itself (assumed final newline)
 
+// zero / zero_bytes: the step's small state in front of the per-rank words (a multiple of 4 bytes), cleared by this launch when the
+// call has few ranks, by a launch of its own in front of it otherwise
 void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
-                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs)
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs,
+                       void *zero, size_t zero_bytes)
 {
-    hipLaunchKernelGGL(k_sync_first, dim3(n_ranks), dim3(64), 0, st, buf, len, buf_off, file_size, P, rank_lo, first_abs,
-                       start_rel, err, resume_abs);
+    if (n_ranks <= SYNC_ONE_WG) {
+        const uint32_t waves = n_ranks < SYNC_WAVES ? n_ranks : SYNC_WAVES;
+        hipLaunchKernelGGL(k_sync_first, dim3(1), dim3(64 * waves), 0, st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, first_abs,
+                           start_rel, err, resume_abs, reinterpret_cast<uint32_t *>(zero), (uint32_t)(zero_bytes / 4));
+        return;
+    }
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t *>(zero), (uint32_t)(zero_bytes / 4));
+    hipLaunchKernelGGL(k_sync_first, dim3(n_ranks), dim3(64), 0, st, buf, len, buf_off, file_size, P, rank_lo, n_ranks, first_abs,
+                       start_rel, err, resume_abs, (uint32_t *)nullptr, 0u);
 }
 
 void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask,

@@ -509,12 +509,13 @@ __global__ __launch_bounds__(256) void k_zero_range(uint4 *out, uint64_t n16)
 
 // SbState of every sub-block (rec_lo, n_rec, rank, slot_bias; the rest is zero already), its first title group and its first tile, from
 // the cut list the planner left on the device (engine.cpp built these on the host and copied them over until round 3).
-// One workgroup; a thread takes a rank: totals of its cuts, workgroup scan, then its cuts again.
+// One workgroup; a thread takes a cut: totals, workgroup scan, then the cuts again.
 // It also holds the job against the shape its arrays and grids were sized for (caps): the step may have been enqueued from a
 // PREDICTION of the planner's counts and the job's maxima (engine.cpp: JobShape) - another number of sub-blocks, more records,
 // slots, groups or tiles than there is room for, or a longer title / read / record than the kernels were chosen for raise
 // ERR_SHAPE, every kernel behind this one leaves at once, and the host runs the step again with the job's own numbers.
-__global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
+constexpr uint32_t INIT_THREADS = 256;   // (a job of eight ranks has ~300 cut slots: two rounds.  Not 1024: a workgroup of sixteen waves waits for a CU with that much room while the early clearing runs beside it - the 1 GB step lost 30 us that way)
+__global__ __launch_bounds__(INIT_THREADS) void k_init_sb(Arena A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
                                                  ShapeCaps caps, const uint32_t *total_lines, const uint32_t *max_title, const uint32_t *max_q,
                                                  const uint32_t *max_rec_bytes)
 {
@@ -527,19 +528,29 @@ __global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const
                  *max_rec_bytes > caps.max_rec_bytes) ? 1u : 0u;
     }
     __syncthreads();
+    // (round 4) a thread per CUT SLOT (rank i's k-th cut = cuts[i * max_cuts + k]; slots behind a rank's count are empty) instead of a
+    // thread per rank walking its cuts: eight threads with 15 cuts each were two chains of dependent loads, 14 us between the planner
+    // and the first statistics kernel of a 1 GB job
+    const uint32_t n_slot = n_ranks * max_cuts;
+    auto load = [&](uint32_t j, uint32_t v[4]) -> bool {   // v = {1, records, title groups, tiles} of slot j, zeros if it is empty
+        v[0] = v[1] = v[2] = v[3] = 0;
+        if (j >= n_slot) return false;
+        const uint32_t i = j / max_cuts, k = j - i * max_cuts;
+        const uint32_t nc = plans[i].n_cuts < max_cuts ? plans[i].n_cuts : max_cuts;
+        if (k >= nc) return false;
+        const uint32_t n = cuts[j].n_rec;
+        v[0] = 1; v[1] = n; v[2] = (n + GROUP - 1) / GROUP; v[3] = R ? (n + R - 1) / R : 0;
+        return true;
+    };
     {   // the planner's counts, before anything is written
         uint32_t s_cnt = 0, mr = 0;
         uint64_t sl = 0, gr = 0, tl = 0;
-        for (uint32_t i = tid; i < n_ranks; i += 256) {
-            const uint32_t nc = plans[i].n_cuts < max_cuts ? plans[i].n_cuts : max_cuts;
-            s_cnt += nc;
-            for (uint32_t k = 0; k < nc; ++k) {
-                const uint32_t n = cuts[(size_t)i * max_cuts + k].n_rec;
-                mr = n > mr ? n : mr;
-                sl += n;
-                gr += (n + GROUP - 1) / GROUP;
-                tl += R ? (n + R - 1) / R : 0;
-            }
+        for (uint32_t j = tid; j < n_slot; j += INIT_THREADS) {
+            uint32_t v[4];
+            load(j, v);
+            s_cnt += v[0];
+            mr = v[1] > mr ? v[1] : mr;
+            sl += v[1]; gr += v[2]; tl += v[3];
         }
         __shared__ uint32_t s_S;
         __shared__ unsigned long long s_sl, s_gr, s_tl;
@@ -554,18 +565,12 @@ __global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const
         if (s_bad) { if (tid == 0) atomicMin(A.err, (int32_t)ERR_SHAPE); return; }
     }
     // (the SbState array lies in the arena the engine clears for every call: only the non-zero words are written here)
-    __shared__ uint32_t s_w[4][4];
-    uint32_t base[4] = {0, 0, 0, 0};   // sub-blocks, record slots, title groups, tiles of the ranks in front (workgroup-uniform)
-    for (uint32_t r0 = 0; r0 < n_ranks; r0 += 256) {
-        const uint32_t i = r0 + tid;
-        const uint32_t nc = i < n_ranks ? (plans[i].n_cuts < max_cuts ? plans[i].n_cuts : max_cuts) : 0;
-        uint32_t v[4] = {nc, 0, 0, 0};
-        for (uint32_t k = 0; k < nc; ++k) {
-            const uint32_t n = cuts[(size_t)i * max_cuts + k].n_rec;
-            v[1] += n;
-            v[2] += (n + GROUP - 1) / GROUP;
-            v[3] += R ? (n + R - 1) / R : 0;
-        }
+    __shared__ uint32_t s_w[4][INIT_THREADS / 64];
+    uint32_t base[4] = {0, 0, 0, 0};   // sub-blocks, record slots, title groups, tiles of the slots in front (workgroup-uniform)
+    for (uint32_t j0 = 0; j0 < n_slot; j0 += INIT_THREADS) {
+        const uint32_t j = j0 + tid;
+        uint32_t v[4];
+        const bool have = load(j, v);
         uint32_t ex[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
@@ -579,32 +584,27 @@ __global__ __launch_bounds__(256) void k_init_sb(Arena A, const Cut *cuts, const
             ex[q] = incl - v[q];
         }
         __syncthreads();
-        uint32_t tot[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
-            tot[q] = 0;
+            uint32_t tot = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < 4; ++w) {
+            for (uint32_t w = 0; w < INIT_THREADS / 64; ++w) {
                 if (w < wave) ex[q] += s_w[q][w];
-                tot[q] += s_w[q][w];
+                tot += s_w[q][w];
             }
             ex[q] += base[q];
-            base[q] += tot[q];
+            base[q] += tot;
         }
         __syncthreads();   // s_w is written again in the next round
-        uint32_t s = ex[0], slot = ex[1], grp = ex[2], tile = ex[3];
-        for (uint32_t k = 0; k < nc && s < A.n_sb; ++k, ++s) {
-            const Cut c = cuts[(size_t)i * max_cuts + k];
-            SbState &x = A.sb[s];
+        if (have && ex[0] < A.n_sb) {
+            const Cut c = cuts[j];
+            SbState &x = A.sb[ex[0]];
             x.rec_lo = c.rec_lo;
             x.n_rec = c.n_rec;
             x.rank = c.rank;
-            x.slot_bias = slot - c.rec_lo;   // (mod 2^32)
-            A.grp_lo[s] = grp;
-            A.tile_lo[s] = tile;
-            slot += c.n_rec;
-            grp += (c.n_rec + GROUP - 1) / GROUP;
-            tile += R ? (c.n_rec + R - 1) / R : 0;
+            x.slot_bias = ex[1] - c.rec_lo;   // (mod 2^32)
+            A.grp_lo[ex[0]] = ex[2];
+            A.tile_lo[ex[0]] = ex[3];
         }
     }
 }
@@ -628,7 +628,7 @@ void launch_zero_range(hipStream_t st, void *d_out, uint64_t bytes)   // bytes: 
 void launch_init_sb(hipStream_t st, const Arena &A, const Cut *cuts, const RankPlan *plans, uint32_t n_ranks, uint32_t max_cuts, uint32_t R,
                     const ShapeCaps &caps, const uint32_t *total_lines, const uint32_t *max_title, const uint32_t *max_q, const uint32_t *max_rec_bytes)
 {
-    hipLaunchKernelGGL(k_init_sb, dim3(1), dim3(256), 0, st, A, cuts, plans, n_ranks, max_cuts, R, caps, total_lines, max_title, max_q, max_rec_bytes);
+    hipLaunchKernelGGL(k_init_sb, dim3(1), dim3(INIT_THREADS), 0, st, A, cuts, plans, n_ranks, max_cuts, R, caps, total_lines, max_title, max_q, max_rec_bytes);
 }
 
 static uint32_t lds_entries_for(uint32_t qrows)

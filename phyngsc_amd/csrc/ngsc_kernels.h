@@ -8,7 +8,8 @@ namespace ngsc {
 // ---- kernels_index.hip ----
 uint32_t index_num_tiles(uint32_t len);
 void launch_sync_first(hipStream_t st, const uint8_t *buf, uint32_t len, uint64_t buf_off, uint64_t file_size, uint32_t P,
-                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs);
+                       uint32_t rank_lo, uint32_t n_ranks, uint64_t *first_abs, uint32_t *start_rel, int32_t *err, uint64_t resume_abs,
+                       void *zero, size_t zero_bytes);   // (+ clears the step's small state)
 void launch_nl_count(hipStream_t st, const uint8_t *buf, uint32_t len, const uint32_t *start_rel, uint32_t *tile_cnt, uint32_t *nl_mask,
                      bool at_file_end);
 size_t index_mask_words(uint32_t len);

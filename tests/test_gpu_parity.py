@@ -261,6 +261,18 @@ def test_rank_split_invariance_and_repeatability(eng):
     assert sum(sb.n_records for sb in whole.subblocks) == n_rec
 
 
+def test_many_ranks_in_one_call(eng):
+    """Calls of more ranks than one workgroup of the first kernel takes (k_sync_first: a wave per rank, up to 64 ranks in the
+    workgroup that also clears the step's small state; more: a grid of them behind a clearing launch of its own) and than one round
+    of k_init_sb's cut slots: 65, 100 and 300 ranks over a file of 36-base reads, each twice (the second call is a predicted step)."""
+    data = fastq_gen.generate(fastq_gen.CFG2, target_bytes=12_000_000)
+    for P in (64, 65, 100, 300):
+        want, _ = orc.compress_file(data, P, threads=8)
+        for _ in range(2):
+            _, out = _gpu(eng, data, P)
+            assert out == want, P
+
+
 def test_rank_walked_in_parts(eng):
     """ngsc_compress_rank_part: a rank's region streamed through the engine in several buffers (the reference takes a
     region of any size through 8 MiB windows, phyNGSC.cpp:113-128, 168, 745-755; one engine job stays below 4 GiB).
