@@ -62,6 +62,7 @@ struct ngsc_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t side_stream = nullptr;          // the latency-bound kernels of the staggered schedule (high priority)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
+    std::vector<Cut> cuts_tmp;                  // a call's cut list while its result tables are made
     size_t zero_hint = 0;         // bytes of the zero-initialised arena the last call used: cleared while the host waits for the cut list
     uint64_t out_hint = 0;        // output bytes of the last call: that much of the output buffer is cleared beside the index kernels
     std::string hip_err;
@@ -868,10 +869,12 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
             if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(20)) break;
         if (q != hipSuccess) HIPCHK(c, hipStreamSynchronize(st));
     }
-    // (host time of a call, -DNGSC_HOST_TIMING: 4 us to the first launch, 125-145 us to enqueue the step, 6-13 us from here to the
-    // return - prefetching the pinned result lines did not change that - and 8-17 us in the Python caller: 25-35 of the ~47 us
+    // (host time of a call, -DNGSC_HOST_TIMING: 4 us to the first launch, 105-145 us to enqueue the step, 1-3 us from here to the
+    // return - 6-15 while the cut list below was a vector of the call's own - and 10-20 us in the Python caller: ~25 of the ~45 us
     // the GPU idles between two steps of the bench; the rest is the copy's completion reaching the host and the first launch
-    // reaching the GPU, profiles/r04_host_time_of_a_call.txt)
+    // reaching the GPU.  Reading the result tables once while the pack kernel still runs - they are in host memory by then, not
+    // in the host's caches - takes 1 us off the loops below and was not kept; the host thread on the GPU's NUMA node or the
+    // other: 105 against 111-118 us to enqueue a step, step times within 0.3 %; profiles/r04_host_time_of_a_call.txt)
     HT(t_waited);
     HIPCHK(c, hipGetLastError());
     const int32_t err3 = *(int32_t *)(h_small + o_err);   // state behind the layout kernels
@@ -921,7 +924,10 @@ static int compress_impl(ngsc_ctx *c, const void *d_buf, uint64_t buf_len, uint6
     // ---- results (the planner's tables came back with the small state) ----
     const RankPlan *h_plans = (const RankPlan *)(h_small + o_plans);
     const Cut *h_cuts = (const Cut *)(h_small + o_cuts);
-    std::vector<Cut> cuts;
+    // (the context's vector, not a local one: the first allocation behind the wait was 6-15 us of host time; -DNGSC_HOST_TIMING found
+    // it.  The caller's first allocation pays about as much instead - it is whoever allocates first behind the runtime's clean-up)
+    std::vector<Cut> &cuts = c->cuts_tmp;
+    cuts.clear();
     cuts.reserve(S);
     c->res_rank.resize(n_ranks);
     JobShape seen = g;   // what this job really looked like: the next call's prediction
