@@ -6,6 +6,7 @@
 // record's line start.  HBM-bound: 1 B read per input byte (twice: count + write), 12 B written per
 // record.  No MFMA - integer byte classification.
 #include "ngsc_kernels.h"
+#include "ngsc_swar.h"
 #include <cstdlib>
 
 namespace ngsc {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_nl_count(const uint8_t *buf, u
             uint4 v[PIECES];
 #pragma unroll
             for (uint32_t k = 0; k < PIECES; ++k)
-                v[k] = *reinterpret_cast<const uint4 *>(buf + wbase + (half * PIECES + k) * 1024u + lane * 16u);
+                v[k] = ld16_nt(buf + wbase + (half * PIECES + k) * 1024u + lane * 16u);   // (read once: ngsc_swar.h)
 #pragma unroll
             for (uint32_t k = 0; k < PIECES; ++k) {
                 const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};

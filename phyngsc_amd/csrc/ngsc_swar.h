@@ -28,6 +28,19 @@ __device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a,
     return make_uint2(w[0], w[1]);
 }
 
+// Bytes a kernel reads ONCE and nothing reads soon after: loads with the non-temporal policy (`nt`) leave the L2 and the Infinity Cache to
+// what is read again - masks, record tables.  The newline count reads the job that way: 0.212 -> 0.19 ms per GB of its own, the cut
+// planner behind it 0.075 -> 0.03-0.05 ms, the step 1.887 -> 1.814 ms per GB of 36-base reads, 1.108 -> 1.084 per 400 MB of 150-base
+// reads, 1.722 -> 1.688 of 36..300-base reads.  NOT the statistics kernels' reads of the same bytes (the sequence/quality kernel's
+// spans: 1.814 -> 1.839; the title kernel's chunks on top: no change): what they leave in the caches the next pass over the file
+// finds (profiles/r04_ab_nontemporal_loads.txt).
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld16_nt(const uint8_t *p)   // p: a multiple of 16
+{
+    const nt_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+
 struct __attribute__((packed, aligned(1))) U1u { uint32_t x; };
 __device__ __forceinline__ uint32_t load4_unaligned(const uint8_t *buf, uint32_t a) { return reinterpret_cast<const U1u *>(buf + a)->x; }
 
