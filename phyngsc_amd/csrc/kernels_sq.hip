@@ -24,6 +24,7 @@ namespace ngsc {
 
 // one 16-byte chunk of a record's bases or qualities: from the chunk-major copy the statistics kernel leaves (Arena::dstride) or the file
 struct __attribute__((packed, aligned(4))) U3a { uint32_t x, y, z; };
+template <bool NT = false>
 __device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *dense, uint32_t g, uint32_t off, uint32_t file_pos)
 {
     if (A.dstride) {
@@ -35,6 +36,7 @@ __device__ __forceinline__ uint4 sq_chunk_load(const Arena &A, const uint8_t *de
             const U3a v = *reinterpret_cast<const U3a *>(p);
             return make_uint4(v.x, v.y, v.z, 0);
         }
+        if (NT) return ld16_nt(dense + ((size_t)c * A.dstride + g) * 16);   // (the copies' last reader: ngsc_swar.h)
         return *reinterpret_cast<const uint4 *>(dense + ((size_t)c * A.dstride + g) * 16);
     }
     return load16_unaligned(A.buf, file_pos + off, A.buf_len);
@@ -1334,8 +1336,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     const uint32_t off = 16 * NB * c4 + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Qb[k] = sq_chunk_load(A, A.dense_q, g, off, q0);
-                        if (need_s) Sb[k] = sq_chunk_load(A, A.dense_s, g, off, s0);
+                        Qb[k] = sq_chunk_load<true>(A, A.dense_q, g, off, q0);
+                        if (need_s) Sb[k] = sq_chunk_load<true>(A, A.dense_s, g, off, s0);
                     }
                 }
 #pragma unroll
@@ -1345,15 +1347,15 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         } else {
             uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
             if (L) {
-                if (need_s) Sn = sq_chunk_load(A, A.dense_s, g, 0, s0);
-                Qn = sq_chunk_load(A, A.dense_q, g, 0, q0);
+                if (need_s) Sn = sq_chunk_load<true>(A, A.dense_s, g, 0, s0);
+                Qn = sq_chunk_load<true>(A, A.dense_q, g, 0, q0);
             }
             for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
                 const uint4 S = Sn, Q = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * ch + 16) {
-                    if (need_s) Sn = sq_chunk_load(A, A.dense_s, g, 16 * ch + 16, s0);
-                    Qn = sq_chunk_load(A, A.dense_q, g, 16 * ch + 16, q0);
+                    if (need_s) Sn = sq_chunk_load<true>(A, A.dense_s, g, 16 * ch + 16, s0);
+                    Qn = sq_chunk_load<true>(A, A.dense_q, g, 16 * ch + 16, q0);
                 }
                 chunk(ch, S, Q);
             }
@@ -1393,7 +1395,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 } else if (keeps) {
                     for (uint32_t ch = 0; 16 * ch < L; ++ch) {
                         const uint32_t nv = L - 16 * ch < 16 ? L - 16 * ch : 16;
-                        const uint4 S = sq_chunk_load(A, A.dense_s, g, 16 * ch, s0);
+                        const uint4 S = sq_chunk_load<true>(A, A.dense_s, g, 16 * ch, s0);
                         const uint32_t sw[4] = {S.x, S.y, S.z, S.w};
                         const uint32_t ambm = sr_amb_mask(sw, nv);
 #pragma unroll
@@ -1499,8 +1501,8 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         constexpr uint32_t NBX = BURST ? NB : 1u;   // chunks per trip, see k_sq_stats_reg
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
         if (!BURST && L) {
-            Sn = sq_chunk_load(A, A.dense_s, g, 0, s0);
-            Qn = sq_chunk_load(A, A.dense_q, g, 0, q0);
+            Sn = sq_chunk_load<true>(A, A.dense_s, g, 0, s0);
+            Qn = sq_chunk_load<true>(A, A.dense_q, g, 0, q0);
         }
         for (uint32_t w = 0; w < n_win; ++w) {
         const uint32_t r0 = w * win;
@@ -1517,16 +1519,16 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint32_t off = 16 * NBX * grp + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Sb[k] = sq_chunk_load(A, A.dense_s, g, off, s0);
-                        Qb[k] = sq_chunk_load(A, A.dense_q, g, off, q0);
+                        Sb[k] = sq_chunk_load<true>(A, A.dense_s, g, off, s0);
+                        Qb[k] = sq_chunk_load<true>(A, A.dense_q, g, off, q0);
                     }
                 }
             } else {
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * grp + 16) {
-                    Sn = sq_chunk_load(A, A.dense_s, g, 16 * grp + 16, s0);
-                    Qn = sq_chunk_load(A, A.dense_q, g, 16 * grp + 16, q0);
+                    Sn = sq_chunk_load<true>(A, A.dense_s, g, 16 * grp + 16, s0);
+                    Qn = sq_chunk_load<true>(A, A.dense_q, g, 16 * grp + 16, q0);
                 }
             }
 #pragma unroll
