@@ -1336,8 +1336,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                     const uint32_t off = 16 * NB * c4 + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Qb[k] = sq_chunk_load<true>(A, A.dense_q, g, off, q0);
-                        if (need_s) Sb[k] = sq_chunk_load<true>(A, A.dense_s, g, off, s0);
+                        Qb[k] = sq_chunk_load<BURST>(A, A.dense_q, g, off, q0);
+                        if (need_s) Sb[k] = sq_chunk_load<BURST>(A, A.dense_s, g, off, s0);
                     }
                 }
 #pragma unroll
@@ -1347,15 +1347,15 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
         } else {
             uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;   // the next chunk is loaded while the current one is processed
             if (L) {
-                if (need_s) Sn = sq_chunk_load<true>(A, A.dense_s, g, 0, s0);
-                Qn = sq_chunk_load<true>(A, A.dense_q, g, 0, q0);
+                if (need_s) Sn = sq_chunk_load<BURST>(A, A.dense_s, g, 0, s0);
+                Qn = sq_chunk_load<BURST>(A, A.dense_q, g, 0, q0);
             }
             for (uint32_t ch = 0; __any(16 * ch < L); ++ch) {
                 const uint4 S = Sn, Q = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * ch + 16) {
-                    if (need_s) Sn = sq_chunk_load<true>(A, A.dense_s, g, 16 * ch + 16, s0);
-                    Qn = sq_chunk_load<true>(A, A.dense_q, g, 16 * ch + 16, q0);
+                    if (need_s) Sn = sq_chunk_load<BURST>(A, A.dense_s, g, 16 * ch + 16, s0);
+                    Qn = sq_chunk_load<BURST>(A, A.dense_q, g, 16 * ch + 16, q0);
                 }
                 chunk(ch, S, Q);
             }
@@ -1395,7 +1395,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
                 } else if (keeps) {
                     for (uint32_t ch = 0; 16 * ch < L; ++ch) {
                         const uint32_t nv = L - 16 * ch < 16 ? L - 16 * ch : 16;
-                        const uint4 S = sq_chunk_load<true>(A, A.dense_s, g, 16 * ch, s0);
+                        const uint4 S = sq_chunk_load<BURST>(A, A.dense_s, g, 16 * ch, s0);
                         const uint32_t sw[4] = {S.x, S.y, S.z, S.w};
                         const uint32_t ambm = sr_amb_mask(sw, nv);
 #pragma unroll
@@ -1416,7 +1416,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_sq_measure_reg(Arena A, uint32_t
 }
 
 // ---- pack ----
-template <bool BURST>
+// NT: the chunk-major copies are read with non-temporal loads (long reads: ngsc_swar.h)
+template <bool BURST, bool NT>
 __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void k_sq_pack_reg(Arena A, uint32_t lds_rows, uint32_t sw_q, uint32_t sw_d, uint32_t tpw, uint32_t win)
 {
     // win != 0 (long reads): the table holds one WINDOW of win positions (rows r0 .. r0 + win, lds_rows = win + 1), refilled
@@ -1501,8 +1502,8 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         constexpr uint32_t NBX = BURST ? NB : 1u;   // chunks per trip, see k_sq_stats_reg
         uint4 Sn = make_uint4(0, 0, 0, 0), Qn = Sn;
         if (!BURST && L) {
-            Sn = sq_chunk_load<true>(A, A.dense_s, g, 0, s0);
-            Qn = sq_chunk_load<true>(A, A.dense_q, g, 0, q0);
+            Sn = sq_chunk_load<NT>(A, A.dense_s, g, 0, s0);
+            Qn = sq_chunk_load<NT>(A, A.dense_q, g, 0, q0);
         }
         for (uint32_t w = 0; w < n_win; ++w) {
         const uint32_t r0 = w * win;
@@ -1519,16 +1520,16 @@ __global__ __launch_bounds__(SR_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     const uint32_t off = 16 * NBX * grp + 16 * k;
                     Sb[k] = Qb[k] = make_uint4(0, 0, 0, 0);
                     if (L > off) {
-                        Sb[k] = sq_chunk_load<true>(A, A.dense_s, g, off, s0);
-                        Qb[k] = sq_chunk_load<true>(A, A.dense_q, g, off, q0);
+                        Sb[k] = sq_chunk_load<NT>(A, A.dense_s, g, off, s0);
+                        Qb[k] = sq_chunk_load<NT>(A, A.dense_q, g, off, q0);
                     }
                 }
             } else {
                 Sb[0] = Sn; Qb[0] = Qn;
                 Sn = Qn = make_uint4(0, 0, 0, 0);
                 if (L > 16 * grp + 16) {
-                    Sn = sq_chunk_load<true>(A, A.dense_s, g, 16 * grp + 16, s0);
-                    Qn = sq_chunk_load<true>(A, A.dense_q, g, 16 * grp + 16, q0);
+                    Sn = sq_chunk_load<NT>(A, A.dense_s, g, 16 * grp + 16, s0);
+                    Qn = sq_chunk_load<NT>(A, A.dense_q, g, 16 * grp + 16, q0);
                 }
             }
 #pragma unroll
@@ -1963,7 +1964,9 @@ void launch_sq_pack_reg(hipStream_t st, const Arena &A, uint32_t max_rec, uint32
     // is bound by its bit writers, not by the loads), so only that variant is built
     // (measured again with the chunks coming from the chunk-major copies: NB chunks per trip change nothing on 150-base and
     // mixed reads - 0.340 against 0.334 ms, 0.530 / 0.530 - and cost 16 % at 36 bases)
-    auto kern = k_sq_pack_reg<false>;
+    // (non-temporal loads of the copies where the reads are long: 150-base reads 0.282 -> 0.262 ms per 400 MB, 36..300-base reads
+    // 0.520 -> 0.478; at 36 bases the kernel gains nothing and the step loses 0.5 %)
+    auto kern = sr_burst(A) ? k_sq_pack_reg<false, true> : k_sq_pack_reg<false, false>;
     if (lds > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
     // (the tables: written by launch_sq_measure_reg's first kernel)
     hipLaunchKernelGGL(kern, grid, dim3(SR_THREADS), lds, st, A, rows, sw_q, sw_d, tpw, win);

@@ -33,8 +33,9 @@ __device__ __forceinline__ uint2 load8_unaligned(const uint8_t *buf, uint32_t a,
 // planner behind it 0.075 -> 0.03-0.05 ms, the step 1.887 -> 1.814 ms per GB of 36-base reads, 1.108 -> 1.084 per 400 MB of 150-base
 // reads, 1.722 -> 1.688 of 36..300-base reads.  NOT the statistics kernels' reads of the same bytes (the sequence/quality kernel's
 // spans: 1.814 -> 1.839; the title kernel's chunks on top: no change): what they leave in the caches the next pass over the file
-// finds (profiles/r04_ab_nontemporal_loads.txt).  The measure and pack kernels read the chunk-major copies that way too (kernels_sq.hip:
-// sq_chunk_load<true>): 150-base reads 1.109 -> 1.066 ms per 400 MB, 36..300-base reads 1.708 -> 1.648, 36-base reads unchanged.
+// finds (profiles/r04_ab_nontemporal_loads.txt).  The measure and pack kernels read the chunk-major copies that way too where the reads
+// are long (kernels_sq.hip: sq_chunk_load<true>): 150-base reads 1.109 -> 1.066 ms per 400 MB, 36..300-base reads 1.708 -> 1.648; at
+// 36 bases the kernels gain nothing and the measure kernel, beside the title kernels, takes 0.37 instead of 0.31 ms: left as it was.
 // Measured and not kept: non-temporal STORES for the early clearing of the output (36-base reads 1.806 -> 1.832: the pack kernel's
 // read-modify-writes find the zeros in the caches) and for the pack kernel's output words (no gain, 150-base reads 1.073 -> 1.093);
 // non-temporal loads of the title statistics kernel's chunks and of the newline masks in k_nl_write (within +-0.3 %).
