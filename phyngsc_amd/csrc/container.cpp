@@ -115,6 +115,9 @@ int ngsc_plan_blocks(uint32_t P, uint32_t wrid, const uint32_t *sb_sizes, uint32
             stream_pos += fill;
             open_start = stream_pos;
             written = S - fill;
+            // what is left of the sub-block must fit the next block: BCSS says "continues" for one block border only (the
+            // reference cannot meet such a sub-block - 8 MiB of FASTQ text never compress to more than a block)
+            if (written + header_size(bewr, floor_log2_plus1(written), 1) > W) return NGSC_ERR_UNSUPPORTED;
             stream_pos += written;
             bcss |= 2;                               // FSBS
             bcss &= ~1u;

@@ -90,6 +90,22 @@ def test_block_split_large_streams():
     assert b"".join(out) + footer == ref
 
 
+def test_block_split_refuses_a_sub_block_longer_than_two_blocks():
+    """BCSS marks a sub-block that continues over ONE block border (tasks.cpp:1179-1200).  One whose remainder would not fit
+    the next block either - nothing the engine produces, 8 MiB of FASTQ text never compress to more than a block, but the
+    planner is a public entry point - is refused instead of planned as a last block beyond 8 MiB (found by
+    tools/fuzz_host_parsers.py)."""
+    B = _lib.BLOCK_SIZE
+    for sizes in ([(1 << 32) - 1], [1000, 3 * B], [B - 100, 2 * B + 5, 7]):
+        with pytest.raises(api.NgscError) as e:
+            api.plan_blocks(8, 1, sizes)
+        assert e.value.code == -8   # NGSC_ERR_UNSUPPORTED
+    # ... while a remainder that just fits is still planned, every block within 8 MiB
+    blocks = api.plan_blocks(8, 1, [B - 100, B - 200, 5])
+    assert all(b.size <= B and b.size == b.header_len + b.payload for b in blocks)
+    assert sum(b.payload for b in blocks) == 2 * B - 295
+
+
 def test_make_header_matches_oracle():
     rng = np.random.default_rng(5)
     L = _lib.lib()
