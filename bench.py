@@ -292,6 +292,10 @@ def report(sh: Share, args, world, dt, total_raw, total_out, ktimes_all, dom, la
     }
     if extra_config:
         line["config"].update(extra_config)
+    if world > 1:
+        # the per-kernel tables of an N > 1 line are rank 0's GPU, profiled by itself in an untimed pass: they say nothing about
+        # contention on the other GPUs or on the host; the line's value and ms_per_step are the max-over-ranks wall time
+        line["config"]["kernel_tables_scope"] = "GPU of rank 0 alone, untimed pass (not the timed multi-GPU steps)"
     if world == 1 and not args.no_verify:
         out = api.assemble_container(res, sh.P, sh.file_size)
         man_path = os.path.join(ROOT, "tests", "golden", "manifest_cfg2_1GB.json")
