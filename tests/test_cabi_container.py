@@ -168,3 +168,16 @@ def test_read_footer_and_headers_of_reference_outputs(ngsc_path):
         assert L.ngsc_read_header(buf, len(blk), want.PS, ctypes.byref(got)) == 0
         assert (got.wrid, got.header_len, got.n_subblocks, got.bcss) == (w, hdr.BHS, hdr.NOSB, hdr.BCSS)
         assert list(got.sb_len)[:hdr.NOSB] == list(hdr.SBOL)
+
+
+def test_hostile_inputs_to_the_host_side_readers():
+    """tools/fuzz_host_parsers.py (the tool that runs under AddressSanitizer + UBSan in tools/asan_host.sh), a short run in the
+    ordinary build: damaged footers, block headers, block-size rows and sub-block size lists are refused or read consistently
+    (counts inside the capacities handed in, block owners below P, planned blocks within 8 MiB) and nothing crashes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_host_parsers.py"), "--n", "600", "--seed", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "no inconsistent acceptance" in r.stdout
