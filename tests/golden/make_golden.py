@@ -246,6 +246,25 @@ def small_cases():
         return "".join(out)
     add("qual_past_Q_with_N_36", wide_q_with_n(2400, 36), [2, 3])
     add("qual_past_Q_with_N_100", wide_q_with_n(1000, 100), [2])
+    # round 4, last session: the wide title kernels (more than 64 separators) pinned by the reference binary beyond 80 fields - 130
+    # fields (numeric ones that vary, text ones that vary in content and in length, constants) and 200 one- and two-character fields,
+    # both inside the reference's 500-byte record domain
+    rng7 = random.Random(20261009)
+
+    def wide_title(i, nf):
+        f = []
+        for k in range(nf - 1):
+            if k % 9 == 0:
+                f.append(str((i * (k + 3) + k) % (5 + k % 11)))                                  # numeric, varying
+            elif k % 13 == 5:
+                f.append("".join(rng7.choice("xyz") for _ in range(1 + (i + k) % 2)))            # text, varying length
+            elif k % 7 == 3:
+                f.append(rng7.choice("ab"))                                                      # text, varying content
+            else:
+                f.append("c")                                                                    # constant
+        return f"@W{i}:" + ":".join(f)
+    add("title_fields_130", "".join(rec(wide_title(i, 130), rand_seq(rng7, 36), rand_qual(rng7, 36)) for i in range(700)), [2, 3])
+    add("title_fields_200", "".join(rec(wide_title(i, 200), rand_seq(rng7, 30), rand_qual(rng7, 30)) for i in range(500)), [2])
     return cases
 
 
